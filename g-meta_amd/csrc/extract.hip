@@ -1,0 +1,592 @@
+// h-hop subgraph extraction, node sampling, induced-subgraph CSR build and batching on gfx950.
+// Replaces Subgraphs.generate_subgraph / generate_subgraph_link_pred (sdp.py:295-346) and
+// dgl.batch (sdp.py:399-406).  One workgroup per subgraph; the membership set is an LDS bitmap
+// over the parent graph's nodes, so the node list comes out in ascending order for free and
+// local ids are prefix popcounts.  Edge lists are read from HBM coalesced (wave per frontier node).
+#include <algorithm>
+#include "gm_internal.h"
+
+#define EX_BLOCK 512
+#define EX_WAVES (EX_BLOCK / GM_WAVE)
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t sample_salt(uint64_t seed, int g, int i, int j) {
+    uint32_t s = lowbias32((uint32_t)(seed & 0xffffffffu) ^ 0x9E3779B9u);
+    s = lowbias32(s ^ (uint32_t)(seed >> 32));
+    s = lowbias32(s + (uint32_t)g * 0x85EBCA6Bu);
+    s = lowbias32(s ^ (uint32_t)i);
+    s = lowbias32(s + (uint32_t)(j + 1) * 0xC2B2AE35u);
+    return s;
+}
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ bool bit_test(const uint32_t* bm, int v) { return (bm[v >> 5] >> (v & 31)) & 1u; }
+__device__ __forceinline__ void bit_set(uint32_t* bm, int v) { atomicOr(&bm[v >> 5], 1u << (v & 31)); }
+__device__ __forceinline__ int bit_rank(const uint32_t* bm, const uint32_t* pref, int v) {
+    return (int)pref[v >> 5] + __popc(bm[v >> 5] & ((1u << (v & 31)) - 1u));
+}
+
+// Exclusive scan of part[0..EX_BLOCK) in LDS by wave 0; returns the total through *total (LDS).
+__device__ __forceinline__ void scan_partials(int* part, int* total) {
+    __syncthreads();
+    if (threadIdx.x < GM_WAVE) {
+        const int l = threadIdx.x;
+        constexpr int PER = EX_BLOCK / GM_WAVE;
+        int loc[PER], s = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) { loc[k] = s; s += part[l * PER + k]; }
+        int inc = s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if (l >= o) inc += t; }
+        const int base = inc - s;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) part[l * PER + k] = base + loc[k];
+        if (l == 63) *total = inc;
+    }
+    __syncthreads();
+}
+
+// pref[w] = number of set bits in seen[0..w); returns the total.
+__device__ __forceinline__ int bitmap_prefix(const uint32_t* seen, uint32_t* pref, int W, int* part, int* total) {
+    const int chunk = (W + EX_BLOCK - 1) / EX_BLOCK;
+    const int w0 = threadIdx.x * chunk, w1 = min(W, w0 + chunk);
+    int s = 0;
+    for (int w = w0; w < w1; ++w) s += __popc(seen[w]);
+    part[threadIdx.x] = s;
+    scan_partials(part, total);
+    int run = part[threadIdx.x];
+    for (int w = w0; w < w1; ++w) { pref[w] = run; run += __popc(seen[w]); }
+    __syncthreads();
+    return *total;
+}
+
+struct ExStore {
+    const int64_t* node_off;
+    const int64_t* in_ptr; const int32_t* in_idx;
+    const int64_t* out_ptr; const int32_t* out_idx;
+};
+
+// Marks every in-neighbour of v (graph-local id) in `seen`; called by a whole wave.
+__device__ __forceinline__ void wave_mark_preds(const ExStore& S, int64_t base, int v, uint32_t* seen, int lane) {
+    const int64_t p0 = S.in_ptr[base + v], p1 = S.in_ptr[base + v + 1];
+    for (int64_t q = p0 + lane; q < p1; q += GM_WAVE) bit_set(seen, S.in_idx[q]);
+}
+
+// Phase A: node set (BFS or given), sampling, sorted node list, induced in/out degrees.
+__global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* seeds, int n_seeds, int h, int sample_n,
+                                                    uint64_t rng_seed, int link, const int32_t* given, const int64_t* given_off,
+                                                    int cap, int32_t* nodes_slab, int32_t* degi_slab, int32_t* dego_slab,
+                                                    int32_t* n_sub, int32_t* e_sub, int Wmax) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* seen = lds;
+    uint32_t* pref = lds + Wmax;              // doubles as the `expanded` bitmap during the BFS
+    int* part = (int*)(lds + 2 * Wmax);       // [EX_BLOCK]
+    uint32_t* hist = (uint32_t*)(part + EX_BLOCK);   // [256]
+    int* sc = (int*)(hist + 256);             // scalars: 0 total, 1 kk, 2 prefix, 3 edge count in, 4 edge count out
+    const int seed = blockIdx.x;
+    if (seed >= n_seeds) return;
+    const int g = seeds[seed].graph, ci = seeds[seed].i, cj = link ? seeds[seed].j : -1;
+    const int64_t base = S.node_off[g];
+    const int n = (int)(S.node_off[g + 1] - base);
+    const int W = (n + 31) >> 5;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+
+    for (int w = tid; w < W; w += EX_BLOCK) { seen[w] = 0; pref[w] = 0; }
+    if (tid < 8) sc[tid] = 0;
+    __syncthreads();
+    if (given) {
+        const int64_t a = given_off[seed], b = given_off[seed + 1];
+        for (int64_t k = a + tid; k < b; k += EX_BLOCK) bit_set(seen, given[k]);
+        __syncthreads();
+    } else {
+        const int H = link ? 2 : h;
+        const int64_t p0 = S.in_ptr[base + ci], p1 = S.in_ptr[base + ci + 1];
+        if (tid == 0) { bit_set(seen, ci); bit_set(pref, ci); }
+        for (int64_t q = p0 + tid; q < p1; q += EX_BLOCK) bit_set(seen, S.in_idx[q]);          // hop 1 (sdp.py:301,305,308)
+        __syncthreads();
+        if (H >= 2) {                                                                         // hop 2 (sdp.py:302,309)
+            for (int64_t q = p0 + wave; q < p1; q += EX_WAVES) {
+                const int v = S.in_idx[q];
+                int first = 0;
+                if (lane == 0) { const uint32_t bit = 1u << (v & 31); first = !(atomicOr(&pref[v >> 5], bit) & bit); }
+                first = __shfl(first, 0, 64);
+                if (first) wave_mark_preds(S, base, v, seen, lane);
+            }
+            __syncthreads();
+        }
+        if (H >= 3) {                                                                         // hop 3 (sdp.py:310)
+            for (int64_t q = p0 + wave; q < p1; q += EX_WAVES) {
+                const int v = S.in_idx[q];
+                const int64_t a = S.in_ptr[base + v], b = S.in_ptr[base + v + 1];
+                for (int64_t r = a; r < b; r += GM_WAVE) {
+                    int u = -1, first = 0;
+                    if (r + lane < b) {
+                        u = S.in_idx[r + lane];
+                        const uint32_t bit = 1u << (u & 31);
+                        first = !(atomicOr(&pref[u >> 5], bit) & bit);
+                    }
+                    unsigned long long m = __ballot(first);
+                    while (m) {
+                        const int src = __ffsll((long long)m) - 1;
+                        m &= m - 1;
+                        wave_mark_preds(S, base, __shfl(u, src, 64), seen, lane);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (link) {                                                                           // j side: 1 hop only (sdp.py:331-333)
+            if (tid == 0) bit_set(seen, cj);
+            const int64_t a = S.in_ptr[base + cj], b = S.in_ptr[base + cj + 1];
+            for (int64_t q = a + tid; q < b; q += EX_BLOCK) bit_set(seen, S.in_idx[q]);
+            __syncthreads();
+        }
+        // ---- count, and sample if above the threshold (strict '>' at sdp.py:312,337)
+        int c = 0;
+        for (int w = tid; w < W; w += EX_BLOCK) c += __popc(seen[w]);
+        c = wave_sum(c);
+        if (lane == 0) atomicAdd(&sc[0], c);
+        __syncthreads();
+        const int count = sc[0];
+        __syncthreads();
+        if (count > sample_n) {
+            // keep the sample_n nodes with the smallest key(node) = lowbias32(node ^ salt): 4-pass radix select.
+            const uint32_t salt = sample_salt(rng_seed, g, ci, cj);
+            if (tid == 0) { sc[1] = sample_n; sc[2] = 0; }
+            for (int pass = 0; pass < 4; ++pass) {
+                const int shift = 24 - 8 * pass;
+                for (int k = tid; k < 256; k += EX_BLOCK) hist[k] = 0;
+                __syncthreads();
+                const uint32_t prefix = (uint32_t)sc[2];
+                for (int w = tid; w < W; w += EX_BLOCK) {
+                    uint32_t bits = seen[w];
+                    while (bits) {
+                        const int b = __ffs(bits) - 1; bits &= bits - 1;
+                        const uint32_t key = lowbias32((uint32_t)(w * 32 + b) ^ salt);
+                        if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    int kk = sc[1], d = 0;
+                    while (d < 255 && (int)hist[d] < kk) { kk -= (int)hist[d]; ++d; }
+                    sc[1] = kk; sc[2] = (int)(prefix | ((uint32_t)d << shift));
+                }
+                __syncthreads();
+            }
+            const uint32_t tau = (uint32_t)sc[2];
+            for (int w = tid; w < W; w += EX_BLOCK) {
+                uint32_t bits = seen[w], keep = 0;
+                while (bits) {
+                    const int b = __ffs(bits) - 1; bits &= bits - 1;
+                    if (lowbias32((uint32_t)(w * 32 + b) ^ salt) <= tau) keep |= 1u << b;
+                }
+                seen[w] = keep;
+            }
+            __syncthreads();
+            if (tid == 0) { bit_set(seen, ci); if (cj >= 0) bit_set(seen, cj); }   // np.unique(np.append(., centres))
+            __syncthreads();
+        }
+    }
+    // ---- ascending node list + local-id prefix
+    const int ns = bitmap_prefix(seen, pref, W, part, &sc[0]);
+    if (ns > cap) { if (tid == 0) { n_sub[seed] = -ns; e_sub[seed] = 0; } return; }   // host reports the error
+    int32_t* nodes = nodes_slab + (int64_t)seed * cap;
+    for (int w = tid; w < W; w += EX_BLOCK) {
+        uint32_t bits = seen[w];
+        int r = pref[w];
+        while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; nodes[r++] = w * 32 + b; }
+    }
+    __syncthreads();
+    // ---- induced in/out degree of every selected node (wave per node)
+    int ein = 0, eout = 0;
+    for (int r = wave; r < ns; r += EX_WAVES) {
+        const int v = nodes[r];
+        int ci_ = 0, co_ = 0;
+        for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test(seen, S.in_idx[q]);
+        for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test(seen, S.out_idx[q]);
+        ci_ = wave_sum(ci_); co_ = wave_sum(co_);
+        if (lane == 0) { degi_slab[(int64_t)seed * cap + r] = ci_; dego_slab[(int64_t)seed * cap + r] = co_; }
+        ein += ci_; eout += co_;
+    }
+    if (lane == 0) { atomicAdd(&sc[3], ein); atomicAdd(&sc[4], eout); }
+    __syncthreads();
+    if (tid == 0) { n_sub[seed] = ns; e_sub[seed] = (sc[3] == sc[4]) ? sc[3] : -1; }
+}
+
+// In-block exclusive scan of deg[0..ns) (global) into ptr[row0 + r] = e0 + excl.
+__device__ __forceinline__ void scan_degrees(const int32_t* deg, int ns, int32_t* ptr_out, int e0, int* part, int* total) {
+    const int chunk = (ns + EX_BLOCK - 1) / EX_BLOCK;
+    const int r0 = threadIdx.x * chunk, r1 = min(ns, r0 + chunk);
+    int s = 0;
+    for (int r = r0; r < r1; ++r) s += deg[r];
+    part[threadIdx.x] = s;
+    scan_partials(part, total);
+    int run = e0 + part[threadIdx.x];
+    for (int r = r0; r < r1; ++r) { ptr_out[r] = run; run += deg[r]; }
+}
+
+// Ordered compaction of the neighbours of v that are inside the subgraph, remapped to batch rows.
+__device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t* idx, int64_t base, int v, const uint32_t* seen,
+                                              const uint32_t* pref, int row0, int32_t* out, int pos, int lane) {
+    const int64_t a = ptr[base + v], b = ptr[base + v + 1];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t q = a; q < b; q += GM_WAVE) {
+        int u = 0, hit = 0;
+        if (q + lane < b) { u = idx[q + lane]; hit = bit_test(seen, u); }
+        const unsigned long long m = __ballot(hit);
+        if (hit) out[pos + __popcll(m & lt)] = row0 + bit_rank(seen, pref, u);
+        pos += __popcll(m);
+    }
+}
+
+// Phase B: write the batched CSR (by destination and by source), parents, feature rows, norm, centres.
+__global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* seeds, int n_seeds, int link, int cap,
+                                                   const int32_t* nodes_slab, const int32_t* degi_slab, const int32_t* dego_slab,
+                                                   const int32_t* sub_off, const int32_t* sub_eoff, int32_t* parent, int32_t* feat_row,
+                                                   float* norm, int32_t* indptr, int32_t* indices, int32_t* indptr_t,
+                                                   int32_t* indices_t, int32_t* centre, int Wmax) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t* seen = lds;
+    uint32_t* pref = lds + Wmax;
+    int* part = (int*)(lds + 2 * Wmax);
+    int* sc = part + EX_BLOCK;
+    const int seed = blockIdx.x;
+    if (seed >= n_seeds) return;
+    const int g = seeds[seed].graph;
+    const int64_t base = S.node_off[g];
+    const int n = (int)(S.node_off[g + 1] - base);
+    const int W = (n + 31) >> 5;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const int row0 = sub_off[seed], ns = sub_off[seed + 1] - row0, e0 = sub_eoff[seed];
+    const int32_t* nodes = nodes_slab + (int64_t)seed * cap;
+    const int32_t* degi = degi_slab + (int64_t)seed * cap;
+    const int32_t* dego = dego_slab + (int64_t)seed * cap;
+
+    for (int w = tid; w < W; w += EX_BLOCK) seen[w] = 0;
+    __syncthreads();
+    for (int r = tid; r < ns; r += EX_BLOCK) {
+        const int v = nodes[r];
+        bit_set(seen, v);
+        parent[row0 + r] = v;
+        feat_row[row0 + r] = (int32_t)(base + v);
+        const int d = degi[r];
+        norm[row0 + r] = 1.0f / sqrtf((float)(d > 1 ? d : 1));          // in_degrees().clamp(min=1) ** -0.5 (learner.py:29)
+    }
+    __syncthreads();
+    bitmap_prefix(seen, pref, W, part, &sc[0]);
+    scan_degrees(degi, ns, indptr + row0, e0, part, &sc[0]);
+    scan_degrees(dego, ns, indptr_t + row0, e0, part, &sc[1]);
+    if (seed == n_seeds - 1 && tid == 0) { indptr[row0 + ns] = e0 + sc[0]; indptr_t[row0 + ns] = e0 + sc[1]; }
+    __syncthreads();
+    if (tid == 0) {
+        const int nc = link ? 2 : 1;
+        centre[seed * nc] = bit_rank(seen, pref, seeds[seed].i);
+        if (link) centre[seed * nc + 1] = bit_rank(seen, pref, seeds[seed].j);
+    }
+    for (int r = wave; r < ns; r += EX_WAVES) {
+        const int v = nodes[r];
+        wave_fill_row(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, indptr[row0 + r], lane);
+        wave_fill_row(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, indptr_t[row0 + r], lane);
+    }
+}
+
+__global__ void k_copy_add(int32_t* dst, const int32_t* src, int64_t n, int32_t add) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k] + add;
+}
+__global__ void k_gather_rows(const float* feat, const int32_t* feat_row, float* out, int64_t rows, int F) {
+    const int64_t total = rows * F;
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = k / F; const int f = (int)(k - r * F);
+        out[k] = feat[(int64_t)feat_row[r] * F + f];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host
+static void batch_free(gm_batch* b) {
+    hipStream_t s = b->stream;
+    gm_dev_free(b->d_sub_off, s); gm_dev_free(b->d_set_sub_off, s); gm_dev_free(b->d_set_row_off, s); gm_dev_free(b->d_graph, s);
+    gm_dev_free(b->d_parent, s); gm_dev_free(b->d_feat_row, s); gm_dev_free(b->d_indptr, s); gm_dev_free(b->d_indices, s);
+    gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
+    gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
+}
+
+// Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
+// fast weights), weight-gradient chunks are sized so that a batch yields roughly 768 blocks.
+int gm_batch_finalize(gm_batch* b, hipStream_t s) {
+    std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
+    for (int t = 0; t < b->sets; ++t)
+        for (int k = b->h_set_sub_off[t]; k < b->h_set_sub_off[t + 1]; ++k) sub_set[k] = t;
+    int64_t cr = (b->rows / 768 + 31) / 32 * 32;
+    cr = std::max<int64_t>(512, std::min<int64_t>(8192, cr));
+    for (int t = 0; t < b->sets; ++t) {
+        const int r0 = b->h_set_row_off[t], r1 = b->h_set_row_off[t + 1];
+        for (int r = r0; r < r1; r += GM_GEMM_BM) { tiles.push_back(t); tiles.push_back(r); tiles.push_back(std::min(GM_GEMM_BM, r1 - r)); }
+        for (int r = r0; r < r1; r += (int)cr) { chunks.push_back(t); chunks.push_back(r); chunks.push_back(std::min<int>((int)cr, r1 - r)); }
+        set_chunk_off[t + 1] = (int32_t)(chunks.size() / 3);
+    }
+    b->n_tiles = (int32_t)(tiles.size() / 3); b->n_chunks = (int32_t)(chunks.size() / 3);
+    GM_TRY(gm_alloc(&b->d_sub_set, sub_set.size(), s)); GM_TRY(gm_alloc(&b->d_tiles, tiles.size(), s));
+    GM_TRY(gm_alloc(&b->d_chunks, chunks.size(), s)); GM_TRY(gm_alloc(&b->d_set_chunk_off, set_chunk_off.size(), s));
+    GM_HIP(hipMemcpyAsync(b->d_sub_set, sub_set.data(), 4 * sub_set.size(), hipMemcpyHostToDevice, s));
+    if (!tiles.empty()) GM_HIP(hipMemcpyAsync(b->d_tiles, tiles.data(), 4 * tiles.size(), hipMemcpyHostToDevice, s));
+    if (!chunks.empty()) GM_HIP(hipMemcpyAsync(b->d_chunks, chunks.data(), 4 * chunks.size(), hipMemcpyHostToDevice, s));
+    GM_HIP(hipMemcpyAsync(b->d_set_chunk_off, set_chunk_off.data(), 4 * set_chunk_off.size(), hipMemcpyHostToDevice, s));
+    GM_HIP(hipStreamSynchronize(s));     // host vectors go out of scope
+    return GM_OK;
+}
+
+extern "C" void gm_batch_destroy(gm_batch_t* b) {
+    if (!b) return;
+    batch_free(b);
+    delete b;
+}
+
+static int batch_alloc(gm_batch* b, hipStream_t s) {
+    GM_TRY(gm_alloc(&b->d_sub_off, b->subs + 1, s)); GM_TRY(gm_alloc(&b->d_set_sub_off, b->sets + 1, s));
+    GM_TRY(gm_alloc(&b->d_set_row_off, b->sets + 1, s)); GM_TRY(gm_alloc(&b->d_graph, b->subs, s));
+    GM_TRY(gm_alloc(&b->d_parent, b->rows, s)); GM_TRY(gm_alloc(&b->d_feat_row, b->rows, s));
+    GM_TRY(gm_alloc(&b->d_indptr, b->rows + 1, s)); GM_TRY(gm_alloc(&b->d_indices, b->edges, s));
+    GM_TRY(gm_alloc(&b->d_indptr_t, b->rows + 1, s)); GM_TRY(gm_alloc(&b->d_indices_t, b->edges, s));
+    GM_TRY(gm_alloc(&b->d_centre, (size_t)b->subs * b->centres, s)); GM_TRY(gm_alloc(&b->d_norm, b->rows, s));
+    return GM_OK;
+}
+
+static int upload_small(gm_batch* b, hipStream_t s) {
+    GM_HIP(hipMemcpyAsync(b->d_sub_off, b->h_sub_off.data(), sizeof(int32_t) * (b->subs + 1), hipMemcpyHostToDevice, s));
+    GM_HIP(hipMemcpyAsync(b->d_set_sub_off, b->h_set_sub_off.data(), sizeof(int32_t) * (b->sets + 1), hipMemcpyHostToDevice, s));
+    GM_HIP(hipMemcpyAsync(b->d_set_row_off, b->h_set_row_off.data(), sizeof(int32_t) * (b->sets + 1), hipMemcpyHostToDevice, s));
+    GM_HIP(hipMemcpyAsync(b->d_graph, b->h_graph.data(), sizeof(int32_t) * b->subs, hipMemcpyHostToDevice, s));
+    return GM_OK;
+}
+
+static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets, int32_t n_sets,
+                        int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link, const int32_t* nodes_flat,
+                        const int64_t* nodes_off, void* stream, gm_batch_t** out) {
+    GM_REQUIRE(out, GM_EINVAL, "extract: out is NULL");
+    *out = nullptr;
+    GM_REQUIRE(store && seeds && set_offsets && n_seeds >= 1 && n_sets >= 1, GM_EINVAL, "extract: bad arguments");
+    GM_REQUIRE(set_offsets[0] == 0 && set_offsets[n_sets] == n_seeds, GM_EINVAL, "extract: set_offsets must span [0,n_seeds]");
+    const bool given = nodes_flat != nullptr;
+    if (!given) {
+        GM_REQUIRE(link || (h >= 1 && h <= 3), GM_EINVAL, "extract: h=%d unsupported (the reference defines h in {1,2,3}, sdp.py:300-311)", h);
+        GM_REQUIRE(sample_nodes >= 1, GM_EINVAL, "extract: sample_nodes must be >= 1");
+    }
+    int64_t cap = 1;
+    for (int k = 0; k < n_seeds; ++k) {
+        const gm_seed_t& sd = seeds[k];
+        GM_REQUIRE(sd.graph >= 0 && sd.graph < store->n_graphs, GM_EINVAL, "extract: seed %d: graph %d out of range", k, sd.graph);
+        const int64_t n = store->node_off[sd.graph + 1] - store->node_off[sd.graph];
+        GM_REQUIRE(sd.i >= 0 && sd.i < n, GM_EINVAL, "extract: seed %d: node %d out of range", k, sd.i);
+        GM_REQUIRE(!link || (sd.j >= 0 && sd.j < n), GM_EINVAL, "extract: seed %d: second node %d out of range", k, sd.j);
+        if (given) {
+            const int64_t a = nodes_off[k], b = nodes_off[k + 1];
+            GM_REQUIRE(b > a, GM_EINVAL, "from_nodes: subgraph %d is empty", k);
+            bool has_i = false, has_j = !link;
+            for (int64_t q = a; q < b; ++q) {
+                GM_REQUIRE(nodes_flat[q] >= 0 && nodes_flat[q] < n, GM_EINVAL, "from_nodes: node id out of range in subgraph %d", k);
+                GM_REQUIRE(q == a || nodes_flat[q] > nodes_flat[q - 1], GM_EINVAL, "from_nodes: subgraph %d not strictly ascending", k);
+                has_i |= nodes_flat[q] == sd.i; has_j |= nodes_flat[q] == sd.j;
+            }
+            GM_REQUIRE(has_i && has_j, GM_EINVAL, "from_nodes: subgraph %d does not contain its centre(s)", k);
+            cap = std::max<int64_t>(cap, b - a);
+        }
+    }
+    if (!given) cap = std::min<int64_t>(store->max_nodes, (int64_t)sample_nodes + 2);
+    const int Wmax = (int)((store->max_nodes + 31) >> 5);
+    const size_t lds_a = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 256 + 16);
+    GM_REQUIRE(lds_a <= 160 * 1024, GM_ERANGE,
+               "extract: parent graph with %lld nodes needs %zu B of LDS bitmap (> 160 KiB); global-bitmap path not implemented",
+               (long long)store->max_nodes, lds_a);
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GM_HIP(hipFuncSetAttribute((const void*)k_nodes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GM_HIP(hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx};
+
+    gm_seed_t* d_seeds = nullptr; int32_t *d_nodes = nullptr, *d_degi = nullptr, *d_dego = nullptr, *d_nsub = nullptr, *d_esub = nullptr;
+    int32_t* d_given = nullptr; int64_t* d_given_off = nullptr, *dummy = nullptr; (void)dummy;
+    int32_t* d_eoff = nullptr;
+    gm_batch* b = new gm_batch();
+    int rc = GM_OK;
+    auto cleanup = [&]() {
+        gm_dev_free(d_seeds, st); gm_dev_free(d_nodes, st); gm_dev_free(d_degi, st); gm_dev_free(d_dego, st);
+        gm_dev_free(d_nsub, st); gm_dev_free(d_esub, st); gm_dev_free(d_given, st); gm_dev_free(d_given_off, st); gm_dev_free(d_eoff, st);
+    };
+#define EX_TRY(x) do { rc = (x); if (rc != GM_OK) { cleanup(); batch_free(b); delete b; return rc; } } while (0)
+#define EX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm_set_error("%s: %s", #x, hipGetErrorString(e_)); cleanup(); batch_free(b); delete b; return GM_EHIP; } } while (0)
+    EX_TRY(gm_alloc(&d_seeds, n_seeds, st));
+    EX_TRY(gm_alloc(&d_nodes, (size_t)n_seeds * cap, st)); EX_TRY(gm_alloc(&d_degi, (size_t)n_seeds * cap, st));
+    EX_TRY(gm_alloc(&d_dego, (size_t)n_seeds * cap, st));
+    EX_TRY(gm_alloc(&d_nsub, n_seeds, st)); EX_TRY(gm_alloc(&d_esub, n_seeds, st));
+    EX_HIP(hipMemcpyAsync(d_seeds, seeds, sizeof(gm_seed_t) * n_seeds, hipMemcpyHostToDevice, st));
+    if (given) {
+        const int64_t tot = nodes_off[n_seeds];
+        EX_TRY(gm_alloc(&d_given, tot, st)); EX_TRY(gm_alloc(&d_given_off, n_seeds + 1, st));
+        EX_HIP(hipMemcpyAsync(d_given, nodes_flat, sizeof(int32_t) * tot, hipMemcpyHostToDevice, st));
+        EX_HIP(hipMemcpyAsync(d_given_off, nodes_off, sizeof(int64_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_nodes, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
+                       d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax);
+    EX_HIP(hipGetLastError());
+    std::vector<int32_t> nsub(n_seeds), esub(n_seeds);
+    EX_HIP(hipMemcpyAsync(nsub.data(), d_nsub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
+    EX_HIP(hipMemcpyAsync(esub.data(), d_esub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
+    EX_HIP(hipStreamSynchronize(st));
+
+    b->store = store; b->subs = n_seeds; b->sets = n_sets; b->centres = link ? 2 : 1; b->stream = st;
+    b->h_sub_off.assign(n_seeds + 1, 0); b->h_graph.resize(n_seeds);
+    std::vector<int32_t> eoff(n_seeds + 1, 0);
+    int64_t rows = 0, edges = 0;
+    for (int k = 0; k < n_seeds; ++k) {
+        if (nsub[k] <= 0 || esub[k] < 0) {
+            gm_set_error("extract: subgraph %d failed on device (nodes=%d, edges=%d, cap=%lld)", k, nsub[k], esub[k], (long long)cap);
+            cleanup(); batch_free(b); delete b; return GM_ERANGE;
+        }
+        rows += nsub[k]; edges += esub[k];
+        if (rows > INT32_MAX - 2 || edges > INT32_MAX - 2) {
+            gm_set_error("extract: batch exceeds 2^31 rows/edges; split the meta-batch"); cleanup(); batch_free(b); delete b; return GM_ERANGE;
+        }
+        b->h_sub_off[k + 1] = (int32_t)rows; eoff[k + 1] = (int32_t)edges; b->h_graph[k] = seeds[k].graph;
+    }
+    b->rows = rows; b->edges = edges;
+    b->h_set_sub_off.assign(set_offsets, set_offsets + n_sets + 1);
+    b->h_set_row_off.resize(n_sets + 1);
+    for (int s = 0; s <= n_sets; ++s) b->h_set_row_off[s] = b->h_sub_off[set_offsets[s]];
+    EX_TRY(batch_alloc(b, st));
+    EX_TRY(upload_small(b, st));
+    EX_TRY(gm_alloc(&d_eoff, n_seeds + 1, st));
+    EX_HIP(hipMemcpyAsync(d_eoff, eoff.data(), sizeof(int32_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
+    const size_t lds_b = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 16);
+    hipLaunchKernelGGL(k_fill, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
+                       b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t,
+                       b->d_indices_t, b->d_centre, Wmax);
+    EX_HIP(hipGetLastError());
+    EX_HIP(hipStreamSynchronize(st));   // eoff (host vector) must outlive the async copy; also surfaces kernel faults here
+    EX_TRY(gm_batch_finalize(b, st));
+    cleanup();
+#undef EX_TRY
+#undef EX_HIP
+    *out = b;
+    return GM_OK;
+}
+
+extern "C" int gm_extract(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets, int32_t n_sets,
+                          int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link_pred, void* stream, gm_batch_t** out) {
+    return extract_impl(store, seeds, n_seeds, set_offsets, n_sets, h, sample_nodes, rng_seed, link_pred, nullptr, nullptr, stream, out);
+}
+
+extern "C" int gm_batch_from_nodes(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets,
+                                   int32_t n_sets, const int32_t* nodes_flat, const int64_t* nodes_off, int32_t link_pred, void* stream,
+                                   gm_batch_t** out) {
+    GM_REQUIRE(nodes_flat && nodes_off, GM_EINVAL, "from_nodes: node lists are NULL");
+    return extract_impl(store, seeds, n_seeds, set_offsets, n_sets, 1, 1, 0, link_pred, nodes_flat, nodes_off, stream, out);
+}
+
+extern "C" int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, void* stream, gm_batch_t** out) {
+    GM_REQUIRE(out, GM_EINVAL, "concat: out is NULL");
+    *out = nullptr;
+    GM_REQUIRE(parts && n_parts >= 1, GM_EINVAL, "concat: no parts");
+    hipStream_t st = (hipStream_t)stream;
+    gm_batch* b = new gm_batch();
+    b->store = parts[0]->store; b->centres = parts[0]->centres; b->stream = st;
+    int64_t rows = 0, edges = 0, subs = 0, sets = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (!parts[p] || parts[p]->store != b->store || parts[p]->centres != b->centres) {
+            delete b; gm_set_error("concat: part %d has a different store or centre count", p); return GM_EINVAL;
+        }
+        rows += parts[p]->rows; edges += parts[p]->edges; subs += parts[p]->subs; sets += parts[p]->sets;
+    }
+    if (rows > INT32_MAX - 2 || edges > INT32_MAX - 2) { delete b; gm_set_error("concat: batch exceeds 2^31 rows/edges"); return GM_ERANGE; }
+    b->rows = rows; b->edges = edges; b->subs = (int32_t)subs; b->sets = (int32_t)sets;
+    b->h_sub_off.assign(1, 0); b->h_set_sub_off.assign(1, 0); b->h_set_row_off.assign(1, 0);
+    int rc = batch_alloc(b, st);
+    if (rc != GM_OK) { batch_free(b); delete b; return rc; }
+    int64_t r0 = 0, e0 = 0; int32_t s0 = 0;
+    auto cpy = [&](int32_t* dst, const int32_t* src, int64_t n, int32_t add) {
+        if (n <= 0) return;
+        const int blocks = (int)std::min<int64_t>(1024, (n + 255) / 256);
+        hipLaunchKernelGGL(k_copy_add, dim3(blocks), dim3(256), 0, st, dst, src, n, add);
+    };
+    for (int p = 0; p < n_parts; ++p) {
+        const gm_batch* q = parts[p];
+        cpy(b->d_parent + r0, q->d_parent, q->rows, 0); cpy(b->d_feat_row + r0, q->d_feat_row, q->rows, 0);
+        cpy((int32_t*)b->d_norm + r0, (const int32_t*)q->d_norm, q->rows, 0);
+        cpy(b->d_indptr + r0, q->d_indptr, q->rows + (p == n_parts - 1 ? 1 : 0), (int32_t)e0);
+        cpy(b->d_indptr_t + r0, q->d_indptr_t, q->rows + (p == n_parts - 1 ? 1 : 0), (int32_t)e0);
+        cpy(b->d_indices + e0, q->d_indices, q->edges, (int32_t)r0); cpy(b->d_indices_t + e0, q->d_indices_t, q->edges, (int32_t)r0);
+        cpy(b->d_centre + (int64_t)s0 * b->centres, q->d_centre, (int64_t)q->subs * b->centres, 0);
+        for (int k = 1; k <= q->subs; ++k) b->h_sub_off.push_back((int32_t)(r0 + q->h_sub_off[k]));
+        for (int k = 1; k <= q->sets; ++k) { b->h_set_sub_off.push_back(s0 + q->h_set_sub_off[k]); b->h_set_row_off.push_back((int32_t)(r0 + q->h_set_row_off[k])); }
+        b->h_graph.insert(b->h_graph.end(), q->h_graph.begin(), q->h_graph.end());
+        r0 += q->rows; e0 += q->edges; s0 += q->subs;
+    }
+    if (hipGetLastError() != hipSuccess) { batch_free(b); delete b; gm_set_error("concat: copy kernel launch failed"); return GM_EHIP; }
+    rc = upload_small(b, st);
+    if (rc == GM_OK && hipStreamSynchronize(st) != hipSuccess) { gm_set_error("concat: stream sync failed"); rc = GM_EHIP; }
+    if (rc == GM_OK) rc = gm_batch_finalize(b, st);
+    if (rc != GM_OK) { batch_free(b); delete b; return rc; }
+    *out = b;
+    return GM_OK;
+}
+
+extern "C" int gm_batch_dims(const gm_batch_t* b, int64_t* rows, int64_t* edges, int32_t* subs, int32_t* sets, int32_t* centres) {
+    GM_REQUIRE(b, GM_EINVAL, "batch_dims: NULL batch");
+    if (rows) *rows = b->rows; if (edges) *edges = b->edges; if (subs) *subs = b->subs; if (sets) *sets = b->sets;
+    if (centres) *centres = b->centres;
+    return GM_OK;
+}
+
+static int field_ptr(const gm_batch_t* b, int32_t field, void** p, int64_t* bytes) {
+    switch (field) {
+        case GM_F_SUB_OFF: *p = b->d_sub_off; *bytes = 4ll * (b->subs + 1); break;
+        case GM_F_SET_SUB_OFF: *p = b->d_set_sub_off; *bytes = 4ll * (b->sets + 1); break;
+        case GM_F_PARENT: *p = b->d_parent; *bytes = 4ll * b->rows; break;
+        case GM_F_GRAPH: *p = b->d_graph; *bytes = 4ll * b->subs; break;
+        case GM_F_INDPTR: *p = b->d_indptr; *bytes = 4ll * (b->rows + 1); break;
+        case GM_F_INDICES: *p = b->d_indices; *bytes = 4ll * b->edges; break;
+        case GM_F_INDPTR_T: *p = b->d_indptr_t; *bytes = 4ll * (b->rows + 1); break;
+        case GM_F_INDICES_T: *p = b->d_indices_t; *bytes = 4ll * b->edges; break;
+        case GM_F_CENTRE: *p = b->d_centre; *bytes = 4ll * b->subs * b->centres; break;
+        case GM_F_NORM: *p = b->d_norm; *bytes = 4ll * b->rows; break;
+        case GM_F_FEAT_ROW: *p = b->d_feat_row; *bytes = 4ll * b->rows; break;
+        default: gm_set_error("unknown batch field %d", field); return GM_EINVAL;
+    }
+    return GM_OK;
+}
+
+extern "C" int gm_batch_read(const gm_batch_t* b, int32_t field, void* host_dst, int64_t bytes) {
+    GM_REQUIRE(b && host_dst, GM_EINVAL, "batch_read: NULL argument");
+    void* p; int64_t need;
+    GM_TRY(field_ptr(b, field, &p, &need));
+    GM_REQUIRE(bytes >= need, GM_EINVAL, "batch_read: destination holds %lld bytes, field needs %lld", (long long)bytes, (long long)need);
+    GM_HIP(hipMemcpyAsync(host_dst, p, (size_t)need, hipMemcpyDeviceToHost, b->stream));
+    GM_HIP(hipStreamSynchronize(b->stream));
+    return GM_OK;
+}
+
+extern "C" int gm_batch_device_ptr(const gm_batch_t* b, int32_t field, void** dptr) {
+    GM_REQUIRE(b && dptr, GM_EINVAL, "batch_device_ptr: NULL argument");
+    int64_t bytes;
+    return field_ptr(b, field, dptr, &bytes);
+}
+
+extern "C" int gm_gather_features(const gm_batch_t* b, float* x_out, void* stream) {
+    GM_REQUIRE(b && x_out, GM_EINVAL, "gather_features: NULL argument");
+    const int F = b->store->feat_dim;
+    const int64_t total = b->rows * F;
+    const int blocks = (int)std::min<int64_t>(256 * 8, (total + 255) / 256);
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->store->d_feat, b->d_feat_row, x_out, b->rows, F);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}

@@ -1,0 +1,321 @@
+// Dense feature x W update of GraphConv (learner.py:36,47: torch.matmul(feat, weight)) and its two
+// backward GEMMs, grouped by task because every task carries its own fast weights (meta.py:126,151).
+// Exact fp32 on the CDNA4 matrix cores: v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain), so the
+// 1e-4 tolerance on logits/meta-grads holds without a reduced-precision path.  MFMA-bound, not HBM-bound
+// (43-64 flop/B at the arxiv config): reported as MFMA utilisation, separately from the aggregate.
+#include <algorithm>
+#include "gm_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BK 16
+#define AS_LD 20            // 16 + 4 pad (keeps 16-B alignment of every row)
+
+struct GemmK {
+    const float* A; int64_t lda; const float* B; int64_t b_stride; int transB; float* C; int64_t ldc; int K, N;
+    const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
+    const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec;
+};
+
+// Block tile 128 x (64*WC); 2 x WC waves, each wave a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks.
+template <int WC>
+__global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
+    constexpr int NT = 128 * WC, BN = 64 * WC, BS_LD = BN + 4;
+    __shared__ __attribute__((aligned(16))) float As[GM_GEMM_BM * AS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * BS_LD];
+    // XCD-aware: hardware block b -> XCD b%8; make logical ids contiguous per XCD so that the column
+    // tiles of one row tile (which share the A rows) and neighbouring row tiles share an L2.
+    const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
+    const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb / g.n_col_tiles, ct = lb % g.n_col_tiles;
+    const int set = g.tiles[tile * 3], row0 = g.tiles[tile * 3 + 1], nrows = g.tiles[tile * 3 + 2];
+    const int n0 = ct * BN;
+    const float* Bp = g.B + (int64_t)set * g.b_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, kh = lane >> 5;
+    const bool kvec = g.a_vec, nvec = g.b_vec;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr int A_PER = (GM_GEMM_BM * BK / 4 + NT - 1) / NT;   // float4 per thread for the A tile
+    constexpr int B_PER = (BK * BN / 4) / NT;                     // == 2
+    float4 ra[A_PER], rb[B_PER];
+
+    auto load_tiles = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int id = tid + p * NT;
+            const int rr = id >> 2, c4 = (id & 3) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id < GM_GEMM_BM * BK / 4 && rr < nrows) {
+                const float* src = g.A + (int64_t)(row0 + rr) * g.lda + k0 + c4;
+                if (kvec) { if (k0 + c4 < g.K) v = *reinterpret_cast<const float4*>(src); }
+                else {
+                    if (k0 + c4 + 0 < g.K) v.x = src[0];
+                    if (k0 + c4 + 1 < g.K) v.y = src[1];
+                    if (k0 + c4 + 2 < g.K) v.z = src[2];
+                    if (k0 + c4 + 3 < g.K) v.w = src[3];
+                }
+            }
+            ra[p] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int id = tid + p * NT;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!g.transB) {
+                const int kk = id / (BN / 4), n = n0 + (id % (BN / 4)) * 4;
+                if (k0 + kk < g.K) {
+                    const float* src = Bp + (int64_t)(k0 + kk) * g.N + n;
+                    if (nvec) { if (n < g.N) v = *reinterpret_cast<const float4*>(src); }
+                    else {
+                        if (n + 0 < g.N) v.x = src[0];
+                        if (n + 1 < g.N) v.y = src[1];
+                        if (n + 2 < g.N) v.z = src[2];
+                        if (n + 3 < g.N) v.w = src[3];
+                    }
+                }
+            } else {   // B[k][n] = W[n][k], W stored [N][K]: read along k
+                const int n = n0 + (id >> 2), c4 = (id & 3) * 4;
+                if (n < g.N) {
+                    const float* src = Bp + (int64_t)n * g.K + k0 + c4;
+                    if (nvec) { if (k0 + c4 < g.K) v = *reinterpret_cast<const float4*>(src); }
+                    else {
+                        if (k0 + c4 + 0 < g.K) v.x = src[0];
+                        if (k0 + c4 + 1 < g.K) v.y = src[1];
+                        if (k0 + c4 + 2 < g.K) v.z = src[2];
+                        if (k0 + c4 + 3 < g.K) v.w = src[3];
+                    }
+                }
+            }
+            rb[p] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int id = tid + p * NT;
+            if (id < GM_GEMM_BM * BK / 4) *reinterpret_cast<float4*>(&As[(id >> 2) * AS_LD + (id & 3) * 4]) = ra[p];
+        }
+#pragma unroll
+        for (int p = 0; p < B_PER; ++p) {
+            const int id = tid + p * NT;
+            if (!g.transB) {
+                *reinterpret_cast<float4*>(&Bs[(id / (BN / 4)) * BS_LD + (id % (BN / 4)) * 4]) = rb[p];
+            } else {
+                const int n = id >> 2, c4 = (id & 3) * 4;
+                Bs[(c4 + 0) * BS_LD + n] = rb[p].x; Bs[(c4 + 1) * BS_LD + n] = rb[p].y;
+                Bs[(c4 + 2) * BS_LD + n] = rb[p].z; Bs[(c4 + 3) * BS_LD + n] = rb[p].w;
+            }
+        }
+    };
+
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        const bool more = k0 + BK < g.K;
+        if (more) load_tiles(k0 + BK);                 // global loads for the next chunk fly under the MFMAs
+        // A fragments: lane (li,kh) takes k = 8q + 4kh + r  (r = 0..3) of its row -> MFMA step 4q + r
+        float4 af[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+                af[i][qq] = *reinterpret_cast<const float4*>(&As[(wr * 64 + i * 32 + li) * AS_LD + qq * 8 + kh * 4]);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int kk = qq * 8 + kh * 4 + rr;
+                const float b0 = Bs[kk * BS_LD + wc * 64 + li], b1 = Bs[kk * BS_LD + wc * 64 + 32 + li];
+                const float a0 = rr == 0 ? af[0][qq].x : rr == 1 ? af[0][qq].y : rr == 2 ? af[0][qq].z : af[0][qq].w;
+                const float a1 = rr == 0 ? af[1][qq].x : rr == 1 ? af[1][qq].y : rr == 2 ? af[1][qq].z : af[1][qq].w;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (more) { store_tiles(); __syncthreads(); }
+    }
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int rl = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (rl >= nrows) continue;
+            const int64_t row = row0 + rl;
+            const float sc = g.row_scale ? g.row_scale[row] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wc * 64 + j * 32 + li;
+                if (col >= g.N) continue;
+                float v = acc[i][j][e] * sc;
+                if (biasp) v += biasp[col];
+                if (g.relu) v = v > 0.f ? v : 0.f;
+                if (g.mask_h && !(g.mask_h[row * g.ldc + col] > 0.f)) v = 0.f;
+                g.C[row * g.ldc + col] = v;
+            }
+        }
+    }
+}
+
+int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
+    if (a.n_tiles <= 0) return GM_OK;
+    GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
+            a.tiles, a.n_tiles, 0, 0, 0};
+    g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
+    g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
+    if (a.N > 128) {
+        g.n_col_tiles = (a.N + 255) / 256;
+        hipLaunchKernelGGL((k_gemm_nn<4>), dim3(g.n_tiles * g.n_col_tiles), dim3(512), 0, s, g);
+    } else if (a.N > 64) {
+        g.n_col_tiles = 1;
+        hipLaunchKernelGGL((k_gemm_nn<2>), dim3(g.n_tiles), dim3(256), 0, s, g);
+    } else {
+        g.n_col_tiles = 1;
+        hipLaunchKernelGGL((k_gemm_nn<1>), dim3(g.n_tiles), dim3(128), 0, s, g);
+    }
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient: dW[K,N] = sum_rows a_scale[row] * A[row,:]^T G[row,:],  db[N] = sum_rows Gb[row,:].
+// The reduction runs over the (huge, ragged) row dimension, so it is the MFMA k dimension here:
+// both operands are read in their natural row-major layout (lane i of a half-wave reads 32
+// consecutive floats of one row).  One block per row chunk accumulates the whole K x N tile grid
+// in registers (8 waves x up to 8 MFMA 32x32 tiles); chunk partials are reduced in a second,
+// deterministic pass (no float atomics).
+#define WG_THREADS 512
+#define WG_WAVES 8
+#define WG_MAXT 8
+
+struct WgradK {
+    const float* A; int64_t lda; int K; const int32_t* a_row;   // optional row indirection for A (feature gather)
+    const float* G; int64_t ldg; int N; const float* Gb; int64_t ldgb;
+    const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN;
+};
+
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int ldA = w.TK * 32, ldG = w.TN * 32;
+    float* As = sm;                       // [RK][ldA]  (scaled, zero padded)
+    float* Gs = sm + (size_t)w.RK * ldA;  // [RK][ldG]
+    const int chunk = blockIdx.x, zt = blockIdx.y;     // zt: group of 64 output tiles
+    const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int TT = w.TK * w.TN;
+    f32x16 acc[WG_MAXT];
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // thread accumulates db[tid + 512*j] (only zt == 0; N <= 2048)
+    const float* Gb = w.Gb ? w.Gb : w.G;
+    const int64_t ldgb = w.Gb ? w.ldgb : w.ldg;
+
+    for (int r0 = 0; r0 < nrows; r0 += w.RK) {
+        const int nr = min(w.RK, nrows - r0);
+        for (int id = tid; id < w.RK * ldA; id += WG_THREADS) {
+            const int rr = id / ldA, k = id - rr * ldA;
+            float v = 0.f;
+            if (rr < nr && k < w.K) {
+                const int64_t row = row0 + r0 + rr;
+                const int64_t ar = w.a_row ? w.a_row[row] : row;
+                v = w.A[ar * w.lda + k] * (w.a_scale ? w.a_scale[row] : 1.f);
+            }
+            As[id] = v;
+        }
+        for (int id = tid; id < w.RK * ldG; id += WG_THREADS) {
+            const int rr = id / ldG, n = id - rr * ldG;
+            Gs[id] = (rr < nr && n < w.N) ? w.G[(int64_t)(row0 + r0 + rr) * w.ldg + n] : 0.f;
+        }
+        if (zt == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = tid + j * WG_THREADS;
+                if (n < w.N) for (int rr = 0; rr < nr; ++rr) bsum[j] += Gb[(int64_t)(row0 + r0 + rr) * ldgb + n];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < WG_MAXT; ++t) {
+            const int tt = zt * (WG_WAVES * WG_MAXT) + t * WG_WAVES + wave;
+            if (tt < TT) {
+                const int tk = tt / w.TN, tn = tt - tk * w.TN;
+                const float* ap = As + tk * 32 + li;
+                const float* gp = Gs + tn * 32 + li;
+                for (int kk = 0; kk < w.RK; kk += 2)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(kk + kh) * ldA], gp[(kk + kh) * ldG], acc[t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    float* out = w.partial + (int64_t)chunk * (w.K + 1) * w.N;
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t) {
+        const int tt = zt * (WG_WAVES * WG_MAXT) + t * WG_WAVES + wave;
+        if (tt < TT) {
+            const int tk = tt / w.TN, tn = tt - tk * w.TN;
+            const int n = tn * 32 + li;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                if (k < w.K && n < w.N) out[(int64_t)k * w.N + n] = acc[t][e];
+            }
+        }
+    }
+    if (zt == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int n = tid + j * WG_THREADS; if (n < w.N) out[(int64_t)w.K * w.N + n] = bsum[j]; }
+    }
+}
+
+// out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
+__global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
+                               float* db, int64_t db_stride) {
+    const int set = blockIdx.y;
+    const int c0 = set_chunk_off[set], c1 = set_chunk_off[set + 1];
+    const int tot = KN + N;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < tot; j += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = c0; c < c1; ++c) s += partial[(int64_t)c * tot + j];
+        if (j < KN) dW[(int64_t)set * dw_stride + j] = s;
+        else if (db) db[(int64_t)set * db_stride + (j - KN)] = s;
+    }
+}
+
+int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
+    if (a.n_chunks <= 0) return GM_OK;
+    WgradK w{};
+    w.A = a.A; w.lda = a.lda; w.K = a.K; w.a_row = a.a_row; w.G = a.G; w.ldg = a.ldg; w.N = a.N; w.Gb = a.Gb; w.ldgb = a.ldgb;
+    w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
+    w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
+    const int ld = (w.TK + w.TN) * 32;
+    w.RK = ld <= 768 ? 32 : ld <= 1536 ? 16 : 8;
+    const size_t lds = (size_t)w.RK * ld * sizeof(float);
+    GM_REQUIRE(lds <= 160 * 1024, GM_ERANGE, "wgrad: K=%d N=%d needs %zu B of LDS", a.K, a.N, lds);
+    static bool attr = false;
+    if (!attr) { GM_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    const int zgroups = (w.TK * w.TN + WG_WAVES * WG_MAXT - 1) / (WG_WAVES * WG_MAXT);
+    hipLaunchKernelGGL(k_wgrad, dim3(a.n_chunks, zgroups), dim3(WG_THREADS), lds, s, w);
+    GM_HIP(hipGetLastError());
+    const int tot = (a.K + 1) * a.N;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(std::min(64, (tot + 255) / 256), a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+                       a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}

@@ -1,0 +1,156 @@
+// Internal declarations shared by the HIP translation units of libgmeta_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/gmeta_hip.h"
+
+#define GM_WAVE 64
+#define GM_NXCD 8
+
+void gm_set_error(const char* fmt, ...);
+
+#define GM_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            gm_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return GM_EHIP;                                                                       \
+        }                                                                                         \
+    } while (0)
+#define GM_REQUIRE(cond, code, ...)  \
+    do {                             \
+        if (!(cond)) {               \
+            gm_set_error(__VA_ARGS__); \
+            return (code);           \
+        }                            \
+    } while (0)
+#define GM_TRY(call)            \
+    do {                        \
+        int r__ = (call);       \
+        if (r__ != GM_OK) return r__; \
+    } while (0)
+
+struct gm_store {
+    int32_t n_graphs = 0, feat_dim = 0;
+    int64_t total_nodes = 0, total_edges = 0, max_nodes = 0;
+    std::vector<int64_t> node_off, edge_off;      // host prefix sums per graph
+    // device
+    int64_t* d_node_off = nullptr;   // [G+1]
+    int64_t* d_in_ptr = nullptr;     // [total_nodes + 1] global edge offsets, rows = global node ids
+    int32_t* d_in_idx = nullptr;     // [total_edges]     source node, LOCAL to its graph
+    int64_t* d_out_ptr = nullptr;    // by-source CSR of the same edges (for the transposed induce)
+    int32_t* d_out_idx = nullptr;    // destination node, LOCAL to its graph
+    float* d_feat = nullptr;         // [total_nodes, feat_dim]
+};
+
+struct gm_batch {
+    const gm_store* store = nullptr;
+    int64_t rows = 0, edges = 0;
+    int32_t subs = 0, sets = 0, centres = 1;
+    // host mirrors (small)
+    std::vector<int32_t> h_sub_off, h_set_sub_off, h_set_row_off, h_graph;
+    // device
+    int32_t* d_sub_off = nullptr;      // [subs+1]
+    int32_t* d_set_sub_off = nullptr;  // [sets+1]
+    int32_t* d_set_row_off = nullptr;  // [sets+1]
+    int32_t* d_graph = nullptr;        // [subs]
+    int32_t* d_parent = nullptr;       // [rows]
+    int32_t* d_feat_row = nullptr;     // [rows]
+    int32_t* d_indptr = nullptr;       // [rows+1]
+    int32_t* d_indices = nullptr;      // [edges]
+    int32_t* d_indptr_t = nullptr;     // [rows+1]
+    int32_t* d_indices_t = nullptr;    // [edges]
+    int32_t* d_centre = nullptr;       // [subs*centres] local index
+    float* d_norm = nullptr;           // [rows]
+    // derived launch tables (built by gm_batch_finalize)
+    int32_t* d_sub_set = nullptr;      // [subs]  set of each subgraph
+    int32_t* d_tiles = nullptr;        // [n_tiles*3]  GEMM row tiles: set, row0, nrows (<= GM_GEMM_BM)
+    int32_t n_tiles = 0;
+    int32_t* d_chunks = nullptr;       // [n_chunks*3] weight-gradient row chunks: set, row0, nrows
+    int32_t n_chunks = 0;
+    int32_t* d_set_chunk_off = nullptr;// [sets+1]
+    hipStream_t stream = nullptr;      // stream the arrays were produced on
+};
+int gm_batch_finalize(gm_batch* b, hipStream_t s);
+
+// ---- device allocation helpers (stream-ordered pool so that per-batch builds do not sync the device)
+int gm_dev_alloc(void** p, size_t bytes, hipStream_t s);
+void gm_dev_free(void* p, hipStream_t s);
+template <class T>
+static inline int gm_alloc(T** p, size_t n, hipStream_t s) { return gm_dev_alloc((void**)p, (n ? n : 1) * sizeof(T), s); }
+
+// ---- layout helpers
+struct gm_layout {
+    int n_gcn;
+    int dims[GM_MAX_GCN + 1];
+    int n_out, link, hc;              // hc = width of the head input
+    int64_t w_off[GM_MAX_GCN], b_off[GM_MAX_GCN], wl_off, bl_off, P;
+};
+int gm_make_layout(const gm_model_t* m, gm_layout* L);
+
+// ---- kernels launched across translation units
+// Generic CSR aggregate: out[r,:] = epi( s_out[r] * sum_{c in row r} s_in[c] * x[src(c),:] ).
+struct gm_agg_args {
+    const int32_t* indptr;
+    const int32_t* indices;
+    const float* x;            // [*, ldx]
+    const int32_t* x_row;      // optional indirection applied to the column index (feature gather)
+    int64_t ldx;
+    const float* s_in;         // optional per-source scale
+    const float* s_out;        // optional per-destination scale
+    const float* mask_h;       // optional [rows, width]: zero the output where mask_h <= 0 (relu')
+    const float* bias;         // optional per-set bias (bias + set*bias_stride) -- matmul-first layers
+    int64_t bias_stride;
+    const int32_t* set_row_off;// required when bias != NULL and bias_stride != 0: row range of every set
+    int n_sets;
+    int relu;
+    float* out;                // [rows, width]
+    int64_t rows;
+    int width;
+};
+int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);
+
+// Grouped GEMM  C[rows of set t] = epi( A[rows] @ op(B_t) ),  A [rows,K] (lda), C [rows,N] (ldc).
+struct gm_gemm_args {
+    const float* A; int64_t lda;
+    const float* B; int64_t b_stride;   // B_t = B + t*b_stride ; [K,N] row-major, or [N,K] when transB
+    int transB;
+    float* C; int64_t ldc;
+    int K, N;
+    const float* row_scale;             // optional: C *= row_scale[row] (before bias)
+    const float* bias; int64_t bias_stride;   // optional per-set bias [N]
+    int relu;
+    const float* mask_h;                // optional [rows, ldc]: zero C where mask_h <= 0 (relu')
+    const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
+    int n_tiles;
+};
+#define GM_GEMM_BM 128
+int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
+
+// Grouped transposed-A GEMM for weight gradients:
+//   dW_t[K,N] = sum_{rows of set t} a_scale[row] * A[row,:]^T  G[row,:]   and   db_t[N] = sum G[row,:]
+// computed as per-chunk partials followed by a deterministic reduction that also applies `beta`:
+//   out_t = (beta_is_sgd ? w_t - lr * sum : sum)
+struct gm_wgrad_args {
+    const float* A; int64_t lda; int K;
+    const int32_t* a_row;               // optional row indirection for A (layer-1 feature gather)
+    const float* G; int64_t ldg; int N;
+    const float* Gb; int64_t ldgb;      // optional: matrix whose column sums give db (default: G)
+    const float* a_scale;               // optional
+    const int32_t* chunks;              // device [n_chunks*3]: set, row0, nrows
+    int n_chunks;
+    const int32_t* set_chunk_off;       // device [sets+1]: chunk range per set
+    int sets;
+    float* partial;                     // workspace [n_chunks, (K+1)*N]  (row K = bias partial)
+    float* dW; int64_t dw_stride;       // dW_t = dW + t*dw_stride   [K,N]
+    float* db; int64_t db_stride;       // db_t                      [N]
+};
+#define GM_WGRAD_ROWS 1024
+int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
+
+// profiling of aggregate launches (bench.py roofline)
+void gm_prof_agg_begin(hipStream_t s, int64_t bytes);
+void gm_prof_agg_end(hipStream_t s);

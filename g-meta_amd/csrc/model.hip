@@ -1,0 +1,568 @@
+// Classifier forward/backward (learner.py:134-175), prototypical losses (meta.py:14-79) and the
+// first-order ProtoMAML inner/outer step (meta.py:101-173, 175-234) for ALL tasks of a meta-batch
+// at once.  Each task (set) owns its fast weights; the K-loop runs here so that one FFI call is one
+// meta-step and nothing returns to the host until the accuracies are read back.
+#include <algorithm>
+#include <map>
+#include "gm_internal.h"
+
+void gm_prof_reset();
+
+// ================================================================================ small kernels
+__device__ __forceinline__ float wave_sumf(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+struct HeadK {
+    const float* H; int64_t ldh; int Hd;            // last GCN activation [rows, Hd]
+    const int32_t* sub_off; const int32_t* centre; int nc; const int32_t* sub_set; const int32_t* set_sub_off;
+    const float* params; int64_t pstride; int64_t wl_off, bl_off; int hc, C; int subs;
+};
+
+__device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) { return (int64_t)k.sub_off[s] + k.centre[s * k.nc + which]; }
+
+// logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
+__global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= k.subs) return;
+    const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
+    const float* h0 = k.H + centre_row(k, s, 0) * k.ldh;
+    const float* h1 = k.nc == 2 ? k.H + centre_row(k, s, 1) * k.ldh : nullptr;
+    for (int c = 0; c < k.C; ++c) {
+        const float* w = P + k.wl_off + (int64_t)c * k.hc;
+        float acc = 0.f;
+        for (int h = lane; h < k.hc; h += 64) acc += (h < k.Hd ? h0[h] : h1[h - k.Hd]) * w[h];
+        acc = wave_sumf(acc);
+        if (lane == 0) logits[(int64_t)s * k.C + c] = acc + P[k.bl_off + c];
+    }
+}
+
+// Backward of the head for one set per block: dWl, dbl into dparams; dQ_L (pre-zeroed) at the centre rows,
+// already multiplied by relu'(H_L).
+__global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ) {
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
+    const float* P = k.params + (int64_t)set * k.pstride;
+    float* D = dparams + (int64_t)set * dstride;
+    for (int id = tid; id < k.C * k.hc; id += 256) {
+        const int c = id / k.hc, h = id - c * k.hc;
+        float acc = 0.f;
+        for (int s = s0; s < s1; ++s) {
+            const float hv = h < k.Hd ? k.H[centre_row(k, s, 0) * k.ldh + h] : k.H[centre_row(k, s, 1) * k.ldh + h - k.Hd];
+            acc += dlogits[(int64_t)s * k.C + c] * hv;
+        }
+        D[k.wl_off + id] = acc;
+    }
+    for (int c = tid; c < k.C; c += 256) {
+        float acc = 0.f;
+        for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)s * k.C + c];
+        D[k.bl_off + c] = acc;
+    }
+    for (int col = tid; col < k.Hd; col += 256) {
+        for (int s = s0; s < s1; ++s) {
+            for (int which = 0; which < k.nc; ++which) {
+                float v = 0.f;
+                for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
+                const int64_t at = centre_row(k, s, which) * k.ldh + col;
+                if (k.H[at] > 0.f) dQ[at] += v;
+            }
+        }
+    }
+}
+
+// Prototypical loss for one set per block (meta.py:28-79).  rows: [sets, Ct, n] global subgraph ids grouped by
+// sorted class.  mode 0 = support (prototypes = class means of the same rows), 1 = query (prototypes given).
+struct ProtoK {
+    const float* logits; int D; const int32_t* rows; int Ct, n; int mode;
+    const float* protos_in; float* protos_out; float* loss; float* acc; int64_t ld_out; int col_out;
+    float* dlogits; float* dprotos;
+};
+
+__device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
+    float d = 0.f;
+    for (int k = 0; k < D; ++k) { const float t = x[k] - p[k]; d += t * t; }
+    return d;
+}
+
+__global__ __launch_bounds__(256) void k_proto(ProtoK k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int set = blockIdx.x, tid = threadIdx.x, Q = k.Ct * k.n, D = k.D;
+    float* protos = sm;                 // [Ct*D]
+    float* lse = sm + k.Ct * D;         // [Q]
+    float* red = lse + Q;               // [512]
+    const int32_t* rows = k.rows + (int64_t)set * Q;
+    for (int id = tid; id < k.Ct * D; id += 256) {
+        const int c = id / D, d = id - c * D;
+        float p;
+        if (k.mode == 0) {
+            p = 0.f;
+            for (int r = 0; r < k.n; ++r) p += k.logits[(int64_t)rows[c * k.n + r] * D + d];
+            p /= (float)k.n;                                                        // .mean(0) (meta.py:41)
+            if (k.protos_out) k.protos_out[(int64_t)set * k.Ct * D + id] = p;
+        } else {
+            p = k.protos_in[(int64_t)set * k.Ct * D + id];
+        }
+        protos[id] = p;
+    }
+    __syncthreads();
+    float lpart = 0.f, apart = 0.f;
+    for (int q = tid; q < Q; q += 256) {
+        const float* x = k.logits + (int64_t)rows[q] * D;
+        const int tgt = q / k.n;
+        float m = -INFINITY, at = 0.f; int best = 0;
+        for (int c = 0; c < k.Ct; ++c) {
+            const float a = -sqdist(x, protos + c * D, D);                           // -dists (meta.py:44-45)
+            if (a > m) { m = a; best = c; }
+            if (c == tgt) at = a;
+        }
+        float se = 0.f;
+        for (int c = 0; c < k.Ct; ++c) se += expf(-sqdist(x, protos + c * D, D) - m);
+        const float l = m + logf(se);
+        lse[q] = l;
+        lpart += -(at - l);                                                          // -log_p[q, class(q)]
+        apart += (best == tgt) ? 1.f : 0.f;
+    }
+    red[tid] = lpart; red[256 + tid] = apart;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; } __syncthreads(); }
+    if (tid == 0) {
+        k.loss[(int64_t)set * k.ld_out + k.col_out] = red[0] / (float)Q;
+        k.acc[(int64_t)set * k.ld_out + k.col_out] = red[256] / (float)Q;
+    }
+    if (!k.dlogits) return;
+    // G[q,c] = (softmax(-d)[q,c] - [c == tgt(q)]) / Q ;  d(-d_qc)/dx_q = -2 (x_q - p_c) ; d(-d_qc)/dp_c = +2 (x_q - p_c)
+    const float invQ = 1.f / (float)Q;
+    for (int id = tid; id < Q * D; id += 256) {
+        const int q = id / D, d = id - q * D;
+        const float* x = k.logits + (int64_t)rows[q] * D;
+        const int tgt = q / k.n;
+        float s = 0.f;
+        for (int c = 0; c < k.Ct; ++c) {
+            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == tgt ? 1.f : 0.f)) * invQ;
+            s += g * -2.f * (x[d] - protos[c * D + d]);
+        }
+        k.dlogits[(int64_t)rows[q] * D + d] = s;
+    }
+    __syncthreads();
+    for (int id = tid; id < k.Ct * D; id += 256) {
+        const int c = id / D, d = id - c * D;
+        float s = 0.f;
+        for (int q = 0; q < Q; ++q) {
+            const float* x = k.logits + (int64_t)rows[q] * D;
+            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / k.n ? 1.f : 0.f)) * invQ;
+            s += g * 2.f * (x[d] - protos[id]);
+        }
+        if (k.mode == 0) {
+            for (int r = 0; r < k.n; ++r) k.dlogits[(int64_t)rows[c * k.n + r] * D + d] += s / (float)k.n;
+        } else if (k.dprotos) {
+            k.dprotos[(int64_t)set * k.Ct * D + id] = s;
+        }
+    }
+}
+
+// Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
+__global__ void k_protos_to_dlogits(const float* dprotos, const int32_t* rows, int Ct, int n, int D, float* dlogits) {
+    const int set = blockIdx.x;
+    for (int id = threadIdx.x; id < Ct * n * D; id += blockDim.x) {
+        const int q = id / D, d = id - q * D, c = q / n;
+        dlogits[(int64_t)rows[(int64_t)set * Ct * n + q] * D + d] = dprotos[((int64_t)set * Ct + c) * D + d] / (float)n;
+    }
+}
+
+// dst[t, j] = src[t*src_stride + j] - lr * g[t*stride + j]     (meta.py:126,151)
+__global__ void k_sgd(float* dst, const float* src, int64_t src_stride, const float* g, float lr, int64_t P, int64_t stride, int T) {
+    const int64_t tot = (int64_t)T * P;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = id / P, j = id - t * P;
+        dst[t * stride + j] = src[t * src_stride + j] - lr * g[t * stride + j];
+    }
+}
+
+__global__ void k_colsum_partial(const float* G, int64_t ldg, int N, const int32_t* chunks, float* partial, int64_t pstride, int64_t poff) {
+    const int chunk = blockIdx.x;
+    const int row0 = chunks[chunk * 3 + 1], nrows = chunks[chunk * 3 + 2];
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < nrows; ++r) s += G[(int64_t)(row0 + r) * ldg + n];
+        partial[(int64_t)chunk * pstride + poff + n] = s;
+    }
+}
+__global__ void k_colsum_reduce(const float* partial, int64_t pstride, int64_t poff, const int32_t* set_chunk_off, int N, float* db, int64_t db_stride) {
+    const int set = blockIdx.x;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        float s = 0.f;
+        for (int c = set_chunk_off[set]; c < set_chunk_off[set + 1]; ++c) s += partial[(int64_t)c * pstride + poff + n];
+        db[(int64_t)set * db_stride + n] = s;
+    }
+}
+
+// out = [ sum_t (gq+gp) | sum_t lq[t,:] | sum_t aq[t,:] | aq[t,:] ... ]
+__global__ void k_finalize(const float* gq, const float* gp, int64_t stride, int64_t P, int T, const float* lq, const float* aq, int K1, float* out) {
+    const int64_t tot = P + 2 * K1 + (int64_t)T * K1;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        if (id < P) { if (gq) for (int t = 0; t < T; ++t) s += gq[t * stride + id] + gp[t * stride + id]; }
+        else if (id < P + K1) { for (int t = 0; t < T; ++t) s += lq[t * K1 + (id - P)]; }
+        else if (id < P + 2 * K1) { for (int t = 0; t < T; ++t) s += aq[t * K1 + (id - P - K1)]; }
+        else s = aq[id - P - 2 * K1];
+        out[id] = s;
+    }
+}
+
+// ================================================================================ workspace carving
+struct Carver {
+    char* base; int64_t used = 0, cap;
+    Carver(void* p, int64_t c) : base((char*)p), cap(c) {}
+    template <class T> T* take(int64_t n) {
+        const int64_t bytes = ((n > 0 ? n : 1) * (int64_t)sizeof(T) + 255) / 256 * 256;
+        T* r = base ? (T*)(base + used) : nullptr;
+        used += bytes;
+        return r;
+    }
+    bool ok() const { return !base || used <= cap; }
+};
+
+struct GcnCtx {
+    const gm_batch* b; gm_layout L;
+    float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    const float* x0_user; const int32_t* centre; int z1_valid;
+    int zw[GM_MAX_GCN];
+};
+
+static void gcn_carve(GcnCtx& c, Carver& cv) {
+    const gm_layout& L = c.L; const int64_t rows = c.b->rows;
+    int maxd = 0; int64_t maxkn = 0;
+    for (int l = 0; l < L.n_gcn; ++l) {
+        const int fi = L.dims[l], fo = L.dims[l + 1];
+        c.zw[l] = fi > fo ? fo : fi;
+        c.Z[l] = cv.take<float>(rows * c.zw[l]);
+        c.H[l] = cv.take<float>(rows * fo);
+        maxd = std::max(maxd, std::max(fi, fo));
+        maxkn = std::max<int64_t>(maxkn, (int64_t)(fi + 1) * fo);
+    }
+    c.X0 = (L.dims[0] > L.dims[1]) ? cv.take<float>(rows * L.dims[0]) : nullptr;
+    c.bufA = cv.take<float>(rows * maxd);
+    c.bufB = cv.take<float>(rows * maxd);
+    c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
+}
+
+extern "C" int64_t gm_gcn_ws_bytes(const gm_batch_t* b, const gm_model_t* m) {
+    GcnCtx c{}; c.b = b;
+    if (!b || gm_make_layout(m, &c.L) != GM_OK) return -1;
+    Carver cv(nullptr, 0);
+    gcn_carve(c, cv);
+    return cv.used + 256;
+}
+
+static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b;
+    HeadK k{};
+    k.H = c.H[L.n_gcn - 1]; k.ldh = L.dims[L.n_gcn]; k.Hd = L.dims[L.n_gcn];
+    k.sub_off = b->d_sub_off; k.centre = c.centre ? c.centre : b->d_centre; k.nc = b->centres; k.sub_set = b->d_sub_set;
+    k.set_sub_off = b->d_set_sub_off; k.params = params; k.pstride = pstride; k.wl_off = L.wl_off; k.bl_off = L.bl_off;
+    k.hc = L.hc; k.C = L.n_out; k.subs = b->subs;
+    return k;
+}
+
+static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b;
+    GM_REQUIRE(L.dims[0] == b->store->feat_dim || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
+    GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
+    const float* xin = c.x0_user;           // NULL = gather rows of the store through feat_row
+    for (int l = 0; l < L.n_gcn; ++l) {
+        const int fi = L.dims[l], fo = L.dims[l + 1];
+        const bool gather = (l == 0 && !c.x0_user);
+        if (fi > fo) {                      // learner.py:34-40: multiply first, then aggregate
+            const float* A = xin; int64_t lda = fi;
+            if (gather) { GM_TRY(gm_gather_features(b, c.X0, st)); A = c.X0; }
+            gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
+            g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+            GM_TRY(gm_launch_gemm_nn(g, st));
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
+            a.out = c.H[l]; a.rows = b->rows; a.width = fo;
+            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo));
+            GM_TRY(gm_launch_aggregate(a, st));
+            gm_prof_agg_end(st);
+        } else {                            // learner.py:41-47: aggregate first, then multiply
+            if (!(l == 0 && reuse_z1 && c.z1_valid)) {
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = fi; }
+                else { a.x = xin; a.ldx = fi; }
+                gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
+                GM_TRY(gm_launch_aggregate(a, st));
+                gm_prof_agg_end(st);
+                if (l == 0) c.z1_valid = 1;
+            }
+            gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
+            g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+            GM_TRY(gm_launch_gemm_nn(g, st));
+        }
+        xin = c.H[l];
+    }
+    HeadK k = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_fwd, dim3((b->subs + 3) / 4), dim3(256), 0, st, k, logits);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b;
+    const int Lg = L.n_gcn;
+    float* dQ = c.bufA; float* T = c.bufB;
+    GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[Lg], st));
+    HeadK k = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ);
+    GM_HIP(hipGetLastError());
+    for (int l = Lg - 1; l >= 0; --l) {
+        const int fi = L.dims[l], fo = L.dims[l + 1];
+        const float* Xprev = l > 0 ? c.H[l - 1] : (c.x0_user ? c.x0_user : c.X0);
+        const float* maskprev = l > 0 ? c.H[l - 1] : nullptr;
+        gm_wgrad_args w{}; w.chunks = b->d_chunks; w.n_chunks = b->n_chunks; w.set_chunk_off = b->d_set_chunk_off; w.sets = b->sets;
+        w.partial = c.partial; w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
+        w.a_scale = b->d_norm; w.K = fi; w.N = fo;
+        if (fi > fo) {
+            // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo));
+            GM_TRY(gm_launch_aggregate(a, st));
+            gm_prof_agg_end(st);
+            w.A = Xprev; w.lda = fi; w.G = T; w.ldg = fo; w.Gb = dQ; w.ldgb = fo;
+            GM_TRY(gm_launch_wgrad(w, st));
+            if (l > 0) {
+                gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
+                g.row_scale = b->d_norm; g.mask_h = maskprev; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+                GM_TRY(gm_launch_gemm_nn(g, st));
+            }
+        } else {
+            // dW = (norm*Z)^T dQ ; db = colsum(dQ) ; dZ = norm * (dQ W^T) ; dQ_prev = relu'(H_prev) * norm * A^T dZ
+            w.A = c.Z[l]; w.lda = fi; w.G = dQ; w.ldg = fo;
+            GM_TRY(gm_launch_wgrad(w, st));
+            if (l > 0) {
+                gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
+                g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+                GM_TRY(gm_launch_gemm_nn(g, st));
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev;
+                a.out = dQ; a.rows = b->rows; a.width = fi;
+                gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
+                GM_TRY(gm_launch_aggregate(a, st));
+                gm_prof_agg_end(st);
+            }
+        }
+    }
+    return GM_OK;
+}
+
+extern "C" int gm_gcn_forward(const gm_batch_t* b, const gm_model_t* m, const float* params, int64_t param_stride, const float* x0,
+                              const int32_t* centre_local, float* logits, void* ws, int64_t ws_bytes, void* stream) {
+    GM_REQUIRE(b && m && params && logits && ws, GM_EINVAL, "gcn_forward: NULL argument");
+    GcnCtx c{}; c.b = b;
+    GM_TRY(gm_make_layout(m, &c.L));
+    Carver cv(ws, ws_bytes);
+    gcn_carve(c, cv);
+    GM_REQUIRE(cv.ok(), GM_ENOMEM, "gcn_forward: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
+    c.x0_user = x0; c.centre = centre_local;
+    return gcn_forward(c, params, param_stride, logits, (hipStream_t)stream, 0);
+}
+
+extern "C" int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* params, int64_t param_stride, const float* x0,
+                               const int32_t* centre_local, const float* dlogits, float* dparams, int64_t dparam_stride, void* ws,
+                               int64_t ws_bytes, void* stream) {
+    GM_REQUIRE(b && m && params && dlogits && dparams && ws, GM_EINVAL, "gcn_backward: NULL argument");
+    GcnCtx c{}; c.b = b;
+    GM_TRY(gm_make_layout(m, &c.L));
+    GM_REQUIRE(dparam_stride >= c.L.P, GM_EINVAL, "gcn_backward: dparam_stride %lld < P=%lld", (long long)dparam_stride, (long long)c.L.P);
+    Carver cv(ws, ws_bytes);
+    gcn_carve(c, cv);
+    GM_REQUIRE(cv.ok(), GM_ENOMEM, "gcn_backward: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
+    c.x0_user = x0; c.centre = centre_local;
+    return gcn_backward(c, params, param_stride, dlogits, dparams, dparam_stride, (hipStream_t)stream);
+}
+
+// ================================================================================ prototypical losses
+// Host side of meta.py:32-42,60-65: sorted unique classes, rows of each class (first n_support for the
+// support loss; all rows, equal counts required, for the query loss), as global subgraph ids.
+static int class_tables(const gm_batch* b, const int32_t* y, int limit, std::vector<int32_t>& rows, int* Ct, int* n) {
+    *Ct = -1; *n = -1;
+    rows.clear();
+    for (int t = 0; t < b->sets; ++t) {
+        std::map<int32_t, std::vector<int32_t>> by;
+        for (int s = b->h_set_sub_off[t]; s < b->h_set_sub_off[t + 1]; ++s) by[y[s]].push_back(s);
+        GM_REQUIRE(!by.empty(), GM_EINVAL, "proto loss: set %d is empty", t);
+        int cnt = -1;
+        for (auto& kv : by) {
+            int c = (int)kv.second.size();
+            if (limit > 0) {
+                GM_REQUIRE(c >= limit, GM_EINVAL, "proto loss: class %d of set %d has %d rows < n_support=%d (torch.stack at meta.py:42 fails)", kv.first, t, c, limit);
+                c = limit;
+            }
+            GM_REQUIRE(cnt < 0 || cnt == c, GM_EINVAL, "proto loss: classes of set %d have unequal row counts (torch.stack at meta.py:65 fails)", t);
+            cnt = c;
+        }
+        GM_REQUIRE(*Ct < 0 || (*Ct == (int)by.size() && *n == cnt), GM_EINVAL, "proto loss: set %d has a different class layout than set 0", t);
+        *Ct = (int)by.size(); *n = cnt;
+        for (auto& kv : by) rows.insert(rows.end(), kv.second.begin(), kv.second.begin() + cnt);
+    }
+    GM_REQUIRE((int64_t)*Ct * *n <= 8192 && *Ct <= 256, GM_ERANGE, "proto loss: %d classes x %d rows per set is outside the kernel's range", *Ct, *n);
+    return GM_OK;
+}
+
+static size_t proto_lds(int Ct, int n, int D) { return sizeof(float) * ((size_t)Ct * D + (size_t)Ct * n + 512); }
+
+static int launch_proto(const gm_batch* b, ProtoK k, hipStream_t st) {
+    hipLaunchKernelGGL(k_proto, dim3(b->sets), dim3(256), proto_lds(k.Ct, k.n, k.D), st, k);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+extern "C" int gm_proto_loss_spt(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, int32_t n_support, float* loss,
+                                 float* acc, float* protos, float* dlogits, void* stream) {
+    GM_REQUIRE(b && logits && y && loss && acc && n_support >= 1, GM_EINVAL, "proto_loss_spt: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> rows; int Ct, n;
+    GM_TRY(class_tables(b, y, n_support, rows, &Ct, &n));
+    int32_t* d_rows = nullptr;
+    GM_TRY(gm_alloc(&d_rows, rows.size(), st));
+    GM_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, st));
+    if (dlogits) GM_HIP(hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st));
+    ProtoK k{logits, n_out, d_rows, Ct, n, 0, nullptr, protos, loss, acc, 1, 0, dlogits, nullptr};
+    int rc = launch_proto(b, k, st);
+    GM_HIP(hipStreamSynchronize(st));
+    gm_dev_free(d_rows, st);
+    return rc;
+}
+
+extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, const float* protos, int32_t c_task,
+                                 float* loss, float* acc, float* dlogits, float* dprotos, void* stream) {
+    GM_REQUIRE(b && logits && y && protos && loss && acc, GM_EINVAL, "proto_loss_qry: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> rows; int Ct, n;
+    GM_TRY(class_tables(b, y, 0, rows, &Ct, &n));
+    GM_REQUIRE(Ct == c_task, GM_EINVAL, "proto_loss_qry: %d query classes but %d prototypes", Ct, c_task);
+    int32_t* d_rows = nullptr;
+    GM_TRY(gm_alloc(&d_rows, rows.size(), st));
+    GM_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, st));
+    if (dlogits) GM_HIP(hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st));
+    ProtoK k{logits, n_out, d_rows, Ct, n, 1, protos, nullptr, loss, acc, 1, 0, dlogits, dprotos};
+    int rc = launch_proto(b, k, st);
+    GM_HIP(hipStreamSynchronize(st));
+    gm_dev_free(d_rows, st);
+    return rc;
+}
+
+// ================================================================================ the fused meta-step
+struct MetaPlan {
+    gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
+    GcnCtx S, Q;
+    float *fwA, *fwB, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq;
+    int32_t *rows_s, *rows_q;
+    int Ct, ns, nq;
+};
+
+static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, const gm_model_t* m, const gm_hparams_t* hp, void* ws, int64_t ws_bytes,
+                     int Ct, int ns, int nq, int64_t* need) {
+    GM_TRY(gm_make_layout(m, &p.L));
+    p.T = spt->sets; p.K = hp->update_step; p.Pp = (p.L.P + 63) / 64 * 64;
+    p.S = GcnCtx{}; p.Q = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.S.L = p.L; p.Q.L = p.L;
+    Carver cv(ws, ws_bytes);
+    const int64_t TP = (int64_t)p.T * p.Pp; const int C = p.L.n_out; const int K1 = p.K + 1;
+    p.fwA = cv.take<float>(TP); p.fwB = cv.take<float>(TP); p.g = cv.take<float>(TP); p.gq = cv.take<float>(TP); p.gp = cv.take<float>(TP);
+    p.logit_s = cv.take<float>((int64_t)spt->subs * C); p.logit_q = cv.take<float>((int64_t)qry->subs * C);
+    p.dlog_s = cv.take<float>((int64_t)spt->subs * C); p.dlog_q = cv.take<float>((int64_t)qry->subs * C);
+    p.protos = cv.take<float>((int64_t)p.T * 256 * C); p.dprotos = cv.take<float>((int64_t)p.T * 256 * C);
+    p.ls = cv.take<float>((int64_t)p.T * K1); p.as_ = cv.take<float>((int64_t)p.T * K1);
+    p.lq = cv.take<float>((int64_t)p.T * K1); p.aq = cv.take<float>((int64_t)p.T * K1);
+    p.rows_s = cv.take<int32_t>(spt->subs); p.rows_q = cv.take<int32_t>(qry->subs);
+    gcn_carve(p.S, cv); gcn_carve(p.Q, cv);
+    p.Ct = Ct; p.ns = ns; p.nq = nq;
+    if (need) *need = cv.used + 256;
+    GM_REQUIRE(cv.ok(), GM_ENOMEM, "meta_step: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
+    return GM_OK;
+}
+
+extern "C" int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry, const gm_model_t* m, const gm_hparams_t* hp) {
+    if (!spt || !qry || !m || !hp) return -1;
+    MetaPlan p; int64_t need = 0;
+    if (meta_plan(p, spt, qry, m, hp, nullptr, 0, 1, 1, 1, &need) != GM_OK) return -1;
+    return need;
+}
+
+extern "C" int64_t gm_meta_out_floats(const gm_batch_t* spt, const gm_model_t* m, const gm_hparams_t* hp) {
+    gm_layout L;
+    if (!spt || !hp || gm_make_layout(m, &L) != GM_OK) return -1;
+    return L.P + 2 * (int64_t)(hp->update_step + 1) + (int64_t)spt->sets * (hp->update_step + 1);
+}
+
+extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_spt, const int32_t* y_qry, const gm_model_t* m,
+                            const gm_hparams_t* hp, const float* theta, float* out, void* ws, int64_t ws_bytes, void* stream) {
+    GM_REQUIRE(spt && qry && y_spt && y_qry && m && hp && theta && out && ws, GM_EINVAL, "meta_step: NULL argument");
+    GM_REQUIRE(spt->sets == qry->sets, GM_EINVAL, "meta_step: %d support sets but %d query sets", spt->sets, qry->sets);
+    GM_REQUIRE(spt->store == qry->store, GM_EINVAL, "meta_step: support and query batches come from different stores");
+    const int K = hp->update_step;
+    GM_REQUIRE(K >= 1, GM_EINVAL, "meta_step: update_step must be >= 1");
+    GM_REQUIRE(!hp->need_meta_grad || K >= 2, GM_EINVAL,
+               "meta_step: update_step must be >= 2 for training (losses_q[0..1] are computed under no_grad, meta.py:129-141)");
+    GM_REQUIRE(((uintptr_t)theta & 15) == 0, GM_EINVAL, "meta_step: theta must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int32_t> rows_s, rows_q; int Ct, ns, Ctq, nq;
+    GM_TRY(class_tables(spt, y_spt, hp->k_spt, rows_s, &Ct, &ns));
+    GM_TRY(class_tables(qry, y_qry, 0, rows_q, &Ctq, &nq));
+    GM_REQUIRE(Ct == Ctq, GM_EINVAL, "meta_step: %d support classes but %d query classes per task", Ct, Ctq);
+    MetaPlan p;
+    GM_TRY(meta_plan(p, spt, qry, m, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
+    const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
+    GM_HIP(hipMemcpyAsync(p.rows_s, rows_s.data(), 4 * rows_s.size(), hipMemcpyHostToDevice, st));
+    GM_HIP(hipMemcpyAsync(p.rows_q, rows_q.data(), 4 * rows_q.size(), hipMemcpyHostToDevice, st));
+    GM_HIP(hipStreamSynchronize(st));       // pageable host vectors: make the copies complete before they go out of scope
+    gm_prof_reset();
+    const int sgd_blocks = (int)std::min<int64_t>(2048, ((int64_t)T * L.P + 255) / 256);
+
+    auto spt_loss = [&](int col) -> int {      // proto_loss_spt (meta.py:123,146): loss, prototypes, dlogits
+        GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
+        ProtoK k{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, p.protos, p.ls, p.as_, K1, col, p.dlog_s, nullptr};
+        return launch_proto(spt, k, st);
+    };
+    auto qry_loss = [&](int col, bool grad) -> int {   // proto_loss_qry (meta.py:132,139,154)
+        if (grad) GM_HIP(hipMemsetAsync(p.dlog_q, 0, sizeof(float) * qry->subs * C, st));
+        ProtoK k{p.logit_q, C, p.rows_q, Ct, nq, 1, p.protos, nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr};
+        return launch_proto(qry, k, st);
+    };
+    const int hoist = hp->hoist_z1;
+    // ---- step 0 (meta.py:122-141)
+    GM_TRY(gcn_forward(p.S, theta, 0, p.logit_s, st, hoist));
+    GM_TRY(spt_loss(0));
+    GM_TRY(gcn_backward(p.S, theta, 0, p.dlog_s, p.g, Pp, st));
+    hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, p.fwA, theta, (int64_t)0, p.g, hp->update_lr, L.P, Pp, T);
+    GM_TRY(gcn_forward(p.Q, theta, 0, p.logit_q, st, hoist));
+    GM_TRY(qry_loss(0, false));
+    GM_TRY(gcn_forward(p.Q, p.fwA, Pp, p.logit_q, st, hoist));
+    GM_TRY(qry_loss(1, false));
+    float* cur = p.fwA; float* nxt = p.fwB;
+    bool have_grad = false;
+    for (int k = 1; k < K; ++k) {            // meta.py:143-157
+        GM_TRY(gcn_forward(p.S, cur, Pp, p.logit_s, st, hoist));
+        GM_TRY(spt_loss(k));
+        GM_TRY(gcn_backward(p.S, cur, Pp, p.dlog_s, p.g, Pp, st));
+        hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, nxt, cur, Pp, p.g, hp->update_lr, L.P, Pp, T);
+        GM_TRY(gcn_forward(p.Q, nxt, Pp, p.logit_q, st, hoist));
+        const bool last = hp->need_meta_grad && k == K - 1;
+        GM_TRY(qry_loss(k + 1, last));
+        if (last) {
+            // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
+            // query forward plus d L_q / d fw_{K-1} through the prototypes of the last support forward.
+            GM_TRY(gcn_backward(p.Q, nxt, Pp, p.dlog_q, p.gq, Pp, st));
+            GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
+            hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, Ct, ns, C, p.dlog_s);
+            GM_TRY(gcn_backward(p.S, cur, Pp, p.dlog_s, p.gp, Pp, st));
+            have_grad = true;
+        }
+        std::swap(cur, nxt);
+    }
+    const int64_t tot = L.P + 2 * K1 + (int64_t)T * K1;
+    hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
+                       have_grad ? p.gq : nullptr, p.gp, Pp, L.P, T, p.lq, p.aq, K1, out);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}

@@ -1,0 +1,128 @@
+"""Mirror of G-Meta/meta.py: Meta (ProtoMAML inner/outer loop).  Same constructor, same 11-argument
+forward / finetunning, same return values; the whole task loop runs inside one gm_meta_step call
+(include/gmeta_hip.h) with every task of the meta-batch batched per kernel launch.  When
+torch.distributed is initialised each rank passes ITS shard of the meta-batch and the first-order
+meta-gradient is summed by one all-reduce (RCCL over xGMI on MI355X) before the NaN guard and Adam."""
+import ctypes as C
+from copy import deepcopy  # noqa: F401  (kept: train.py deep-copies the Meta object)
+
+import numpy as np
+import torch
+from torch import nn, optim
+
+from . import _lib
+from .learner import Classifier
+from .subgraphs import SubgraphBatch
+
+
+class Meta(nn.Module):
+    def __init__(self, args, config):                                          # meta.py:83-99
+        super(Meta, self).__init__()
+        self.update_lr = args.update_lr
+        self.meta_lr = args.meta_lr
+        self.n_way = args.n_way
+        self.k_spt = args.k_spt
+        self.k_qry = args.k_qry
+        self.task_num = args.task_num
+        self.update_step = args.update_step
+        self.update_step_test = args.update_step_test
+        self.net = Classifier(config)
+        if torch.cuda.is_available():
+            self.net = self.net.to('cuda')
+        self.meta_optim = optim.Adam(self.net.parameters(), lr=self.meta_lr)
+        self.method = args.method
+        self.hoist_z1 = int(getattr(args, 'hoist_z1', 0))
+        self.last_stats = {}
+        self._ws = None
+
+    # ---- helpers
+    def _flat_theta(self):
+        return torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).contiguous()
+
+    def _workspace(self, nbytes, dev):
+        if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=dev)
+        return self._ws
+
+    def _run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
+        """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + T(K+1) + 1], P, T)."""
+        _lib.require_gpu()
+        lib = _lib.lib()
+        theta = self._flat_theta()
+        dev = theta.device
+        if dev.type != 'cuda':
+            raise RuntimeError('Meta parameters must live on the GPU (call .to("cuda")); there is no CPU fallback')
+        if any(not isinstance(b, SubgraphBatch) for b in list(x_spt) + list(x_qry)):
+            raise TypeError('x_spt / x_qry must be lists of gmeta_amd.SubgraphBatch (from gmeta_amd.Subgraphs)')
+        S, Q = SubgraphBatch.concat(list(x_spt)), SubgraphBatch.concat(list(x_qry))
+        T = S.sets
+        ys = np.ascontiguousarray(np.concatenate([np.asarray(y).reshape(-1) for y in y_spt]), np.int32)
+        yq = np.ascontiguousarray(np.concatenate([np.asarray(y).reshape(-1) for y in y_qry]), np.int32)
+        if len(ys) != S.subs or len(yq) != Q.subs:
+            raise ValueError('label count does not match the number of subgraphs')
+        model = self.net.model
+        hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1))
+        P = int(lib.gm_model_param_count(C.byref(model)))
+        n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
+        ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
+        if ws_bytes < 0 or n_out < 0:
+            _lib.check(-1, 'gm_meta_ws_bytes')
+        ws = self._workspace(ws_bytes, dev)
+        out = torch.empty(n_out + 1, dtype=torch.float32, device=dev)
+        _lib.check(lib.gm_meta_step(S.handle, Q.handle, _lib.ptr(ys), _lib.ptr(yq), C.byref(model), C.byref(hp), _lib.ptr(theta),
+                                    _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'gm_meta_step')
+        out[n_out] = float(T)           # local task count rides along with the all-reduce
+        self._keep = (S, Q)             # keep concatenated batches alive until the stream has consumed them
+        return out, P, T
+
+    # ---- meta.py:101-173
+    def forward_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+        K = self.update_step
+        if K < 2:
+            raise ValueError('update_step must be >= 2: losses_q[0] and [1] are computed under no_grad (meta.py:129-141), '
+                             'so the reference cannot back-propagate with fewer steps')
+        out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, True)
+        K1 = K + 1
+        head = torch.cat([out[:P + 2 * K1], out[-1:]])       # [grad | losses_q | corrects | task count]
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
+        tail = head[P:].cpu().numpy().astype(np.float64)     # the only device->host sync of the meta-step
+        task_num = float(tail[-1])
+        loss_q = tail[K1 - 1] / task_num                      # losses_q[-1] / task_num (meta.py:161)
+        self.last_stats = {'loss_q': loss_q, 'losses_q': tail[:K1] / task_num, 'task_num': task_num}
+        if not np.isnan(loss_q):                              # meta.py:163-169
+            grad = head[:P] / task_num
+            self.meta_optim.zero_grad()
+            off = 0
+            for p in self.net.parameters():
+                n = p.numel()
+                p.grad = grad[off:off + n].view_as(p).clone()
+                off += n
+            self.meta_optim.step()
+        return tail[K1:2 * K1] / task_num                     # np.array(corrects) / task_num (meta.py:171)
+
+    # ---- meta.py:175-234
+    def finetunning_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+        K = self.update_step_test
+        out, P, T = self._run(x_spt[:1], y_spt[:1], x_qry[:1], y_qry[:1], K, False)      # `[0]` of every argument (meta.py:182-191)
+        K1 = K + 1
+        return out[P + 2 * K1:P + 3 * K1].cpu().numpy().astype(np.float64)
+
+    def finetunning_batch(self, x_spt, y_spt, x_qry, y_qry):
+        """All given evaluation tasks in ONE call (the reference loops 100 val/test tasks one at a time,
+        train.py:118-121); returns accs [T, K_test+1]."""
+        K = self.update_step_test
+        out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
+        K1 = K + 1
+        return out[P + 2 * K1:P + 2 * K1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
+
+    def forward(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+        if self.method == 'G-Meta':
+            accs = self.forward_ProtoMAML(x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat)
+        return accs
+
+    def finetunning(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+        if self.method == 'G-Meta':
+            accs = self.finetunning_ProtoMAML(x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat)
+        return accs

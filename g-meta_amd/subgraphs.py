@@ -1,0 +1,352 @@
+"""Task / subgraph data: mirror of G-Meta/subgraph_data_processing.py (Subgraphs, collate) with the
+h-hop extraction, sampling, induced-subgraph build and batching done by HIP kernels
+(gm_extract, include/gmeta_hip.h) on HBM-resident CSR instead of DGL + Python loops."""
+import collections
+import csv
+import ctypes as C
+import os
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import _lib
+from .graphstore import GraphStore
+
+
+class _NodeIds(collections.abc.Sequence):
+    """Parent node ids of one subgraph (== list(sub.parent_nid), sdp.py:317); fetched from HBM on first use."""
+
+    def __init__(self, owner, k):
+        self._o, self._k = owner, k
+
+    def __len__(self):
+        off = self._o.sub_off
+        return int(off[self._k + 1] - off[self._k])
+
+    def _data(self):
+        p, off = self._o.parent(), self._o.sub_off
+        return p[off[self._k]:off[self._k + 1]]
+
+    def __getitem__(self, i):
+        return self._data()[i]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._data()
+        return a.astype(dtype) if dtype is not None else a
+
+
+class SubgraphBatch:
+    """Device-resident batched induced subgraphs: stands where the reference has a batched DGLGraph
+    (slots 0 and 2 of the task tuple, sdp.py:399-408).  `sets` > 1 when it holds several tasks.
+    A view (parent, index) addresses one set of a multi-set batch without copying."""
+
+    def __init__(self, handle, store, owner=True, view_of=None, view_index=None):
+        self.handle, self.store, self._owner = handle, store, owner
+        self.view_of, self.view_index = view_of, view_index
+        self._cache = {}
+        rows, edges, subs, sets, cen = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(_lib.lib().gm_batch_dims(handle, C.byref(rows), C.byref(edges), C.byref(subs), C.byref(sets), C.byref(cen)))
+        self.rows, self.edges, self.subs, self.sets, self.centres = rows.value, edges.value, subs.value, sets.value, cen.value
+
+    # ---- construction
+    @staticmethod
+    def _seed_array(seeds):
+        seeds = np.asarray(seeds, np.int32).reshape(-1, 3)
+        arr = (_lib.Seed * len(seeds))()
+        for k, (g, i, j) in enumerate(seeds):
+            arr[k].graph, arr[k].i, arr[k].j = int(g), int(i), int(j)
+        return arr
+
+    @classmethod
+    def extract(cls, store, seeds, set_offsets, h, sample_nodes, rng_seed, link_pred):
+        arr = cls._seed_array(seeds)
+        so = np.ascontiguousarray(set_offsets, np.int32)
+        out = C.c_void_p()
+        _lib.check(_lib.lib().gm_extract(store.handle, arr, len(arr), _lib.ptr(so), len(so) - 1, int(h), int(sample_nodes),
+                                         C.c_uint64(int(rng_seed) & (2 ** 64 - 1)), int(bool(link_pred)), _lib.stream_ptr(), C.byref(out)),
+                   'gm_extract')
+        return cls(out, store)
+
+    @classmethod
+    def from_nodes(cls, store, seeds, set_offsets, node_lists, link_pred):
+        arr = cls._seed_array(seeds)
+        so = np.ascontiguousarray(set_offsets, np.int32)
+        lists = [np.unique(np.asarray(x, np.int32)) for x in node_lists]
+        flat = np.ascontiguousarray(np.concatenate(lists), np.int32)
+        off = np.ascontiguousarray(np.cumsum([0] + [len(x) for x in lists]), np.int64)
+        out = C.c_void_p()
+        _lib.check(_lib.lib().gm_batch_from_nodes(store.handle, arr, len(arr), _lib.ptr(so), len(so) - 1, _lib.ptr(flat), _lib.ptr(off),
+                                                  int(bool(link_pred)), _lib.stream_ptr(), C.byref(out)), 'gm_batch_from_nodes')
+        return cls(out, store)
+
+    @classmethod
+    def concat(cls, parts):
+        """dgl.batch over batches; if `parts` are the consecutive views of one multi-set batch it is returned as is."""
+        p0 = parts[0]
+        if p0.view_of is not None and all(p.view_of is p0.view_of and p.view_index == k for k, p in enumerate(parts)) \
+                and len(parts) == p0.view_of.sets:
+            return p0.view_of
+        if len(parts) == 1 and parts[0].view_of is None:
+            return parts[0]
+        real = [p._materialize() for p in parts]
+        arr = (C.c_void_p * len(real))(*[p.handle.value for p in real])
+        out = C.c_void_p()
+        _lib.check(_lib.lib().gm_batch_concat(arr, len(real), _lib.stream_ptr(), C.byref(out)), 'gm_batch_concat')
+        return cls(out, p0.store)
+
+    def views(self):
+        return [SubgraphBatch(self.handle, self.store, owner=False, view_of=self, view_index=k) for k in range(self.sets)]
+
+    def _materialize(self):
+        if self.view_of is None:
+            return self
+        raise NotImplementedError('concatenating a strict subset of a multi-set batch is not supported; '
+                                  'pass all of its task views, in order')
+
+    # ---- DGL-compatible surface used by meta.py:122 / learner.py:161
+    def to(self, device):
+        return self
+
+    def _read(self, field, n, dtype):
+        if self.view_of is not None:
+            return self.view_of._read(field, n, dtype)
+        key = (field,)
+        if key not in self._cache:
+            a = np.empty(n, dtype)
+            _lib.check(_lib.lib().gm_batch_read(self.handle, field, _lib.ptr(a), a.nbytes), 'gm_batch_read')
+            self._cache[key] = a
+        return self._cache[key]
+
+    @property
+    def sub_off(self):
+        return self._read(_lib.F_SUB_OFF, self.subs + 1, np.int32)
+
+    @property
+    def set_sub_off(self):
+        return self._read(_lib.F_SET_SUB_OFF, self.sets + 1, np.int32)
+
+    def _sub_range(self):
+        if self.view_of is None:
+            return 0, self.subs
+        o = self.set_sub_off
+        return int(o[self.view_index]), int(o[self.view_index + 1])
+
+    @property
+    def batch_num_nodes(self):
+        a, b = self._sub_range()
+        return [int(x) for x in np.diff(self.sub_off)[a:b]]
+
+    def parent(self):
+        return self._read(_lib.F_PARENT, self.rows, np.int32)
+
+    def centres_local(self):
+        a, b = self._sub_range()
+        c = self._read(_lib.F_CENTRE, self.subs * self.centres, np.int32).reshape(self.subs, self.centres)[a:b]
+        return c[:, 0] if self.centres == 1 else c
+
+    def graph_ids(self):
+        a, b = self._sub_range()
+        return self._read(_lib.F_GRAPH, self.subs, np.int32)[a:b]
+
+    def node_lists(self):
+        a, b = self._sub_range()
+        return [_NodeIds(self, k) for k in range(a, b)]
+
+    def csr(self, transposed=False):
+        ip = self._read(_lib.F_INDPTR_T if transposed else _lib.F_INDPTR, self.rows + 1, np.int32)
+        ix = self._read(_lib.F_INDICES_T if transposed else _lib.F_INDICES, self.edges, np.int32)
+        return ip, ix
+
+    def device_ptr(self, field):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().gm_batch_device_ptr(self.handle, field, C.byref(p)))
+        return p
+
+    def __del__(self):
+        try:
+            if self._owner and self.handle:
+                _lib.lib().gm_batch_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def collate(samples):
+    """sdp.py:414-419 / train.py:26-29: list of task tuples -> tuple of 10 lists."""
+    return tuple(map(list, zip(*samples)))
+
+
+class Subgraphs(Dataset):
+    """Mirror of subgraph_data_processing.Subgraphs (sdp.py:14-412).  `adjs` is a GraphStore (the
+    HBM-resident counterpart of the reference's list of DGLGraph objects).  Task sampling
+    (create_batch_*) follows sdp.py:150-292; `tables=` can replace the CSV files by in-memory
+    {'train': (names, labels)} style dictionaries (names 'g_i' or 'g_i_j', labels as in the CSV)."""
+
+    def __init__(self, root, mode, subgraph2label, n_way, k_shot, k_query, batchsz, args, adjs, h, tables=None, verbose=True):
+        self.batchsz, self.n_way, self.k_shot, self.k_query = batchsz, n_way, k_shot, k_query
+        self.setsz, self.querysz = n_way * k_shot, n_way * k_query            # sdp.py:20-21
+        self.h = h
+        self.sample_nodes = args.sample_nodes
+        self.rng_seed = int(getattr(args, 'sample_seed', 222))
+        if verbose:
+            print('shuffle DB :%s, b:%d, %d-way, %d-shot, %d-query, %d-hops' % (mode, batchsz, n_way, k_shot, k_query, h))
+        self.subgraph2label = subgraph2label
+        self.link_pred_mode = args.link_pred_mode == 'True'                   # string booleans (train.py:175)
+        self.task_setup = args.task_setup
+        if not isinstance(adjs, GraphStore):
+            raise TypeError('adjs must be a gmeta_amd.GraphStore (graphs + features resident in HBM)')
+        self.G = adjs
+        self.subgraphs = {}     # kept for source compatibility; extraction is not memoised on the host
+
+        def load(name):
+            if tables is not None:
+                return self._group(*tables[name])
+            return self.loadCSV(os.path.join(root, name + '.csv'))
+        if self.link_pred_mode:                                               # sdp.py:35-38
+            _, dG_s, dGL_s = load(mode + '_spt')
+            _, dG_q, dGL_q = load(mode + '_qry')
+        dictLabels, dictGraphs, dictGraphsLabels = load(mode)
+        if self.task_setup == 'Disjoint':                                     # sdp.py:51-58
+            self.data = [v for v in dictLabels.values()]
+            self.cls_num = len(self.data)
+            self.create_batch_disjoint(batchsz)
+        elif self.task_setup == 'Shared':
+            if self.link_pred_mode:                                           # sdp.py:61-95
+                self.data_label_spt = [list(dGL_s[k].values()) for k in dG_s]
+                self.data_label_qry = [list(dGL_q[k].values()) for k in dG_q]
+                self.graph_num_spt = len(self.data_label_spt)
+                self.create_batch_LinkPred(batchsz)
+            else:                                                             # sdp.py:97-116
+                self.data_label = [list(dictGraphsLabels[k].values()) for k in dictGraphs]
+                self.graph_num = len(self.data_label)
+                self.cls_num = len(self.data_label[0])
+                self.create_batch_shared(batchsz)
+        else:
+            raise ValueError("task_setup must be 'Disjoint' or 'Shared'")
+
+    # ---- CSV index (sdp.py:119-148): columns (pandas index, name, label); label kept as string
+    @staticmethod
+    def _group(names, labels):
+        dictGraphsLabels, dictLabels, dictGraphs = {}, {}, {}
+        for filename, label in zip(names, labels):
+            label = str(label)
+            g_idx = int(filename.split('_')[0])
+            dictGraphs.setdefault(g_idx, []).append(filename)
+            dictGraphsLabels.setdefault(g_idx, {}).setdefault(label, []).append(filename)
+            dictLabels.setdefault(label, []).append(filename)
+        return dictLabels, dictGraphs, dictGraphsLabels
+
+    def loadCSV(self, csvf):
+        names, labels = [], []
+        with open(csvf) as f:
+            rd = csv.reader(f, delimiter=',')
+            next(rd, None)
+            for row in rd:
+                names.append(row[1]); labels.append(row[2])
+        return self._group(names, labels)
+
+    # ---- task sampling (host bookkeeping on names; numpy/python global RNGs like the reference)
+    def _pick(self, pool, k_shot, k_query):
+        idx = np.random.choice(len(pool), k_shot + k_query, False)
+        np.random.shuffle(idx)
+        arr = np.array(pool)
+        return arr[idx[:k_shot]].tolist(), arr[idx[k_shot:]].tolist()
+
+    def create_batch_disjoint(self, batchsz):                                 # sdp.py:150-182
+        self.support_x_batch, self.query_x_batch = [], []
+        for _ in range(batchsz):
+            selected_cls = np.random.choice(self.cls_num, self.n_way, False)
+            np.random.shuffle(selected_cls)
+            support_x, query_x = [], []
+            for cls in selected_cls:
+                s, q = self._pick(self.data[cls], self.k_shot, self.k_query)
+                support_x.append(s); query_x.append(q)
+            random.shuffle(support_x); random.shuffle(query_x)
+            self.support_x_batch.append(support_x); self.query_x_batch.append(query_x)
+
+    def create_batch_shared(self, batchsz):                                   # sdp.py:184-247
+        self.support_x_batch, self.query_x_batch = [], []
+        for _ in range(batchsz):
+            data = self.data_label[np.random.choice(self.graph_num, 1, False)[0]]
+            selected_cls = np.arange(len(data)); np.random.shuffle(selected_cls)
+            support_x, query_x = [], []
+            for cls in selected_cls:
+                if len(data[cls]) < self.k_shot + self.k_query:
+                    raise ValueError('each class in a graph must have at least k_shot + k_query entities (sdp.py:218-240 fallback was "not used in practice")')
+                s, q = self._pick(data[cls], self.k_shot, self.k_query)
+                support_x.append(s); query_x.append(q)
+            random.shuffle(support_x); random.shuffle(query_x)
+            self.support_x_batch.append(support_x); self.query_x_batch.append(query_x)
+
+    def create_batch_LinkPred(self, batchsz):                                 # sdp.py:249-292
+        self.support_x_batch, self.query_x_batch = [], []
+        for _ in range(batchsz):
+            g = np.random.choice(self.graph_num_spt, 1, False)[0]
+            data_spt, data_qry = self.data_label_spt[g], self.data_label_qry[g]
+            cs = np.arange(len(data_spt)); np.random.shuffle(cs)
+            cq = np.arange(len(data_qry)); np.random.shuffle(cq)
+            support_x, query_x = [], []
+            for cls in cs:
+                idx = np.random.choice(len(data_spt[cls]), self.k_shot, False); np.random.shuffle(idx)
+                support_x.append(np.array(data_spt[cls])[idx].tolist())
+            for cls in cq:
+                idx = np.random.choice(len(data_qry[cls]), self.k_query, False); np.random.shuffle(idx)
+                query_x.append(np.array(data_qry[cls])[idx].tolist())
+            random.shuffle(support_x); random.shuffle(query_x)
+            self.support_x_batch.append(support_x); self.query_x_batch.append(query_x)
+
+    # ---- extraction
+    @staticmethod
+    def _seeds(names):
+        out = []
+        for item in names:
+            p = [int(x) for x in item.split('_')]
+            out.append(p + [-1] if len(p) == 2 else p)
+        return np.array(out, np.int32)
+
+    def _task_names(self, index):
+        spt = [item for sub in self.support_x_batch[index] for item in sub]
+        qry = [item for sub in self.query_x_batch[index] for item in sub]
+        return spt, qry
+
+    def _labels(self, spt, qry):
+        support_y = np.array([self.subgraph2label[i] for i in spt]).astype(np.int32)
+        query_y = np.array([self.subgraph2label[i] for i in qry]).astype(np.int32)
+        if self.task_setup == 'Disjoint':                                     # sdp.py:389-397
+            unique = np.unique(support_y)
+            random.shuffle(unique)
+            sy, qy = np.zeros(self.setsz), np.zeros(self.querysz)
+            for idx, l in enumerate(unique):
+                sy[support_y == l] = idx
+                qy[query_y == l] = idx
+            return torch.LongTensor(sy), torch.LongTensor(qy)
+        return torch.LongTensor(support_y), torch.LongTensor(query_y)
+
+    def _tuple(self, bs, bq, ys, yq):
+        return (bs, ys, bq, yq, torch.LongTensor(bs.centres_local().astype(np.int64)), torch.LongTensor(bq.centres_local().astype(np.int64)),
+                bs.node_lists(), bq.node_lists(), [int(g) for g in bs.graph_ids()], [int(g) for g in bq.graph_ids()])
+
+    def __getitem__(self, index):
+        """One task (sdp.py:348-408): the 10-tuple with SubgraphBatch handles in slots 0 and 2."""
+        spt, qry = self._task_names(index)
+        ys, yq = self._labels(spt, qry)
+        bs = SubgraphBatch.extract(self.G, self._seeds(spt), [0, len(spt)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        bq = SubgraphBatch.extract(self.G, self._seeds(qry), [0, len(qry)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        return self._tuple(bs, bq, ys, yq)
+
+    def get_batch(self, indices):
+        """MI355X-first counterpart of DataLoader(..., collate_fn=collate): the subgraphs of ALL tasks of a
+        meta-batch are extracted by two launches (support / query); returns the collated 10-tuple of lists."""
+        names = [self._task_names(i) for i in indices]
+        ys_yq = [self._labels(s, q) for s, q in names]
+        off_s = np.cumsum([0] + [len(s) for s, _ in names]); off_q = np.cumsum([0] + [len(q) for _, q in names])
+        S = SubgraphBatch.extract(self.G, np.concatenate([self._seeds(s) for s, _ in names]), off_s, self.h, self.sample_nodes,
+                                  self.rng_seed, self.link_pred_mode)
+        Q = SubgraphBatch.extract(self.G, np.concatenate([self._seeds(q) for _, q in names]), off_q, self.h, self.sample_nodes,
+                                  self.rng_seed, self.link_pred_mode)
+        return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])
+
+    def __len__(self):
+        return self.batchsz

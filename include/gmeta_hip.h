@@ -1,0 +1,178 @@
+/* gmeta_hip.h -- C ABI of libgmeta_hip.so: the MI355X (gfx950) implementation of G-Meta's
+ * inner-loop hot path.  Plain pointers and sizes only; no torch types.
+ *
+ * The reference (mims-harvard/G-Meta) is pure Python and has no FFI layer: its boundary is the
+ * Python call surface Subgraphs.__getitem__/collate -> Meta.forward/finetunning ->
+ * Classifier.forward, with all native work delegated to the third-party DGL 0.4.3 + torch 1.5.
+ * Each entry point below names the reference code it replaces (paths relative to
+ * /root/reference/G-Meta/).  The Python host mirror in g-meta_amd/ binds these through ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions: every function returns GM_OK (0) or a negative GM_E* code; gm_last_error()
+ * returns a thread-local message for the last failure.  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  Pointers documented "device" are HBM addresses on the
+ * current HIP device; "host" are ordinary host pointers.  Handles (gm_store_t, gm_batch_t) own
+ * their HBM and are released by the matching *_destroy; workspaces are caller-provided.
+ * A handle is not thread-safe; distinct handles may be used from distinct threads.
+ */
+#ifndef GMETA_HIP_H
+#define GMETA_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GM_OK 0
+#define GM_EINVAL (-1)  /* bad argument (also: update_step < 2, unequal class counts)      */
+#define GM_ENOMEM (-2)  /* HBM / workspace too small                                      */
+#define GM_EHIP (-3)    /* a HIP runtime call failed                                      */
+#define GM_ERANGE (-4)  /* size outside what the kernels support (e.g. graph > LDS bitmap) */
+#define GM_MAX_GCN 4
+
+typedef struct gm_store gm_store_t; /* parent graphs (in/out CSR) + node features, resident in HBM */
+typedef struct gm_batch gm_batch_t; /* a batched set of induced subgraphs (one or many task sets)   */
+
+typedef struct gm_seed { int32_t graph, i, j; } gm_seed_t; /* j = -1 for node classification */
+
+/* Model description == the `config` list built at train.py:67-75:
+ * [('GraphConv',[dims[0],dims[1]]), ..., ('Linear',[dims[n_gcn], n_out])] (+('LinkPred',[True])).
+ * Parameter vector layout (== Classifier.vars order, learner.py:81-97), flat fp32:
+ *   W_1[dims0 x dims1] row-major [in,out], b_1[dims1], ..., W_lin[n_out x (dims[n_gcn]*(1+link_pred))], b_lin[n_out] */
+typedef struct gm_model {
+    int32_t n_gcn;
+    int32_t dims[GM_MAX_GCN + 1];
+    int32_t n_out;
+    int32_t link_pred;
+} gm_model_t;
+
+/* Hyper-parameters read by Meta.__init__ (meta.py:85-92). */
+typedef struct gm_hparams {
+    float update_lr;       /* args.update_lr                                            */
+    int32_t update_step;   /* K: args.update_step (train) or args.update_step_test      */
+    int32_t k_spt;         /* n_support of proto_loss_spt (meta.py:123)                 */
+    int32_t need_meta_grad;/* 1 = Meta.forward (meta.py:101-173), 0 = finetunning (175-234) */
+    int32_t hoist_z1;      /* 0 = reference-equivalent schedule (every forward re-aggregates layer 1);
+                              1 = aggregate layer-1 input once per call (loop-invariant)   */
+} gm_hparams_t;
+
+const char* gm_last_error(void);
+int gm_version(void);
+
+/* ---- GraphStore: replaces the list of DGLGraph objects + `feat` list (train.py:41-44,63-65).
+ * indptr[g] (host int64[n_nodes[g]+1]) / indices[g] (host int32) = IN-edge CSR of graph g:
+ * row v lists the sources u of every edge u->v (parallel edges and self loops kept, DGL
+ * multigraph semantics of G.in_edges(v), sdp.py:301).  feat[g] = host fp32 [n_nodes[g], feat_dim]. */
+int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const int64_t* const* indptr,
+                    const int32_t* const* indices, const float* const* feat, int32_t feat_dim,
+                    gm_store_t** out);
+void gm_store_destroy(gm_store_t* s);
+
+/* ---- Extraction: replaces Subgraphs.generate_subgraph / generate_subgraph_link_pred
+ * (sdp.py:295-346: h-hop in-neighbour expansion, node sampling, G.subgraph) and dgl.batch
+ * (sdp.py:399-406) for n_sets sets at once.  seeds/set_offsets are host arrays; set s owns seeds
+ * [set_offsets[s], set_offsets[s+1]).  h in {1,2,3} (ignored when link_pred: i side 2 hops,
+ * j side 1 hop -- the reference's sdp.py:332 behaviour).  Nodes inside a subgraph are in
+ * ASCENDING parent id.  If a neighbourhood has more than sample_nodes nodes, sample_nodes of them
+ * are kept by a keyed permutation of (rng_seed, graph, i, j) and the centre(s) re-added
+ * (sdp.py:312-314,337-339). */
+int gm_extract(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds,
+               const int32_t* set_offsets, int32_t n_sets, int32_t h, int32_t sample_nodes,
+               uint64_t rng_seed, int32_t link_pred, void* stream, gm_batch_t** out);
+/* Same, but the node set of every subgraph is given (host, ascending, concatenated; subgraph k
+ * owns nodes_flat[nodes_off[k]..nodes_off[k+1])): G.subgraph(nodes) + dgl.batch only.  Used to
+ * replay node sets sampled elsewhere (e.g. by the reference's numpy RNG). */
+int gm_batch_from_nodes(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds,
+                        const int32_t* set_offsets, int32_t n_sets, const int32_t* nodes_flat,
+                        const int64_t* nodes_off, int32_t link_pred, void* stream, gm_batch_t** out);
+/* dgl.batch over already-built batches (sets are appended in order).  Inputs stay valid. */
+int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, void* stream, gm_batch_t** out);
+void gm_batch_destroy(gm_batch_t* b);
+
+/* Sizes: rows = total nodes, edges = total induced edges, subs = subgraphs, sets = task sets,
+ * centres = 1 (node-clf) or 2 (link-pred). */
+int gm_batch_dims(const gm_batch_t* b, int64_t* rows, int64_t* edges, int32_t* subs, int32_t* sets,
+                  int32_t* centres);
+enum gm_field {
+    GM_F_SUB_OFF = 0,   /* int32[subs+1]  row offset of each subgraph == cumsum(batch_num_nodes) (learner.py:161-163) */
+    GM_F_SET_SUB_OFF,   /* int32[sets+1]  subgraph range of each set                                                */
+    GM_F_PARENT,        /* int32[rows]    parent node id of each row == sub.parent_nid (sdp.py:317)                  */
+    GM_F_GRAPH,         /* int32[subs]    parent graph of each subgraph                                              */
+    GM_F_INDPTR,        /* int32[rows+1]  in-edge CSR of the batched induced graph                                   */
+    GM_F_INDICES,       /* int32[edges]   source ROW of every in-edge                                                */
+    GM_F_INDPTR_T,      /* int32[rows+1]  by-source CSR (for the backward aggregate)                                 */
+    GM_F_INDICES_T,     /* int32[edges]   destination ROW of every out-edge                                          */
+    GM_F_CENTRE,        /* int32[subs*centres] local index of the centre(s) inside each subgraph (sdp.py:318-319)    */
+    GM_F_NORM,          /* float[rows]    in_degree.clamp(1)^-0.5 (learner.py:29)                                    */
+    GM_F_FEAT_ROW       /* int32[rows]    row of the store's feature matrix for each batch row                       */
+};
+/* Copies a field to host memory (synchronises `stream` internally). */
+int gm_batch_read(const gm_batch_t* b, int32_t field, void* host_dst, int64_t bytes);
+/* Device address of a field (valid until gm_batch_destroy). */
+int gm_batch_device_ptr(const gm_batch_t* b, int32_t field, void** dptr);
+
+/* ---- Feature gather: replaces np.vstack([feat[g][ids] ...]) + H2D (meta.py:119-120,193-194).
+ * x_out: device fp32 [rows, feat_dim]. */
+int gm_gather_features(const gm_batch_t* b, float* x_out, void* stream);
+
+/* ---- GCN building blocks (GraphConv.forward, learner.py:25-56), exported for tests/profiling.
+ * out[v,:] = s_out[v] * sum_{u in row v} s_in[u] * x[u,:]   (s_in / s_out may be NULL = 1).
+ * transposed != 0 runs on the by-source CSR (autograd backward of update_all).  If gather != 0,
+ * x is ignored and rows are read from the store's features through GM_F_FEAT_ROW. */
+int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gather, const float* x, int32_t width,
+                 const float* s_in, const float* s_out, float* out, void* stream);
+int64_t gm_aggregate_bytes(const gm_batch_t* b, int32_t width); /* algorithmic HBM bytes of one call */
+
+/* ---- Classifier.forward / backward (learner.py:134-175) for a batch whose set s uses the
+ * parameter vector params + s*param_stride (param_stride = 0: every set shares one vector, the
+ * `vars=None` case).  x0: device [rows, dims[0]] or NULL (gather from the store).
+ * centre_local: device int32 [subs*centres] `to_fetch` override or NULL (use the batch's own).
+ * logits: device fp32 [subs, n_out].  ws must hold gm_gcn_ws_bytes(); it carries the activations
+ * from forward to backward (pass the same x0 / centre_local to both).  dlogits: device [subs, n_out];
+ * dparams: device, set s written at dparams + s*dparam_stride (dparam_stride >= P).
+ * params + s*param_stride must be 16-byte aligned for the vectorised weight loads (else a scalar path runs). */
+int64_t gm_model_param_count(const gm_model_t* m);
+int64_t gm_gcn_ws_bytes(const gm_batch_t* b, const gm_model_t* m);
+int gm_gcn_forward(const gm_batch_t* b, const gm_model_t* m, const float* params, int64_t param_stride,
+                   const float* x0, const int32_t* centre_local, float* logits, void* ws, int64_t ws_bytes,
+                   void* stream);
+int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* params, int64_t param_stride,
+                    const float* x0, const int32_t* centre_local, const float* dlogits, float* dparams,
+                    int64_t dparam_stride, void* ws, int64_t ws_bytes, void* stream);
+
+/* ---- Prototypical losses (meta.py:28-54 proto_loss_spt, 56-79 proto_loss_qry), per set.
+ * y: HOST int32 [subs] labels.  Outputs (device): loss[sets], acc[sets], protos[sets, c_task, n_out]
+ * (c_task = classes per set, must be equal across sets), dlogits[subs, n_out] (may be NULL),
+ * dprotos[sets, c_task, n_out] (qry only, may be NULL). */
+int gm_proto_loss_spt(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, int32_t n_support,
+                      float* loss, float* acc, float* protos, float* dlogits, void* stream);
+int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, const float* protos,
+                      int32_t c_task, float* loss, float* acc, float* dlogits, float* dprotos, void* stream);
+
+/* ---- The fused hot path: Meta.forward_ProtoMAML (meta.py:101-173) when need_meta_grad = 1,
+ * Meta.finetunning_ProtoMAML (meta.py:175-234) when 0, for ALL sets (tasks) of spt/qry at once.
+ * spt and qry must have the same number of sets; set t of each is task t.  y_spt / y_qry: HOST
+ * int32 labels per subgraph.  theta: device fp32 [P] (read only).
+ * out: device fp32 [P + 2*(K+1) + sets*(K+1)]:
+ *   [0,P)            SUM over tasks of the first-order meta-gradient (query path at fw_K + prototype
+ *                    path through the support forward at fw_{K-1}); zeros when need_meta_grad = 0
+ *   [P, P+K+1)       SUM over tasks of losses_q[k]   (meta.py:133,140,155)
+ *   [P+K+1, P+2K+2)  SUM over tasks of corrects[k]   (meta.py:134,141,157)
+ *   [P+2K+2, ...)    per-task query accuracy [sets, K+1]
+ * The caller divides by the (global) task count, applies the NaN guard (meta.py:163) and the
+ * optimiser -- after the RCCL all-reduce when tasks are sharded over GPUs. */
+int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry, const gm_model_t* m, const gm_hparams_t* hp);
+int64_t gm_meta_out_floats(const gm_batch_t* spt, const gm_model_t* m, const gm_hparams_t* hp);
+int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_spt, const int32_t* y_qry,
+                 const gm_model_t* m, const gm_hparams_t* hp, const float* theta, float* out, void* ws,
+                 int64_t ws_bytes, void* stream);
+
+/* Profiling aid for bench.py: HIP-event time (ms) of the aggregate launches of the last
+ * gm_meta_step on this thread, their count and their summed algorithmic bytes.  Events are only
+ * recorded when gm_profile_enable(1) was called (they add a few microseconds per launch). */
+void gm_profile_enable(int32_t on);
+int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMETA_HIP_H */
