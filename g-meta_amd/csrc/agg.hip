@@ -75,7 +75,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
         for (int k = 0; k < VEC; ++k) {
             float v = (vget(acc0, k) + vget(acc1, k)) * so;
             if (a.bias) v += a.bias[(int64_t)set * a.bias_stride + c0 + k];
-            if (a.relu) v = v > 0.f ? v : 0.f;
+            if (a.relu) v = v < 0.f ? 0.f : v;      // NaN propagates like torch relu (meta.py:163 guard)
             if (a.mask_h) v = a.mask_h[row * a.width + c0 + k] > 0.f ? v : 0.f;
             vset(res, k, v);
         }

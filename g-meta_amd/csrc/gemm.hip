@@ -164,7 +164,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
                 if (col >= g.N) continue;
                 float v = acc[i][j][e] * sc;
                 if (biasp) v += biasp[col];
-                if (g.relu) v = v > 0.f ? v : 0.f;
+                if (g.relu) v = v < 0.f ? 0.f : v;      // NaN propagates like torch relu
                 if (g.mask_h && !(g.mask_h[row * g.ldc + col] > 0.f)) v = 0.f;
                 g.C[row * g.ldc + col] = v;
             }

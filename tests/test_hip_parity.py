@@ -60,7 +60,7 @@ def test_extraction_bit_exact(case, replay):
     fx = Fixture(case)
     store = hu.make_store(fx)
     S, Q = hu.fixture_batches(fx, store, replay)
-    _, os_, oq_ = _oracle_batches(fx, replay)
+    graphs, os_, oq_ = _oracle_batches(fx, replay)
     for hipb, ob in ((S, os_), (Q, oq_)):
         ptr, idx, par, cen, norm, sub = _cat_csr(ob)
         assert hipb.rows == len(par) and hipb.edges == len(idx)
@@ -83,7 +83,9 @@ def test_extraction_bit_exact(case, replay):
                 for s in range(fx.z[tag + '_seeds'].shape[1]):
                     ours = par[sub[k]:sub[k + 1]]
                     ref = np.sort(fx.ref_nodes(tag, t, s))
-                    if len(ref) <= fx.args['sample_nodes'] and len(ours) <= fx.args['sample_nodes']:
+                    g, i, j = fx.z[tag + '_seeds'][t, s]
+                    full = orc.linkpred_nodes(graphs[g], i, j) if fx.link else orc.khop_nodes(graphs[g], i, fx.args['h'])
+                    if len(full) <= fx.args['sample_nodes']:
                         assert np.array_equal(ours, ref)
                     k += 1
 
