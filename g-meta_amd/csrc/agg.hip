@@ -6,6 +6,7 @@
 // output is written once.  A lane group of LPR lanes owns one destination row; each lane holds VEC
 // consecutive floats, so a 256-wide row is one 1-KiB coalesced access per wave.
 #include <algorithm>
+#include <stdlib.h>
 #include "gm_internal.h"
 
 #define AGG_BLOCK 256
@@ -14,6 +15,7 @@ struct AggK {
     const int32_t* indptr; const int32_t* indices; const float* x; const int32_t* x_row; int64_t ldx;
     const float* s_in; const float* s_out; const float* mask_h; const float* bias; int64_t bias_stride;
     const int32_t* set_row_off; int n_sets; int relu; float* out; int64_t rows; int width; int nblocks;
+    const int32_t* heavy; int n_heavy, heavy_deg;
 };
 
 template <int VEC> struct VecT;
@@ -83,6 +85,184 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
     }
 }
 
+// One workgroup per heavy row (in-degree > gm_heavy_deg(): hub nodes inside their own neighbourhood, up to ~1000 edges).
+// The 256/LPR lane groups take interleaved LPR-edge chunks (coalesced index loads, 8 row loads in flight each), the
+// partial rows are summed through LDS in a fixed order (deterministic), then the usual epilogue.
+template <int LPR, int NCH>
+__device__ __forceinline__ void agg_heavy_row(const AggK& a, int row) {
+    constexpr int NG = AGG_BLOCK / LPR;
+    __shared__ __attribute__((aligned(16))) float part[NG * LPR * 4 * NCH];
+    const int tid = threadIdx.x, gi = tid / LPR, l = tid % LPR, lane = tid & 63;
+    const int gbase = (lane / LPR) * LPR;                 // first lane of this group inside its wave
+    const int e0 = a.indptr[row], e1 = a.indptr[row + 1];
+    const float* xl = a.x + l * 4;
+    float4 acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int eb = e0 + gi * LPR; eb < e1; eb += NG * LPR) {
+        int mu = 0; float mw = 0.f;
+        if (eb + l < e1) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
+        const int cnt = min(LPR, e1 - eb);
+        for (int j = 0; j < cnt; j += 8) {
+            float4 v[8][NCH]; float ww[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int sl = gbase + ((j + i) & (LPR - 1));
+                const int uu = __shfl(mu, sl, 64);
+                ww[i] = (j + i < cnt) ? __shfl(mw, sl, 64) : 0.f;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) v[i][c] = *reinterpret_cast<const float4*>(xl + (int64_t)uu * a.ldx + c * LPR * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) vfma(acc[c], v[i][c], ww[i]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(&part[(gi * NCH + c) * LPR * 4 + l * 4]) = acc[c];
+    __syncthreads();
+    if (gi != 0) return;
+    const float so = a.s_out ? a.s_out[row] : 1.f;
+    const float* bp = nullptr;
+    if (a.bias) {
+        int set = 0;
+        if (a.bias_stride) {
+            int lo = 0, hi = a.n_sets;
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.set_row_off[mid] <= row) lo = mid; else hi = mid; }
+            set = lo;
+        }
+        bp = a.bias + (int64_t)set * a.bias_stride + l * 4;
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < NG; ++k) { const float4 t = *reinterpret_cast<const float4*>(&part[(k * NCH + c) * LPR * 4 + l * 4]); s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w; }
+        float4 v = make_float4(s4.x * so, s4.y * so, s4.z * so, s4.w * so);
+        if (bp) { const float4 bb = *reinterpret_cast<const float4*>(bp + c * LPR * 4); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+        if (a.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+        if (a.mask_h) {
+            const float4 m = *reinterpret_cast<const float4*>(a.mask_h + (int64_t)row * a.width + l * 4 + c * LPR * 4);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(a.out + (int64_t)row * a.width + l * 4 + c * LPR * 4) = v;
+    }
+}
+
+// Wave-cooperative kernel (the production path for widths 64/128/256/512).  Induced subgraphs are very sparse
+// (arxiv config: median in-degree 1, p90 2), so a row-per-wave kernel spends its life in the dependent chain
+// indptr -> indices -> scale -> row.  Here a wave owns a WINDOW of 64 consecutive rows: lane i fetches row i's CSR
+// bounds, its first two sources and their scales with coalesced loads (one dependent chain per 64 rows instead of
+// per row); then the row loads are issued from register-held addresses (broadcast by ds_bpermute), UNR rows at a
+// time, so up to 2*UNR independent 16-B loads per lane are in flight.  Edges beyond the second (p99 ~ 19) take a
+// conventional loop.  LPR = width/4 lanes own a row (width 256: the whole wave, 1 KiB per access).
+template <int LPR, int NCH>
+__global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
+    constexpr int G = GM_WAVE / LPR;           // rows processed side by side
+    constexpr int UNR = 4;
+    if ((int)blockIdx.x < a.n_heavy) { agg_heavy_row<LPR, NCH>(a, a.heavy[blockIdx.x]); return; }
+    const int nb = a.nblocks, b = blockIdx.x - a.n_heavy;
+    const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane / LPR, l = lane % LPR;
+    const int64_t R0 = ((int64_t)lb * (AGG_BLOCK / GM_WAVE) + wave) * GM_WAVE;
+    if (R0 >= a.rows) return;
+    // ---- per-lane row descriptor (coalesced)
+    const int64_t myrow = R0 + lane;
+    int p0 = 0, dg = 0, u0 = 0, u1 = 0; float w0 = 0.f, w1 = 0.f, so = 1.f;
+    if (myrow < a.rows) {
+        p0 = a.indptr[myrow]; dg = a.indptr[myrow + 1] - p0;
+        if (a.s_out) so = a.s_out[myrow];
+        if (dg >= 1) { u0 = a.indices[p0]; w0 = a.s_in ? a.s_in[u0] : 1.f; if (a.x_row) u0 = a.x_row[u0]; }
+        if (dg >= 2) { u1 = a.indices[p0 + 1]; w1 = a.s_in ? a.s_in[u1] : 1.f; if (a.x_row) u1 = a.x_row[u1]; }
+    }
+    const int nwin = (int)min((int64_t)GM_WAVE, a.rows - R0);
+    const float* xl = a.x + l * 4;
+    for (int t0 = 0; t0 < nwin; t0 += G * UNR) {
+        float4 acc[UNR][NCH];
+        int rdg[UNR], rp0[UNR]; float rso[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int rr = t0 + k * G + g;                      // row of this lane group inside the window
+            const int src = rr < GM_WAVE ? rr : 0;
+            rdg[k] = rr < nwin ? __shfl(dg, src, 64) : -1;
+            if (a.n_heavy && rdg[k] > a.heavy_deg) rdg[k] = -1;            // written by its own workgroup (agg_heavy_row)
+            rp0[k] = __shfl(p0, src, 64); rso[k] = __shfl(so, src, 64);
+            const int a0 = __shfl(u0, src, 64), a1 = __shfl(u1, src, 64);
+            const float f0 = __shfl(w0, src, 64), f1 = __shfl(w1, src, 64);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) acc[k][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rdg[k] >= 1) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) vfma(acc[k][c], *reinterpret_cast<const float4*>(xl + (int64_t)a0 * a.ldx + c * LPR * 4), f0);
+            }
+            if (rdg[k] >= 2) {
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) vfma(acc[k][c], *reinterpret_cast<const float4*>(xl + (int64_t)a1 * a.ldx + c * LPR * 4), f1);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            if (rdg[k] < 0) continue;
+            const int64_t row = R0 + t0 + k * G + g;
+            // rows with more than two in-edges (p99 ~ 19, hubs up to ~1000): the group's LPR lanes fetch the next LPR
+            // sources + scales with one coalesced load each, then 8 row loads at a time are issued from registers.
+            const int eend = rp0[k] + rdg[k];
+            for (int eb = rp0[k] + 2; eb < eend; eb += LPR) {
+                int mu = 0; float mw = 0.f;
+                if (eb + l < eend) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
+                const int cnt = min(LPR, eend - eb);
+                for (int j = 0; j < cnt; j += 8) {
+                    float4 v[8][NCH]; float ww[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int sl = g * LPR + ((j + i) & (LPR - 1));
+                        const int uu = __shfl(mu, sl, 64);
+                        ww[i] = (j + i < cnt) ? __shfl(mw, sl, 64) : 0.f;      // out-of-range slots re-read a valid row with weight 0
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) v[i][c] = *reinterpret_cast<const float4*>(xl + (int64_t)uu * a.ldx + c * LPR * 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+#pragma unroll
+                        for (int c = 0; c < NCH; ++c) vfma(acc[k][c], v[i][c], ww[i]);
+                }
+            }
+            const float* bp = nullptr;
+            if (a.bias) {
+                int set = 0;
+                if (a.bias_stride) {
+                    int lo = 0, hi = a.n_sets;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (a.set_row_off[mid] <= row) lo = mid; else hi = mid; }
+                    set = lo;
+                }
+                bp = a.bias + (int64_t)set * a.bias_stride + l * 4;
+            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const float s_ = rso[k];
+                float4 v = make_float4(acc[k][c].x * s_, acc[k][c].y * s_, acc[k][c].z * s_, acc[k][c].w * s_);
+                if (bp) { const float4 bb = *reinterpret_cast<const float4*>(bp + c * LPR * 4); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
+                if (a.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                if (a.mask_h) {
+                    const float4 m = *reinterpret_cast<const float4*>(a.mask_h + row * a.width + l * 4 + c * LPR * 4);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(a.out + row * a.width + l * 4 + c * LPR * 4) = v;
+            }
+        }
+    }
+}
+
+template <int LPR, int NCH>
+static void launch_win(const AggK& a0, hipStream_t s) {
+    AggK a = a0;
+    constexpr int RPB = GM_WAVE * (AGG_BLOCK / GM_WAVE);
+    a.nblocks = (int)((a.rows + RPB - 1) / RPB);
+    hipLaunchKernelGGL((k_agg_win<LPR, NCH>), dim3(a.nblocks + a.n_heavy), dim3(AGG_BLOCK), 0, s, a);
+}
+
 template <int VEC, int LPR>
 static void launch_one(const AggK& a0, hipStream_t s) {
     AggK a = a0;
@@ -91,12 +271,27 @@ static void launch_one(const AggK& a0, hipStream_t s) {
     hipLaunchKernelGGL((k_agg<VEC, LPR>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
+static int agg_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_AGG_VARIANT"); v = e ? atoi(e) : 0; }   // 1 = force the generic row-per-group kernel (debug)
+    return v;
+}
+
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
-           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0};
+           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
-    if (vec4) {
+    const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
+    const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
+    const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
+    if (!win) { a.heavy = nullptr; a.n_heavy = 0; }      // the generic kernel walks every row itself
+    if (win) {
+        if (g.width == 64) launch_win<16, 1>(a, s);
+        else if (g.width == 128) launch_win<32, 1>(a, s);
+        else if (g.width == 256) launch_win<64, 1>(a, s);
+        else launch_win<64, 2>(a, s);
+    } else if (vec4) {
         const int n4 = g.width / 4;
         if (n4 > 32) launch_one<4, 64>(a, s);
         else if (n4 > 16) launch_one<4, 32>(a, s);
@@ -134,6 +329,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.x = gather ? b->store->d_feat : x;
     a.x_row = gather ? b->d_feat_row : nullptr;
     a.ldx = width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
+    a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

@@ -1,5 +1,6 @@
 // Error handling, allocation helpers, model layout, aggregate-launch profiling.
 #include <stdarg.h>
+#include <stdlib.h>
 #include "gm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -107,4 +108,10 @@ extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t
     if (launches) *launches = g_prof.launches;
     if (algorithmic_bytes) *algorithmic_bytes = g_prof.bytes;
     return GM_OK;
+}
+
+int gm_heavy_deg() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_HEAVY_DEG"); v = e ? atoi(e) : 64; if (v < 2) v = 2; }
+    return v;
 }

@@ -298,6 +298,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
     }
 }
 
+// rows whose degree exceeds gm_heavy_deg() (hubs inside their own neighbourhood): appended to a list, sorted on the host
+__global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list, int32_t* count, int cap, int thr) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        if (indptr[r + 1] - indptr[r] > thr) { const int k = atomicAdd(count, 1); if (k < cap) list[k] = (int32_t)r; }
+    }
+}
 __global__ void k_copy_add(int32_t* dst, const int32_t* src, int64_t n, int32_t add) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k] + add;
 }
@@ -316,6 +322,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_parent, s); gm_dev_free(b->d_feat_row, s); gm_dev_free(b->d_indptr, s); gm_dev_free(b->d_indices, s);
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
+    gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s);
 }
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
@@ -324,8 +331,10 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
     for (int t = 0; t < b->sets; ++t)
         for (int k = b->h_set_sub_off[t]; k < b->h_set_sub_off[t + 1]; ++k) sub_set[k] = t;
-    int64_t cr = (b->rows / 768 + 31) / 32 * 32;
-    cr = std::max<int64_t>(512, std::min<int64_t>(8192, cr));
+    // weight-gradient blocks run one per CU (128 accumulator VGPRs): aim at 256 (small batches) or 512 chunks
+    const int64_t target = b->rows >= 400000 ? 512 : 256;
+    int64_t cr = ((b->rows + target - 1) / target + 31) / 32 * 32;
+    cr = std::max<int64_t>(128, cr);
     for (int t = 0; t < b->sets; ++t) {
         const int r0 = b->h_set_row_off[t], r1 = b->h_set_row_off[t + 1];
         for (int r = r0; r < r1; r += GM_GEMM_BM) { tiles.push_back(t); tiles.push_back(r); tiles.push_back(std::min(GM_GEMM_BM, r1 - r)); }
@@ -340,6 +349,30 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     if (!chunks.empty()) GM_HIP(hipMemcpyAsync(b->d_chunks, chunks.data(), 4 * chunks.size(), hipMemcpyHostToDevice, s));
     GM_HIP(hipMemcpyAsync(b->d_set_chunk_off, set_chunk_off.data(), 4 * set_chunk_off.size(), hipMemcpyHostToDevice, s));
     GM_HIP(hipStreamSynchronize(s));     // host vectors go out of scope
+    // heavy-row lists for both CSR orientations (a row can have at most rows-1... edges: cap = edges / heavy_deg + 1)
+    b->heavy_deg = gm_heavy_deg();
+    const int cap = (int)(b->edges / b->heavy_deg + 1);
+    int32_t* d_cnt = nullptr;
+    GM_TRY(gm_alloc(&d_cnt, 2, s));
+    GM_HIP(hipMemsetAsync(d_cnt, 0, 8, s));
+    for (int o = 0; o < 2; ++o) {
+        GM_TRY(gm_alloc(&b->d_heavy[o], cap, s));
+        const int blocks = (int)std::min<int64_t>(2048, (b->rows + 255) / 256);
+        hipLaunchKernelGGL(k_find_heavy, dim3(blocks), dim3(256), 0, s, o ? b->d_indptr_t : b->d_indptr, b->rows, b->d_heavy[o], d_cnt + o, cap, b->heavy_deg);
+    }
+    int32_t cnt[2];
+    GM_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    gm_dev_free(d_cnt, s);
+    for (int o = 0; o < 2; ++o) {
+        b->n_heavy[o] = std::min(cnt[o], cap);
+        if (b->n_heavy[o] > 1) {         // deterministic order (atomic append order is not)
+            std::vector<int32_t> h(b->n_heavy[o]);
+            GM_HIP(hipMemcpy(h.data(), b->d_heavy[o], 4 * h.size(), hipMemcpyDeviceToHost));
+            std::sort(h.begin(), h.end());
+            GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
+        }
+    }
     return GM_OK;
 }
 

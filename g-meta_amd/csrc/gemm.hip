@@ -14,15 +14,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GemmK {
     const float* A; int64_t lda; const float* B; int64_t b_stride; int transB; float* C; int64_t ldc; int K, N;
     const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
-    const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec;
+    const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec, c_vec;
 };
 
 // Block tile 128 x (64*WC); 2 x WC waves, each wave a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks.
 template <int WC>
 __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
     constexpr int NT = 128 * WC, BN = 64 * WC, BS_LD = BN + 4;
-    __shared__ __attribute__((aligned(16))) float As[GM_GEMM_BM * AS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[BK * BS_LD];
+    constexpr int EP_LD = 68;                                      // epilogue staging: 32 rows x 64 cols (+4 pad) per wave
+    constexpr int TILE_FLOATS = GM_GEMM_BM * AS_LD + BK * BS_LD, EPI_FLOATS = 2 * WC * 32 * EP_LD;
+    __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS];
+    float* As = smem;
+    float* Bs = smem + GM_GEMM_BM * AS_LD;
     // XCD-aware: hardware block b -> XCD b%8; make logical ids contiguous per XCD so that the column
     // tiles of one row tile (which share the A rows) and neighbouring row tiles share an L2.
     const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
@@ -148,25 +151,53 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
         __syncthreads();
         if (more) { store_tiles(); __syncthreads(); }
     }
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+    // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5): each lane holds one
+    // column, so a direct store would be 64 dword stores per lane (128-B runs, store-issue bound).  Stage each wave's
+    // 32x64 half through LDS instead and store whole 256-B row segments as float4 (16 stores per lane).
     const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+    float* E = smem + wave * (32 * EP_LD);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int col = n0 + wc * 64 + ec;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (biasp) {
+        if (col + 0 < g.N) b4.x = biasp[col + 0];
+        if (col + 1 < g.N) b4.y = biasp[col + 1];
+        if (col + 2 < g.N) b4.z = biasp[col + 2];
+        if (col + 3 < g.N) b4.w = biasp[col + 3];
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int rl = wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (rl >= nrows) continue;
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = wr * 64 + i * 32 + it * 4 + er;
+            if (rl >= nrows || col >= g.N) continue;
             const int64_t row = row0 + rl;
             const float sc = g.row_scale ? g.row_scale[row] : 1.f;
+            float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+            v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+            if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }   // NaN propagates like torch relu
+            float* dst = g.C + row * g.ldc + col;
+            if (g.c_vec) {
+                if (g.mask_h) {
+                    const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
+                *reinterpret_cast<float4*>(dst) = v;
+            } else {
+                const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wc * 64 + j * 32 + li;
-                if (col >= g.N) continue;
-                float v = acc[i][j][e] * sc;
-                if (biasp) v += biasp[col];
-                if (g.relu) v = v < 0.f ? 0.f : v;      // NaN propagates like torch relu
-                if (g.mask_h && !(g.mask_h[row * g.ldc + col] > 0.f)) v = 0.f;
-                g.C[row * g.ldc + col] = v;
+                for (int k = 0; k < 4; ++k) {
+                    if (col + k >= g.N) break;
+                    float o = vv[k];
+                    if (g.mask_h && !(g.mask_h[row * g.ldc + col + k] > 0.f)) o = 0.f;
+                    dst[k] = o;
+                }
             }
         }
     }
@@ -175,9 +206,10 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
-            a.tiles, a.n_tiles, 0, 0, 0};
+            a.tiles, a.n_tiles, 0, 0, 0, 0};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
     g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
+    g.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.mask_h || (((uintptr_t)a.mask_h & 15) == 0));
     if (a.N > 128) {
         g.n_col_tiles = (a.N + 255) / 256;
         hipLaunchKernelGGL((k_gemm_nn<4>), dim3(g.n_tiles * g.n_col_tiles), dim3(512), 0, s, g);
@@ -206,14 +238,15 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
 struct WgradK {
     const float* A; int64_t lda; int K; const int32_t* a_row;   // optional row indirection for A (feature gather)
     const float* G; int64_t ldg; int N; const float* Gb; int64_t ldgb;
-    const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN;
+    const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN; int vec;
 };
+
+#define WG_PF 4     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 4 * 512 * 4 floats per stage
 
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int ldA = w.TK * 32, ldG = w.TN * 32;
-    float* As = sm;                       // [RK][ldA]  (scaled, zero padded)
-    float* Gs = sm + (size_t)w.RK * ldA;  // [RK][ldG]
+    // One LDS matrix S[RK][ld]: columns [0, ldA) hold norm-scaled A rows (zero padded to 32), [ldA, ld) hold G rows.
+    const int ldA = w.TK * 32, ldG = w.TN * 32, ld = ldA + ldG, ld4 = ld >> 2, ldA4 = ldA >> 2;
     const int chunk = blockIdx.x, zt = blockIdx.y;     // zt: group of 64 output tiles
     const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
@@ -223,46 +256,86 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
     for (int t = 0; t < WG_MAXT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // thread accumulates db[tid + 512*j] (only zt == 0; N <= 2048)
-    const float* Gb = w.Gb ? w.Gb : w.G;
-    const int64_t ldgb = w.Gb ? w.ldgb : w.ldg;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // db[tid + 512*j] (only zt == 0; N <= 2048)
+    float4 pf[WG_PF];
+    const int per_stage4 = w.RK * ld4;                   // float4 elements per stage (<= WG_PF * 512)
 
-    for (int r0 = 0; r0 < nrows; r0 += w.RK) {
+    auto load_stage = [&](int r0) {
         const int nr = min(w.RK, nrows - r0);
-        for (int id = tid; id < w.RK * ldA; id += WG_THREADS) {
-            const int rr = id / ldA, k = id - rr * ldA;
-            float v = 0.f;
-            if (rr < nr && k < w.K) {
-                const int64_t row = row0 + r0 + rr;
-                const int64_t ar = w.a_row ? w.a_row[row] : row;
-                v = w.A[ar * w.lda + k] * (w.a_scale ? w.a_scale[row] : 1.f);
-            }
-            As[id] = v;
-        }
-        for (int id = tid; id < w.RK * ldG; id += WG_THREADS) {
-            const int rr = id / ldG, n = id - rr * ldG;
-            Gs[id] = (rr < nr && n < w.N) ? w.G[(int64_t)(row0 + r0 + rr) * w.ldg + n] : 0.f;
-        }
-        if (zt == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = tid + j * WG_THREADS;
-                if (n < w.N) for (int rr = 0; rr < nr; ++rr) bsum[j] += Gb[(int64_t)(row0 + r0 + rr) * ldgb + n];
+        for (int p = 0; p < WG_PF; ++p) {
+            const int id = tid + p * WG_THREADS;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (id < per_stage4) {
+                const int rr = id / ld4, c4 = id - rr * ld4;
+                if (rr < nr) {
+                    const int64_t row = row0 + r0 + rr;
+                    if (c4 < ldA4) {
+                        const int k = c4 * 4;
+                        if (k < w.K) {
+                            const int64_t ar = w.a_row ? w.a_row[row] : row;
+                            const float* src = w.A + ar * w.lda + k;
+                            const float sc = w.a_scale ? w.a_scale[row] : 1.f;
+                            if (w.vec) v = *reinterpret_cast<const float4*>(src);
+                            else { v.x = src[0]; if (k + 1 < w.K) v.y = src[1]; if (k + 2 < w.K) v.z = src[2]; if (k + 3 < w.K) v.w = src[3]; }
+                            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                        }
+                    } else {
+                        const int n = (c4 - ldA4) * 4;
+                        if (n < w.N) {
+                            const float* src = w.G + row * w.ldg + n;
+                            if (w.vec) v = *reinterpret_cast<const float4*>(src);
+                            else { v.x = src[0]; if (n + 1 < w.N) v.y = src[1]; if (n + 2 < w.N) v.z = src[2]; if (n + 3 < w.N) v.w = src[3]; }
+                        }
+                    }
+                }
+            }
+            pf[p] = v;
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int p = 0; p < WG_PF; ++p) {
+            const int id = tid + p * WG_THREADS;
+            if (id < per_stage4) *reinterpret_cast<float4*>(&sm[id * 4]) = pf[p];
+        }
+    };
+
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (int r0 = 0; r0 < nrows; r0 += w.RK) {
+        const bool more = r0 + w.RK < nrows;
+        if (more) load_stage(r0 + w.RK);                 // next stage's HBM reads fly under this stage's MFMAs
+        if (zt == 0) {
+            if (!w.Gb) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tid + j * WG_THREADS;
+                    if (n < w.N) for (int rr = 0; rr < w.RK; ++rr) bsum[j] += sm[rr * ld + ldA + n];
+                }
+            } else {
+                const int nr = min(w.RK, nrows - r0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tid + j * WG_THREADS;
+                    if (n < w.N) for (int rr = 0; rr < nr; ++rr) bsum[j] += w.Gb[(int64_t)(row0 + r0 + rr) * w.ldgb + n];
+                }
             }
         }
-        __syncthreads();
 #pragma unroll
         for (int t = 0; t < WG_MAXT; ++t) {
             const int tt = zt * (WG_WAVES * WG_MAXT) + t * WG_WAVES + wave;
             if (tt < TT) {
                 const int tk = tt / w.TN, tn = tt - tk * w.TN;
-                const float* ap = As + tk * 32 + li;
-                const float* gp = Gs + tn * 32 + li;
+                const float* ap = sm + tk * 32 + li + kh * ld;
+                const float* gp = sm + ldA + tn * 32 + li + kh * ld;
                 for (int kk = 0; kk < w.RK; kk += 2)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[(kk + kh) * ldA], gp[(kk + kh) * ldG], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * ld], gp[kk * ld], acc[t], 0, 0, 0);
             }
         }
         __syncthreads();
+        if (more) { store_stage(); __syncthreads(); }
     }
     float* out = w.partial + (int64_t)chunk * (w.K + 1) * w.N;
 #pragma unroll
@@ -305,7 +378,10 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
     w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
     const int ld = (w.TK + w.TN) * 32;
-    w.RK = ld <= 768 ? 32 : ld <= 1536 ? 16 : 8;
+    w.RK = 32;
+    while (w.RK > 2 && w.RK * ld > WG_PF * WG_THREADS * 4) w.RK >>= 1;
+    GM_REQUIRE(w.RK * ld <= WG_PF * WG_THREADS * 4, GM_ERANGE, "wgrad: K=%d N=%d too wide", a.K, a.N);
+    w.vec = (a.K % 4 == 0) && (a.N % 4 == 0) && (a.lda % 4 == 0) && (a.ldg % 4 == 0) && (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
     const size_t lds = (size_t)w.RK * ld * sizeof(float);
     GM_REQUIRE(lds <= 160 * 1024, GM_ERANGE, "wgrad: K=%d N=%d needs %zu B of LDS", a.K, a.N, lds);
     static bool attr = false;

@@ -72,6 +72,9 @@ struct gm_batch {
     int32_t* d_chunks = nullptr;       // [n_chunks*3] weight-gradient row chunks: set, row0, nrows
     int32_t n_chunks = 0;
     int32_t* d_set_chunk_off = nullptr;// [sets+1]
+    int32_t* d_heavy[2] = {nullptr, nullptr};   // rows with more than gm_heavy_deg() edges, by-destination / by-source CSR
+    int32_t n_heavy[2] = {0, 0};
+    int32_t heavy_deg = 64;
     hipStream_t stream = nullptr;      // stream the arrays were produced on
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);
@@ -110,7 +113,11 @@ struct gm_agg_args {
     float* out;                // [rows, width]
     int64_t rows;
     int width;
+    const int32_t* heavy;      // optional list of rows with more than GM_HEAVY_DEG edges (processed by a whole workgroup)
+    int n_heavy;
+    int heavy_deg;
 };
+int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG, default 64)
 int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);
 
 // Grouped GEMM  C[rows of set t] = epi( A[rows] @ op(B_t) ),  A [rows,K] (lda), C [rows,N] (ldc).
