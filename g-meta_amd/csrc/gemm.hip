@@ -18,14 +18,12 @@ struct GemmK {
 };
 
 // Block tile 128 x (64*WC); 2 x WC waves, each wave a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks.
-template <int WC>
+template <int WC, bool VEC, bool TB>
 __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
     constexpr int NT = 128 * WC, BN = 64 * WC, BS_LD = BN + 4;
     constexpr int EP_LD = 68;                                      // epilogue staging: 32 rows x 64 cols (+4 pad) per wave
     constexpr int TILE_FLOATS = GM_GEMM_BM * AS_LD + BK * BS_LD, EPI_FLOATS = 2 * WC * 32 * EP_LD;
-    __shared__ __attribute__((aligned(16))) float smem[TILE_FLOATS > EPI_FLOATS ? TILE_FLOATS : EPI_FLOATS];
-    float* As = smem;
-    float* Bs = smem + GM_GEMM_BM * AS_LD;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS > EPI_FLOATS ? 2 * TILE_FLOATS : EPI_FLOATS];
     // XCD-aware: hardware block b -> XCD b%8; make logical ids contiguous per XCD so that the column
     // tiles of one row tile (which share the A rows) and neighbouring row tiles share an L2.
     const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
@@ -38,7 +36,6 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave / WC, wc = wave % WC;
     const int li = lane & 31, kh = lane >> 5;
-    const bool kvec = g.a_vec, nvec = g.b_vec;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -51,82 +48,83 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
     constexpr int A_PER = (GM_GEMM_BM * BK / 4 + NT - 1) / NT;   // float4 per thread for the A tile
     constexpr int B_PER = (BK * BN / 4) / NT;                     // == 2
     float4 ra[A_PER], rb[B_PER];
-
+    unsigned okA = 0, okB = 0;       // validity bits, applied when the registers are written to LDS (after the MFMAs), so
+                                     // the loads below are unconditional (clamped addresses), branch-free and stay in flight
+    auto ld4 = [&](const float* base, int64_t off, int64_t lim) -> float4 {   // 4 floats at base[off..off+3], reads clamped to < lim
+        if (VEC) return *reinterpret_cast<const float4*>(base + off);
+        float4 v;
+        v.x = base[min(off + 0, lim - 1)]; v.y = base[min(off + 1, lim - 1)]; v.z = base[min(off + 2, lim - 1)]; v.w = base[min(off + 3, lim - 1)];
+        return v;
+    };
     auto load_tiles = [&](int k0) {
+        okA = 0; okB = 0;
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
-            const int id = tid + p * NT;
+            const int id = min(tid + p * NT, GM_GEMM_BM * BK / 4 - 1);
             const int rr = id >> 2, c4 = (id & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id < GM_GEMM_BM * BK / 4 && rr < nrows) {
-                const float* src = g.A + (int64_t)(row0 + rr) * g.lda + k0 + c4;
-                if (kvec) { if (k0 + c4 < g.K) v = *reinterpret_cast<const float4*>(src); }
-                else {
-                    if (k0 + c4 + 0 < g.K) v.x = src[0];
-                    if (k0 + c4 + 1 < g.K) v.y = src[1];
-                    if (k0 + c4 + 2 < g.K) v.z = src[2];
-                    if (k0 + c4 + 3 < g.K) v.w = src[3];
-                }
-            }
-            ra[p] = v;
+            const int kc = VEC ? min(k0 + c4, g.K - 4) : min(k0 + c4, g.K - 1);
+            const int64_t off = (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + kc;
+            ra[p] = ld4(g.A, off, (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + g.K);
+            if (rr < nrows && k0 + c4 < g.K) okA |= 1u << p;
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
             const int id = tid + p * NT;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!g.transB) {
+            if (!TB) {
                 const int kk = id / (BN / 4), n = n0 + (id % (BN / 4)) * 4;
-                if (k0 + kk < g.K) {
-                    const float* src = Bp + (int64_t)(k0 + kk) * g.N + n;
-                    if (nvec) { if (n < g.N) v = *reinterpret_cast<const float4*>(src); }
-                    else {
-                        if (n + 0 < g.N) v.x = src[0];
-                        if (n + 1 < g.N) v.y = src[1];
-                        if (n + 2 < g.N) v.z = src[2];
-                        if (n + 3 < g.N) v.w = src[3];
-                    }
-                }
+                const int kr = min(k0 + kk, g.K - 1), nc = VEC ? min(n, g.N - 4) : min(n, g.N - 1);
+                rb[p] = ld4(Bp, (int64_t)kr * g.N + nc, (int64_t)kr * g.N + g.N);
+                if (k0 + kk < g.K && n < g.N) okB |= 1u << p;
             } else {   // B[k][n] = W[n][k], W stored [N][K]: read along k
                 const int n = n0 + (id >> 2), c4 = (id & 3) * 4;
-                if (n < g.N) {
-                    const float* src = Bp + (int64_t)n * g.K + k0 + c4;
-                    if (nvec) { if (k0 + c4 < g.K) v = *reinterpret_cast<const float4*>(src); }
-                    else {
-                        if (k0 + c4 + 0 < g.K) v.x = src[0];
-                        if (k0 + c4 + 1 < g.K) v.y = src[1];
-                        if (k0 + c4 + 2 < g.K) v.z = src[2];
-                        if (k0 + c4 + 3 < g.K) v.w = src[3];
-                    }
-                }
+                const int nr_ = min(n, g.N - 1), kc = VEC ? min(k0 + c4, g.K - 4) : min(k0 + c4, g.K - 1);
+                rb[p] = ld4(Bp, (int64_t)nr_ * g.K + kc, (int64_t)nr_ * g.K + g.K);
+                if (n < g.N && k0 + c4 < g.K) okB |= 1u << p;
             }
-            rb[p] = v;
         }
     };
-    auto store_tiles = [&]() {
+    auto kmask = [&](float4 v, int kbase, int lim) -> float4 {        // zero the lanes of a k-vector that run past K (scalar path only)
+        if (VEC) return v;
+        if (kbase + 1 >= lim) v.y = 0.f;
+        if (kbase + 2 >= lim) v.z = 0.f;
+        if (kbase + 3 >= lim) v.w = 0.f;
+        return v;
+    };
+    auto store_tiles = [&](int buf, int k0) {
+        float* As = smem + buf * TILE_FLOATS;
+        float* Bs = As + GM_GEMM_BM * AS_LD;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) {
             const int id = tid + p * NT;
-            if (id < GM_GEMM_BM * BK / 4) *reinterpret_cast<float4*>(&As[(id >> 2) * AS_LD + (id & 3) * 4]) = ra[p];
+            const float4 v = (okA >> p) & 1u ? kmask(ra[p], k0 + (id & 3) * 4, g.K) : z;
+            if (id < GM_GEMM_BM * BK / 4) *reinterpret_cast<float4*>(&As[(id >> 2) * AS_LD + (id & 3) * 4]) = v;
         }
 #pragma unroll
         for (int p = 0; p < B_PER; ++p) {
             const int id = tid + p * NT;
-            if (!g.transB) {
-                *reinterpret_cast<float4*>(&Bs[(id / (BN / 4)) * BS_LD + (id % (BN / 4)) * 4]) = rb[p];
+            if (!TB) {
+                const float4 v = (okB >> p) & 1u ? kmask(rb[p], n0 + (id % (BN / 4)) * 4, g.N) : z;
+                *reinterpret_cast<float4*>(&Bs[(id / (BN / 4)) * BS_LD + (id % (BN / 4)) * 4]) = v;
             } else {
                 const int n = id >> 2, c4 = (id & 3) * 4;
-                Bs[(c4 + 0) * BS_LD + n] = rb[p].x; Bs[(c4 + 1) * BS_LD + n] = rb[p].y;
-                Bs[(c4 + 2) * BS_LD + n] = rb[p].z; Bs[(c4 + 3) * BS_LD + n] = rb[p].w;
+                const float4 v = (okB >> p) & 1u ? kmask(rb[p], k0 + c4, g.K) : z;
+                Bs[(c4 + 0) * BS_LD + n] = v.x; Bs[(c4 + 1) * BS_LD + n] = v.y;
+                Bs[(c4 + 2) * BS_LD + n] = v.z; Bs[(c4 + 3) * BS_LD + n] = v.w;
             }
         }
     };
 
+    // double-buffered LDS: chunk k+1 is written to the other buffer while chunk k is consumed -> one barrier per chunk
     load_tiles(0);
-    store_tiles();
+    store_tiles(0, 0);
     __syncthreads();
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    int buf = 0;
+    for (int k0 = 0; k0 < g.K; k0 += BK, buf ^= 1) {
         const bool more = k0 + BK < g.K;
         if (more) load_tiles(k0 + BK);                 // global loads for the next chunk fly under the MFMAs
+        const float* As = smem + buf * TILE_FLOATS;
+        const float* Bs = As + GM_GEMM_BM * AS_LD;
         // A fragments: lane (li,kh) takes k = 8q + 4kh + r  (r = 0..3) of its row -> MFMA step 4q + r
         float4 af[2][2];
 #pragma unroll
@@ -148,8 +146,8 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
             }
         }
+        if (more) store_tiles(buf ^ 1, k0 + BK);      // the other buffer was last read before the previous barrier
         __syncthreads();
-        if (more) { store_tiles(); __syncthreads(); }
     }
     // epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5): each lane holds one
     // column, so a direct store would be 64 dword stores per lane (128-B runs, store-issue bound).  Stage each wave's
@@ -210,16 +208,19 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
     g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
     g.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.mask_h || (((uintptr_t)a.mask_h & 15) == 0));
-    if (a.N > 128) {
-        g.n_col_tiles = (a.N + 255) / 256;
-        hipLaunchKernelGGL((k_gemm_nn<4>), dim3(g.n_tiles * g.n_col_tiles), dim3(512), 0, s, g);
-    } else if (a.N > 64) {
-        g.n_col_tiles = 1;
-        hipLaunchKernelGGL((k_gemm_nn<2>), dim3(g.n_tiles), dim3(256), 0, s, g);
-    } else {
-        g.n_col_tiles = 1;
-        hipLaunchKernelGGL((k_gemm_nn<1>), dim3(g.n_tiles), dim3(128), 0, s, g);
-    }
+    const bool vec = g.a_vec && g.b_vec && a.K >= 4 && a.N >= 4;
+#define GM_LAUNCH_GEMM(WC_, THREADS_)                                                                                         \
+    do {                                                                                                                      \
+        const dim3 grid(g.n_tiles * g.n_col_tiles), blk(THREADS_);                                                            \
+        if (vec && a.transB) hipLaunchKernelGGL((k_gemm_nn<WC_, true, true>), grid, blk, 0, s, g);                             \
+        else if (vec) hipLaunchKernelGGL((k_gemm_nn<WC_, true, false>), grid, blk, 0, s, g);                                   \
+        else if (a.transB) hipLaunchKernelGGL((k_gemm_nn<WC_, false, true>), grid, blk, 0, s, g);                              \
+        else hipLaunchKernelGGL((k_gemm_nn<WC_, false, false>), grid, blk, 0, s, g);                                           \
+    } while (0)
+    if (a.N > 128) { g.n_col_tiles = (a.N + 255) / 256; GM_LAUNCH_GEMM(4, 512); }
+    else if (a.N > 64) { g.n_col_tiles = 1; GM_LAUNCH_GEMM(2, 256); }
+    else { g.n_col_tiles = 1; GM_LAUNCH_GEMM(1, 128); }
+#undef GM_LAUNCH_GEMM
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -229,11 +230,11 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
 // The reduction runs over the (huge, ragged) row dimension, so it is the MFMA k dimension here:
 // both operands are read in their natural row-major layout (lane i of a half-wave reads 32
 // consecutive floats of one row).  One block per row chunk accumulates the whole K x N tile grid
-// in registers (8 waves x up to 8 MFMA 32x32 tiles); chunk partials are reduced in a second,
+// in registers (16 waves x up to 4 MFMA 32x32 tiles); chunk partials are reduced in a second,
 // deterministic pass (no float atomics).
-#define WG_THREADS 512
-#define WG_WAVES 8
-#define WG_MAXT 8
+#define WG_THREADS 1024
+#define WG_WAVES 16
+#define WG_MAXT 4
 
 struct WgradK {
     const float* A; int64_t lda; int K; const int32_t* a_row;   // optional row indirection for A (feature gather)
@@ -241,7 +242,7 @@ struct WgradK {
     const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN; int vec;
 };
 
-#define WG_PF 4     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 4 * 512 * 4 floats per stage
+#define WG_PF 2     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 2 * 1024 * 4 floats per stage
 
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -256,51 +257,56 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
     for (int t = 0; t < WG_MAXT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-    float bsum[4] = {0.f, 0.f, 0.f, 0.f};               // db[tid + 512*j] (only zt == 0; N <= 2048)
-    float4 pf[WG_PF];
+    float bsum[2] = {0.f, 0.f};                         // db[tid + 1024*j] (only zt == 0; N <= 2048)
+    float4 pf[WG_PF]; float pfs[WG_PF];                 // prefetched values and their (deferred) row scales
     const int per_stage4 = w.RK * ld4;                   // float4 elements per stage (<= WG_PF * 512)
 
-    auto load_stage = [&](int r0) {
+    unsigned okS = 0;
+    auto load_stage = [&](int r0) {                       // unconditional, clamped loads; validity applied in store_stage
         const int nr = min(w.RK, nrows - r0);
+        okS = 0;
 #pragma unroll
         for (int p = 0; p < WG_PF; ++p) {
-            const int id = tid + p * WG_THREADS;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (id < per_stage4) {
-                const int rr = id / ld4, c4 = id - rr * ld4;
-                if (rr < nr) {
-                    const int64_t row = row0 + r0 + rr;
-                    if (c4 < ldA4) {
-                        const int k = c4 * 4;
-                        if (k < w.K) {
-                            const int64_t ar = w.a_row ? w.a_row[row] : row;
-                            const float* src = w.A + ar * w.lda + k;
-                            const float sc = w.a_scale ? w.a_scale[row] : 1.f;
-                            if (w.vec) v = *reinterpret_cast<const float4*>(src);
-                            else { v.x = src[0]; if (k + 1 < w.K) v.y = src[1]; if (k + 2 < w.K) v.z = src[2]; if (k + 3 < w.K) v.w = src[3]; }
-                            v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-                        }
-                    } else {
-                        const int n = (c4 - ldA4) * 4;
-                        if (n < w.N) {
-                            const float* src = w.G + row * w.ldg + n;
-                            if (w.vec) v = *reinterpret_cast<const float4*>(src);
-                            else { v.x = src[0]; if (n + 1 < w.N) v.y = src[1]; if (n + 2 < w.N) v.z = src[2]; if (n + 3 < w.N) v.w = src[3]; }
-                        }
-                    }
-                }
-            }
+            const int id = min(tid + p * WG_THREADS, per_stage4 - 1);
+            const int rr = id / ld4, c4 = id - rr * ld4;
+            const int64_t row = row0 + r0 + min(rr, nr - 1);
+            const bool isA = c4 < ldA4;
+            const int col = isA ? c4 * 4 : (c4 - ldA4) * 4;
+            const int lim = isA ? w.K : w.N;
+            const int64_t ar = (isA && w.a_row) ? w.a_row[row] : row;
+            const float* base = isA ? w.A + ar * w.lda : w.G + row * w.ldg;
+            float4 v;
+            if (w.vec) v = *reinterpret_cast<const float4*>(base + min(col, lim - 4));
+            else { v.x = base[min(col, lim - 1)]; v.y = base[min(col + 1, lim - 1)]; v.z = base[min(col + 2, lim - 1)]; v.w = base[min(col + 3, lim - 1)]; }
             pf[p] = v;
+            pfs[p] = (isA && w.a_scale) ? w.a_scale[row] : 1.f;
+            // validity bits: bit p = whole element valid; bits 8+4p.. = lanes y,z,w inside the column range
+            unsigned ok = (tid + p * WG_THREADS < per_stage4 && rr < nr && col < lim) ? 1u : 0u;
+            okS |= ok << p;
+            okS |= ((col + 1 < lim ? 1u : 0u) | (col + 2 < lim ? 2u : 0u) | (col + 3 < lim ? 4u : 0u)) << (8 + 4 * p);
         }
     };
     auto store_stage = [&]() {
 #pragma unroll
         for (int p = 0; p < WG_PF; ++p) {
             const int id = tid + p * WG_THREADS;
-            if (id < per_stage4) *reinterpret_cast<float4*>(&sm[id * 4]) = pf[p];
+            const float sc = (okS >> p) & 1u ? pfs[p] : 0.f;
+            const unsigned lm = (okS >> (8 + 4 * p)) & 7u;
+            const float4 v = make_float4(pf[p].x * sc, (lm & 1u) ? pf[p].y * sc : 0.f, (lm & 2u) ? pf[p].z * sc : 0.f, (lm & 4u) ? pf[p].w * sc : 0.f);
+            if (id < per_stage4) *reinterpret_cast<float4*>(&sm[id * 4]) = v;
         }
     };
 
+    // fragment base pointers of this wave's output tiles (inactive tiles read tile 0 harmlessly)
+    int apT[WG_MAXT], gpT[WG_MAXT], actT = 0;          // LDS float offsets
+#pragma unroll
+    for (int t = 0; t < WG_MAXT; ++t) {
+        const int tt = zt * (WG_WAVES * WG_MAXT) + t * WG_WAVES + wave;
+        const int tq = tt < TT ? tt : 0;
+        const int tk = tq / w.TN, tn = tq - tk * w.TN;
+        apT[t] = tk * 32 + li + kh * ld; gpT[t] = ldA + tn * 32 + li + kh * ld;
+        if (tt < TT) actT |= 1 << t;
+    }
     load_stage(0);
     store_stage();
     __syncthreads();
@@ -310,29 +316,28 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
         if (zt == 0) {
             if (!w.Gb) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 2; ++j) {
                     const int n = tid + j * WG_THREADS;
                     if (n < w.N) for (int rr = 0; rr < w.RK; ++rr) bsum[j] += sm[rr * ld + ldA + n];
                 }
             } else {
                 const int nr = min(w.RK, nrows - r0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < 2; ++j) {
                     const int n = tid + j * WG_THREADS;
                     if (n < w.N) for (int rr = 0; rr < nr; ++rr) bsum[j] += w.Gb[(int64_t)(row0 + r0 + rr) * w.ldgb + n];
                 }
             }
         }
+        // all fragments of one k-pair are read first (independent ds_reads), then the wave's MFMAs issue back to back
+#pragma unroll 1
+        for (int kk = 0; kk < w.RK; kk += 2) {
+            float av[WG_MAXT], gv[WG_MAXT];
 #pragma unroll
-        for (int t = 0; t < WG_MAXT; ++t) {
-            const int tt = zt * (WG_WAVES * WG_MAXT) + t * WG_WAVES + wave;
-            if (tt < TT) {
-                const int tk = tt / w.TN, tn = tt - tk * w.TN;
-                const float* ap = sm + tk * 32 + li + kh * ld;
-                const float* gp = sm + ldA + tn * 32 + li + kh * ld;
-                for (int kk = 0; kk < w.RK; kk += 2)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk * ld], gp[kk * ld], acc[t], 0, 0, 0);
-            }
+            for (int t = 0; t < WG_MAXT; ++t) { av[t] = sm[apT[t] + kk * ld]; gv[t] = sm[gpT[t] + kk * ld]; }
+#pragma unroll
+            for (int t = 0; t < WG_MAXT; ++t)
+                if (actT & (1 << t)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], gv[t], acc[t], 0, 0, 0);
         }
         __syncthreads();
         if (more) { store_stage(); __syncthreads(); }
@@ -353,8 +358,102 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
     }
     if (zt == 0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const int n = tid + j * WG_THREADS; if (n < w.N) out[(int64_t)w.K * w.N + n] = bsum[j]; }
+        for (int j = 0; j < 2; ++j) { const int n = tid + j * WG_THREADS; if (n < w.N) out[(int64_t)w.K * w.N + n] = bsum[j]; }
     }
+}
+
+// Specialised weight-gradient kernel: K = 32*TK, N = 32*TN known at compile time (the hidden sizes 64/128/256 of
+// the reference's configs), vectorised operands, no row indirection.  All per-thread staging coordinates are
+// stage-invariant, nothing spills, and the only waits on the prefetch loads sit after the MFMA loop.
+template <int TK, int TN>
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
+    constexpr int ldA = TK * 32, ldG = TN * 32, ld = ldA + ldG, ld4 = ld / 4;
+    constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
+    constexpr int PER4 = RK * ld4, PF = (PER4 + WG_THREADS - 1) / WG_THREADS;
+    constexpr int TT = TK * TN, TPW = (TT + WG_WAVES - 1) / WG_WAVES;
+    static_assert(PF <= 2 && TPW <= 4, "tile grid too large for the fast weight-gradient kernel");
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int chunk = blockIdx.x;
+    const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    f32x16 acc[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    // stage-invariant staging coordinates of this thread's PF float4 slots
+    int rrp[PF], colp[PF]; bool isA[PF], inr[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int id = tid + p * WG_THREADS;
+        inr[p] = id < PER4;
+        const int idc = inr[p] ? id : 0;
+        rrp[p] = idc / ld4;
+        const int c4 = idc % ld4;
+        isA[p] = c4 < ldA / 4;
+        colp[p] = isA[p] ? c4 * 4 : (c4 - ldA / 4) * 4;
+    }
+    float4 pf[PF]; float pfs[PF];
+    float bsum = 0.f;
+    auto load_stage = [&](int r0) {
+        const int nr = min(RK, nrows - r0);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int64_t row = row0 + r0 + min(rrp[p], nr - 1);
+            const float* src = isA[p] ? w.A + row * w.lda + colp[p] : w.G + row * w.ldg + colp[p];
+            pf[p] = *reinterpret_cast<const float4*>(src);
+            pfs[p] = (isA[p] && w.a_scale) ? w.a_scale[row] : 1.f;
+            if (!(inr[p] && rrp[p] < nr)) pfs[p] = 0.f;          // rows past the chunk end contribute zeros
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int p = 0; p < PF; ++p)
+            if (inr[p]) *reinterpret_cast<float4*>(&sm[(tid + p * WG_THREADS) * 4]) = make_float4(pf[p].x * pfs[p], pf[p].y * pfs[p], pf[p].z * pfs[p], pf[p].w * pfs[p]);
+    };
+    load_stage(0);
+    store_stage();
+    __syncthreads();
+    for (int r0 = 0; r0 < nrows; r0 += RK) {
+        const bool more = r0 + RK < nrows;
+        if (more) load_stage(r0 + RK);
+        if (tid < ldG) {
+#pragma unroll
+            for (int rr = 0; rr < RK; ++rr) bsum += sm[rr * ld + ldA + tid];
+        }
+#pragma unroll 2
+        for (int kk = 0; kk < RK; kk += 2) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const int tt = t * WG_WAVES + wave;
+                if (TT % WG_WAVES == 0 || tt < TT) {
+                    const int tk = tt / TN, tn = tt % TN;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sm[(kk + kh) * ld + tk * 32 + li], sm[(kk + kh) * ld + ldA + tn * 32 + li], acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+        if (more) { store_stage(); __syncthreads(); }
+    }
+    float* out = w.partial + (int64_t)chunk * (ldA + 1) * ldG;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tt = t * WG_WAVES + wave;
+        if (TT % WG_WAVES == 0 || tt < TT) {
+            const int tk = tt / TN, tn = tt % TN;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * ldG + tn * 32 + li] = acc[t][e];
+        }
+    }
+    if (tid < ldG) out[(int64_t)ldA * ldG + tid] = bsum;
+}
+
+template <int TK, int TN>
+static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
+    constexpr int ld = (TK + TN) * 32;
+    constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
+    hipLaunchKernelGGL((k_wgrad_fast<TK, TN>), dim3(w.n_chunks), dim3(WG_THREADS), RK * ld * sizeof(float), s, w);
+    return GM_OK;
 }
 
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
@@ -377,6 +476,23 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.A = a.A; w.lda = a.lda; w.K = a.K; w.a_row = a.a_row; w.G = a.G; w.ldg = a.ldg; w.N = a.N; w.Gb = a.Gb; w.ldgb = a.ldgb;
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
     w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
+    const bool fast_ok = (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
+                         (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
+    bool launched = false;
+    if (fast_ok) {
+#define GM_WG_CASE(TK_, TN_) if (!launched && w.TK == TK_ && w.TN == TN_) { launch_wgrad_fast<TK_, TN_>(w, s); launched = true; }
+        GM_WG_CASE(8, 8) GM_WG_CASE(4, 8) GM_WG_CASE(8, 4) GM_WG_CASE(4, 4) GM_WG_CASE(2, 4) GM_WG_CASE(4, 2) GM_WG_CASE(2, 2)
+        GM_WG_CASE(1, 2) GM_WG_CASE(2, 1) GM_WG_CASE(1, 4) GM_WG_CASE(1, 8) GM_WG_CASE(1, 1)
+#undef GM_WG_CASE
+    }
+    if (launched) {
+        GM_HIP(hipGetLastError());
+        const int tot = (a.K + 1) * a.N;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3(std::min(64, (tot + 255) / 256), a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+                           a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     const int ld = (w.TK + w.TN) * 32;
     w.RK = 32;
     while (w.RK > 2 && w.RK * ld > WG_PF * WG_THREADS * 4) w.RK >>= 1;
