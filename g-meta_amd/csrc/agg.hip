@@ -16,6 +16,7 @@ struct AggK {
     const float* s_in; const float* s_out; const float* mask_h; const float* bias; int64_t bias_stride;
     const int32_t* set_row_off; int n_sets; int relu; float* out; int64_t rows; int width; int nblocks;
     const int32_t* heavy; int n_heavy, heavy_deg;
+    int win;                   // rows per wave window (64 for big batches; smaller when the batch would underfill the chip)
 };
 
 template <int VEC> struct VecT;
@@ -85,12 +86,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
     }
 }
 
-// One workgroup per heavy row (in-degree > gm_heavy_deg(): hub nodes inside their own neighbourhood, up to ~1000 edges).
-// The 256/LPR lane groups take interleaved LPR-edge chunks (coalesced index loads, 8 row loads in flight each), the
+// One 1024-thread workgroup per heavy row (in-degree > gm_heavy_deg(): hub nodes inside their own neighbourhood, up to
+// ~1000 edges): enough loads in flight on one CU (16 groups x 8 x 1 KiB) to stream the row instead of crawling through it.
+// The 1024/LPR lane groups take interleaved LPR-edge chunks (coalesced index loads, 8 row loads in flight each), the
 // partial rows are summed through LDS in a fixed order (deterministic), then the usual epilogue.
+#define AGG_HEAVY_BLOCK 1024
 template <int LPR, int NCH>
-__device__ __forceinline__ void agg_heavy_row(const AggK& a, int row) {
-    constexpr int NG = AGG_BLOCK / LPR;
+__global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
+    constexpr int NG = AGG_HEAVY_BLOCK / LPR;
+    const int row = a.heavy[blockIdx.x];
     __shared__ __attribute__((aligned(16))) float part[NG * LPR * 4 * NCH];
     const int tid = threadIdx.x, gi = tid / LPR, l = tid % LPR, lane = tid & 63;
     const int gbase = (lane / LPR) * LPR;                 // first lane of this group inside its wave
@@ -160,24 +164,23 @@ template <int LPR, int NCH>
 __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     constexpr int G = GM_WAVE / LPR;           // rows processed side by side
     constexpr int UNR = 4;
-    if ((int)blockIdx.x < a.n_heavy) { agg_heavy_row<LPR, NCH>(a, a.heavy[blockIdx.x]); return; }
-    const int nb = a.nblocks, b = blockIdx.x - a.n_heavy;
+    const int nb = a.nblocks, b = blockIdx.x;
     const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
     const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPR, l = lane % LPR;
-    const int64_t R0 = ((int64_t)lb * (AGG_BLOCK / GM_WAVE) + wave) * GM_WAVE;
+    const int64_t R0 = ((int64_t)lb * (AGG_BLOCK / GM_WAVE) + wave) * a.win;
     if (R0 >= a.rows) return;
     // ---- per-lane row descriptor (coalesced)
     const int64_t myrow = R0 + lane;
     int p0 = 0, dg = 0, u0 = 0, u1 = 0; float w0 = 0.f, w1 = 0.f, so = 1.f;
-    if (myrow < a.rows) {
+    if (lane < a.win && myrow < a.rows) {
         p0 = a.indptr[myrow]; dg = a.indptr[myrow + 1] - p0;
         if (a.s_out) so = a.s_out[myrow];
         if (dg >= 1) { u0 = a.indices[p0]; w0 = a.s_in ? a.s_in[u0] : 1.f; if (a.x_row) u0 = a.x_row[u0]; }
         if (dg >= 2) { u1 = a.indices[p0 + 1]; w1 = a.s_in ? a.s_in[u1] : 1.f; if (a.x_row) u1 = a.x_row[u1]; }
     }
-    const int nwin = (int)min((int64_t)GM_WAVE, a.rows - R0);
+    const int nwin = (int)min((int64_t)a.win, a.rows - R0);
     const float* xl = a.x + l * 4;
     for (int t0 = 0; t0 < nwin; t0 += G * UNR) {
         float4 acc[UNR][NCH];
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
             const int rr = t0 + k * G + g;                      // row of this lane group inside the window
             const int src = rr < GM_WAVE ? rr : 0;
             rdg[k] = rr < nwin ? __shfl(dg, src, 64) : -1;
-            if (a.n_heavy && rdg[k] > a.heavy_deg) rdg[k] = -1;            // written by its own workgroup (agg_heavy_row)
+            if (a.n_heavy && rdg[k] > a.heavy_deg) rdg[k] = -1;            // written by its own workgroup (k_agg_heavy)
             rp0[k] = __shfl(p0, src, 64); rso[k] = __shfl(so, src, 64);
             const int a0 = __shfl(u0, src, 64), a1 = __shfl(u1, src, 64);
             const float f0 = __shfl(w0, src, 64), f1 = __shfl(w1, src, 64);
@@ -258,9 +261,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
 template <int LPR, int NCH>
 static void launch_win(const AggK& a0, hipStream_t s) {
     AggK a = a0;
-    constexpr int RPB = GM_WAVE * (AGG_BLOCK / GM_WAVE);
+    // window = 64 rows per wave when that still gives >= ~8 waves per CU; otherwise shrink it so that small batches
+    // (the support sets, or a 4-task shard) are spread over the whole chip instead of being walked serially
+    a.win = 64;
+    while (a.win > 8 && a.rows / a.win < 2048) a.win >>= 1;
+    const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
     a.nblocks = (int)((a.rows + RPB - 1) / RPB);
-    hipLaunchKernelGGL((k_agg_win<LPR, NCH>), dim3(a.nblocks + a.n_heavy), dim3(AGG_BLOCK), 0, s, a);
+    if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_agg_win<LPR, NCH>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
 template <int VEC, int LPR>
@@ -280,7 +288,7 @@ static int agg_variant() {
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
-           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg};
+           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg, 64};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);

@@ -217,9 +217,14 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         else if (a.transB) hipLaunchKernelGGL((k_gemm_nn<WC_, false, true>), grid, blk, 0, s, g);                              \
         else hipLaunchKernelGGL((k_gemm_nn<WC_, false, false>), grid, blk, 0, s, g);                                           \
     } while (0)
-    if (a.N > 128) { g.n_col_tiles = (a.N + 255) / 256; GM_LAUNCH_GEMM(4, 512); }
-    else if (a.N > 64) { g.n_col_tiles = 1; GM_LAUNCH_GEMM(2, 256); }
-    else { g.n_col_tiles = 1; GM_LAUNCH_GEMM(1, 128); }
+    // column-tile width: the widest (A read once) unless that leaves CUs idle -- small batches are latency-bound, so
+    // trade A re-reads (L2 hits, same XCD) for parallelism
+    int bn = a.N > 128 ? 256 : a.N > 64 ? 128 : 64;
+    while (bn > 64 && (int64_t)a.n_tiles * ((a.N + bn - 1) / bn) < 512) bn >>= 1;
+    g.n_col_tiles = (a.N + bn - 1) / bn;
+    if (bn == 256) GM_LAUNCH_GEMM(4, 512);
+    else if (bn == 128) GM_LAUNCH_GEMM(2, 256);
+    else GM_LAUNCH_GEMM(1, 128);
 #undef GM_LAUNCH_GEMM
     GM_HIP(hipGetLastError());
     return GM_OK;
@@ -365,7 +370,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
 // Specialised weight-gradient kernel: K = 32*TK, N = 32*TN known at compile time (the hidden sizes 64/128/256 of
 // the reference's configs), vectorised operands, no row indirection.  All per-thread staging coordinates are
 // stage-invariant, nothing spills, and the only waits on the prefetch loads sit after the MFMA loop.
-template <int TK, int TN>
+template <int TK, int TN, int ZS>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     constexpr int ldA = TK * 32, ldG = TN * 32, ld = ldA + ldG, ld4 = ld / 4;
     constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
@@ -373,6 +378,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     constexpr int TT = TK * TN, TPW = (TT + WG_WAVES - 1) / WG_WAVES;
     static_assert(PF <= 2 && TPW <= 4, "tile grid too large for the fast weight-gradient kernel");
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    // gridDim.y = ZS splits this chunk's output tiles over ZS workgroups (each does 1/ZS of the MFMAs): used when a
+    // batch has too few row chunks to fill the chip
+    const int zs = ZS > 1 ? (int)blockIdx.y : 0;
     const int chunk = blockIdx.x;
     const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     for (int r0 = 0; r0 < nrows; r0 += RK) {
         const bool more = r0 + RK < nrows;
         if (more) load_stage(r0 + RK);
-        if (tid < ldG) {
+        if (zs == 0 && tid < ldG) {
 #pragma unroll
             for (int rr = 0; rr < RK; ++rr) bsum += sm[rr * ld + ldA + tid];
         }
@@ -426,7 +434,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 const int tt = t * WG_WAVES + wave;
-                if (TT % WG_WAVES == 0 || tt < TT) {
+                if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs)) {
                     const int tk = tt / TN, tn = tt % TN;
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sm[(kk + kh) * ld + tk * 32 + li], sm[(kk + kh) * ld + ldA + tn * 32 + li], acc[t], 0, 0, 0);
                 }
@@ -439,20 +447,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         const int tt = t * WG_WAVES + wave;
-        if (TT % WG_WAVES == 0 || tt < TT) {
+        if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs)) {
             const int tk = tt / TN, tn = tt % TN;
 #pragma unroll
             for (int e = 0; e < 16; ++e) out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * ldG + tn * 32 + li] = acc[t][e];
         }
     }
-    if (tid < ldG) out[(int64_t)ldA * ldG + tid] = bsum;
+    if (zs == 0 && tid < ldG) out[(int64_t)ldA * ldG + tid] = bsum;
 }
 
 template <int TK, int TN>
 static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     constexpr int ld = (TK + TN) * 32;
     constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
-    hipLaunchKernelGGL((k_wgrad_fast<TK, TN>), dim3(w.n_chunks), dim3(WG_THREADS), RK * ld * sizeof(float), s, w);
+    constexpr int TPW = (TK * TN + WG_WAVES - 1) / WG_WAVES;
+    int zs = 1;
+    while (zs < TPW && w.n_chunks * zs < 256) zs <<= 1;       // TPW is 1, 2 or 4
+    const size_t lds = RK * ld * sizeof(float);
+    if (zs == 4 && TPW >= 4) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>), dim3(w.n_chunks, 4), dim3(WG_THREADS), lds, s, w);
+    else if (zs >= 2 && TPW >= 2) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>), dim3(w.n_chunks, 2), dim3(WG_THREADS), lds, s, w);
+    else hipLaunchKernelGGL((k_wgrad_fast<TK, TN, 1>), dim3(w.n_chunks, 1), dim3(WG_THREADS), lds, s, w);
     return GM_OK;
 }
 
@@ -463,8 +477,15 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
     const int c0 = set_chunk_off[set], c1 = set_chunk_off[set + 1];
     const int tot = KN + N;
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < tot; j += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int c = c0; c < c1; ++c) s += partial[(int64_t)c * tot + j];
+        // 8 independent loads in flight; the summation order is fixed (deterministic), just not sequential
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s8[u] += partial[(int64_t)(c + u) * tot + j];
+        }
+        for (int u = 0; c < c1; ++c, ++u) s8[u] += partial[(int64_t)c * tot + j];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         if (j < KN) dW[(int64_t)set * dw_stride + j] = s;
         else if (db) db[(int64_t)set * db_stride + (j - KN)] = s;
     }
@@ -488,7 +509,7 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     if (launched) {
         GM_HIP(hipGetLastError());
         const int tot = (a.K + 1) * a.N;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3(std::min(64, (tot + 255) / 256), a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
                            a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride);
         GM_HIP(hipGetLastError());
         return GM_OK;
@@ -506,7 +527,7 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_chunks, zgroups), dim3(WG_THREADS), lds, s, w);
     GM_HIP(hipGetLastError());
     const int tot = (a.K + 1) * a.N;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(std::min(64, (tot + 255) / 256), a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
                        a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride);
     GM_HIP(hipGetLastError());
     return GM_OK;

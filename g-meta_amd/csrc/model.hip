@@ -198,15 +198,16 @@ __global__ void k_colsum_reduce(const float* partial, int64_t pstride, int64_t p
     }
 }
 
-// out = [ sum_t (gq+gp) | sum_t lq[t,:] | sum_t aq[t,:] | aq[t,:] ... ]
+// out = [ sum_t (gq+gp) | sum_t lq[t,:] | sum_t aq[t,:] | T | aq[t,:] ... ]
 __global__ void k_finalize(const float* gq, const float* gp, int64_t stride, int64_t P, int T, const float* lq, const float* aq, int K1, float* out) {
-    const int64_t tot = P + 2 * K1 + (int64_t)T * K1;
+    const int64_t tot = P + 2 * K1 + 1 + (int64_t)T * K1;
     for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
         if (id < P) { if (gq) for (int t = 0; t < T; ++t) s += gq[t * stride + id] + gp[t * stride + id]; }
         else if (id < P + K1) { for (int t = 0; t < T; ++t) s += lq[t * K1 + (id - P)]; }
         else if (id < P + 2 * K1) { for (int t = 0; t < T; ++t) s += aq[t * K1 + (id - P - K1)]; }
-        else s = aq[id - P - 2 * K1];
+        else if (id == P + 2 * K1) s = (float)T;
+        else s = aq[id - P - 2 * K1 - 1];
         out[id] = s;
     }
 }
@@ -453,10 +454,21 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
 }
 
 // ================================================================================ the fused meta-step
+struct MetaStreams {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;
+    int ensure(int n) {
+        if (!side) GM_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        while ((int)ev.size() < n) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev.push_back(e); }
+        return GM_OK;
+    }
+};
+static MetaStreams& meta_streams() { static thread_local MetaStreams m; return m; }
 struct MetaPlan {
     gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
     GcnCtx S, Q;
-    float *fwA, *fwB, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq;
+    float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq;
+    int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
     int32_t *rows_s, *rows_q;
     int Ct, ns, nq;
 };
@@ -468,10 +480,11 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     p.S = GcnCtx{}; p.Q = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.S.L = p.L; p.Q.L = p.L;
     Carver cv(ws, ws_bytes);
     const int64_t TP = (int64_t)p.T * p.Pp; const int C = p.L.n_out; const int K1 = p.K + 1;
-    p.fwA = cv.take<float>(TP); p.fwB = cv.take<float>(TP); p.g = cv.take<float>(TP); p.gq = cv.take<float>(TP); p.gp = cv.take<float>(TP);
+    p.TP = TP; p.proto_sz = (int64_t)p.T * 256 * C;
+    p.fw = cv.take<float>(TP * p.K); p.g = cv.take<float>(TP); p.gq = cv.take<float>(TP); p.gp = cv.take<float>(TP);
     p.logit_s = cv.take<float>((int64_t)spt->subs * C); p.logit_q = cv.take<float>((int64_t)qry->subs * C);
     p.dlog_s = cv.take<float>((int64_t)spt->subs * C); p.dlog_q = cv.take<float>((int64_t)qry->subs * C);
-    p.protos = cv.take<float>((int64_t)p.T * 256 * C); p.dprotos = cv.take<float>((int64_t)p.T * 256 * C);
+    p.protos = cv.take<float>(p.proto_sz * p.K); p.dprotos = cv.take<float>(p.proto_sz);
     p.ls = cv.take<float>((int64_t)p.T * K1); p.as_ = cv.take<float>((int64_t)p.T * K1);
     p.lq = cv.take<float>((int64_t)p.T * K1); p.aq = cv.take<float>((int64_t)p.T * K1);
     p.rows_s = cv.take<int32_t>(spt->subs); p.rows_q = cv.take<int32_t>(qry->subs);
@@ -492,7 +505,7 @@ extern "C" int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry
 extern "C" int64_t gm_meta_out_floats(const gm_batch_t* spt, const gm_model_t* m, const gm_hparams_t* hp) {
     gm_layout L;
     if (!spt || !hp || gm_make_layout(m, &L) != GM_OK) return -1;
-    return L.P + 2 * (int64_t)(hp->update_step + 1) + (int64_t)spt->sets * (hp->update_step + 1);
+    return L.P + 2 * (int64_t)(hp->update_step + 1) + 1 + (int64_t)spt->sets * (hp->update_step + 1);
 }
 
 extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_spt, const int32_t* y_qry, const gm_model_t* m,
@@ -518,49 +531,68 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_HIP(hipStreamSynchronize(st));       // pageable host vectors: make the copies complete before they go out of scope
     gm_prof_reset();
     const int sgd_blocks = (int)std::min<int64_t>(2048, ((int64_t)T * L.P + 255) / 256);
+    // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
+    // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the
+    // prototypes of step k-1.  The small latency-bound support kernels thus overlap the throughput-bound query work.
+    MetaStreams& ms = meta_streams();
+    GM_TRY(ms.ensure(2 * K + 8));
+    hipStream_t sq = hp->serialize ? st : ms.side;
+    int ev = 0;
+    auto signal = [&](hipStream_t from) -> hipEvent_t { hipEvent_t e = ms.ev[ev++]; (void)hipEventRecord(e, from); return e; };
+    auto wait = [&](hipStream_t who, hipEvent_t e) { (void)hipStreamWaitEvent(who, e, 0); };
+    wait(sq, signal(st));                                  // inputs (theta, class tables, batches) are ready
 
-    auto spt_loss = [&](int col) -> int {      // proto_loss_spt (meta.py:123,146): loss, prototypes, dlogits
+    auto fw = [&](int k) -> float* { return p.fw + (int64_t)(k - 1) * p.TP; };       // fw_k, k = 1..K
+    auto protos = [&](int k) -> float* { return p.protos + (int64_t)k * p.proto_sz; };   // prototypes of support step k
+    auto spt_loss = [&](int k) -> int {        // proto_loss_spt (meta.py:123,146): loss, prototypes, dlogits
         GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
-        ProtoK k{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, p.protos, p.ls, p.as_, K1, col, p.dlog_s, nullptr};
-        return launch_proto(spt, k, st);
+        ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr};
+        return launch_proto(spt, pk, st);
     };
-    auto qry_loss = [&](int col, bool grad) -> int {   // proto_loss_qry (meta.py:132,139,154)
-        if (grad) GM_HIP(hipMemsetAsync(p.dlog_q, 0, sizeof(float) * qry->subs * C, st));
-        ProtoK k{p.logit_q, C, p.rows_q, Ct, nq, 1, p.protos, nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr};
-        return launch_proto(qry, k, st);
+    auto qry_loss = [&](int col, int kproto, bool grad) -> int {   // proto_loss_qry (meta.py:132,139,154)
+        if (grad) GM_HIP(hipMemsetAsync(p.dlog_q, 0, sizeof(float) * qry->subs * C, sq));
+        ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr};
+        return launch_proto(qry, pk, sq);
     };
     const int hoist = hp->hoist_z1;
-    // ---- step 0 (meta.py:122-141)
+    // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq
     GM_TRY(gcn_forward(p.S, theta, 0, p.logit_s, st, hoist));
     GM_TRY(spt_loss(0));
+    hipEvent_t e_proto0 = signal(st);
     GM_TRY(gcn_backward(p.S, theta, 0, p.dlog_s, p.g, Pp, st));
-    hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, p.fwA, theta, (int64_t)0, p.g, hp->update_lr, L.P, Pp, T);
-    GM_TRY(gcn_forward(p.Q, theta, 0, p.logit_q, st, hoist));
-    GM_TRY(qry_loss(0, false));
-    GM_TRY(gcn_forward(p.Q, p.fwA, Pp, p.logit_q, st, hoist));
-    GM_TRY(qry_loss(1, false));
-    float* cur = p.fwA; float* nxt = p.fwB;
+    hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(1), theta, (int64_t)0, p.g, hp->update_lr, L.P, Pp, T);
+    hipEvent_t e_fw = signal(st);                          // fw_1 ready
+    GM_TRY(gcn_forward(p.Q, theta, 0, p.logit_q, sq, hoist));
+    wait(sq, e_proto0);
+    GM_TRY(qry_loss(0, 0, false));
+    wait(sq, e_fw);
+    GM_TRY(gcn_forward(p.Q, fw(1), Pp, p.logit_q, sq, hoist));
+    GM_TRY(qry_loss(1, 0, false));
     bool have_grad = false;
     for (int k = 1; k < K; ++k) {            // meta.py:143-157
-        GM_TRY(gcn_forward(p.S, cur, Pp, p.logit_s, st, hoist));
+        GM_TRY(gcn_forward(p.S, fw(k), Pp, p.logit_s, st, hoist));
         GM_TRY(spt_loss(k));
-        GM_TRY(gcn_backward(p.S, cur, Pp, p.dlog_s, p.g, Pp, st));
-        hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, nxt, cur, Pp, p.g, hp->update_lr, L.P, Pp, T);
-        GM_TRY(gcn_forward(p.Q, nxt, Pp, p.logit_q, st, hoist));
+        GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.g, Pp, st));
+        hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(k + 1), fw(k), Pp, p.g, hp->update_lr, L.P, Pp, T);
+        e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
+        wait(sq, e_fw);
+        GM_TRY(gcn_forward(p.Q, fw(k + 1), Pp, p.logit_q, sq, hoist));
         const bool last = hp->need_meta_grad && k == K - 1;
-        GM_TRY(qry_loss(k + 1, last));
+        GM_TRY(qry_loss(k + 1, k, last));
         if (last) {
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
-            // query forward plus d L_q / d fw_{K-1} through the prototypes of the last support forward.
-            GM_TRY(gcn_backward(p.Q, nxt, Pp, p.dlog_q, p.gq, Pp, st));
+            // query forward (on sq) plus d L_q / d fw_{K-1} through the prototypes of the last support forward (on st).
+            hipEvent_t e_dp = signal(sq);                  // dprotos ready
+            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq));
+            wait(st, e_dp);
             GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
             hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, Ct, ns, C, p.dlog_s);
-            GM_TRY(gcn_backward(p.S, cur, Pp, p.dlog_s, p.gp, Pp, st));
+            GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st));
             have_grad = true;
         }
-        std::swap(cur, nxt);
     }
-    const int64_t tot = L.P + 2 * K1 + (int64_t)T * K1;
+    wait(st, signal(sq));                                  // join
+    const int64_t tot = L.P + 2 * K1 + 1 + (int64_t)T * K1;
     hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
                        have_grad ? p.gq : nullptr, p.gp, Pp, L.P, T, p.lq, p.aq, K1, out);
     GM_HIP(hipGetLastError());

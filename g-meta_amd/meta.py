@@ -29,13 +29,51 @@ class Meta(nn.Module):
         self.net = Classifier(config)
         if torch.cuda.is_available():
             self.net = self.net.to('cuda')
-        self.meta_optim = optim.Adam(self.net.parameters(), lr=self.meta_lr)
+        self.meta_optim = self._make_adam()
         self.method = args.method
         self.hoist_z1 = int(getattr(args, 'hoist_z1', 0))
+        self.serialize = int(getattr(args, 'serialize', 0))     # 1: one stream (per-kernel timing)
         self.last_stats = {}
         self._ws = None
 
     # ---- helpers
+    def _make_adam(self):
+        params = self.net.parameters()
+        if all(p.is_cuda for p in params):
+            try:                                   # one fused kernel instead of ~7 foreach launches (same update rule)
+                return optim.Adam(params, lr=self.meta_lr, fused=True)
+            except (TypeError, RuntimeError):
+                pass
+        return optim.Adam(params, lr=self.meta_lr)
+
+    def _apply(self, fn, *a, **k):                 # .to(device) moves parameters: rebuild the optimiser on the new tensors
+        r = super(Meta, self)._apply(fn, *a, **k)
+        if getattr(self, 'meta_optim', None) is not None and not self.meta_optim.state:
+            self.meta_optim = self._make_adam()
+        return r
+
+    def _bind_grads(self, dev):
+        """p.grad of every parameter is a view into one flat buffer, so the reduced meta-gradient is installed by a
+        single kernel.  (Re-bound if a deepcopy or an external zero_grad(set_to_none) broke the aliasing.)"""
+        params = list(self.net.parameters())
+        P = sum(p.numel() for p in params)
+        fg = getattr(self, '_flat_grad', None)
+        ok = fg is not None and fg.numel() == P and fg.device == dev
+        if ok:
+            off = 0
+            for p in params:
+                if p.grad is None or p.grad.data_ptr() != fg.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            self._flat_grad = fg = torch.zeros(P, dtype=torch.float32, device=dev)
+            off = 0
+            for p in params:
+                p.grad = fg[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        return fg
+
     def _flat_theta(self):
         return torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).contiguous()
 
@@ -46,7 +84,7 @@ class Meta(nn.Module):
         return self._ws
 
     def _run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
-        """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + T(K+1) + 1], P, T)."""
+        """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + 1 + T(K+1)], P, T)."""
         _lib.require_gpu()
         lib = _lib.lib()
         theta = self._flat_theta()
@@ -62,17 +100,16 @@ class Meta(nn.Module):
         if len(ys) != S.subs or len(yq) != Q.subs:
             raise ValueError('label count does not match the number of subgraphs')
         model = self.net.model
-        hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1))
+        hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1), int(self.serialize))
         P = int(lib.gm_model_param_count(C.byref(model)))
         n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
         ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
         if ws_bytes < 0 or n_out < 0:
             _lib.check(-1, 'gm_meta_ws_bytes')
         ws = self._workspace(ws_bytes, dev)
-        out = torch.empty(n_out + 1, dtype=torch.float32, device=dev)
+        out = torch.empty(n_out, dtype=torch.float32, device=dev)
         _lib.check(lib.gm_meta_step(S.handle, Q.handle, _lib.ptr(ys), _lib.ptr(yq), C.byref(model), C.byref(hp), _lib.ptr(theta),
                                     _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'gm_meta_step')
-        out[n_out] = float(T)           # local task count rides along with the all-reduce
         self._keep = (S, Q)             # keep concatenated batches alive until the stream has consumed them
         return out, P, T
 
@@ -84,7 +121,7 @@ class Meta(nn.Module):
                              'so the reference cannot back-propagate with fewer steps')
         out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, True)
         K1 = K + 1
-        head = torch.cat([out[:P + 2 * K1], out[-1:]])       # [grad | losses_q | corrects | task count]
+        head = out[:P + 2 * K1 + 1]                           # [grad | losses_q | corrects | task count], contiguous view
         if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
         tail = head[P:].cpu().numpy().astype(np.float64)     # the only device->host sync of the meta-step
@@ -92,13 +129,8 @@ class Meta(nn.Module):
         loss_q = tail[K1 - 1] / task_num                      # losses_q[-1] / task_num (meta.py:161)
         self.last_stats = {'loss_q': loss_q, 'losses_q': tail[:K1] / task_num, 'task_num': task_num}
         if not np.isnan(loss_q):                              # meta.py:163-169
-            grad = head[:P] / task_num
-            self.meta_optim.zero_grad()
-            off = 0
-            for p in self.net.parameters():
-                n = p.numel()
-                p.grad = grad[off:off + n].view_as(p).clone()
-                off += n
+            fg = self._bind_grads(head.device)               # (stands for meta_optim.zero_grad(); loss_q.backward())
+            torch.div(head[:P], task_num, out=fg)
             self.meta_optim.step()
         return tail[K1:2 * K1] / task_num                     # np.array(corrects) / task_num (meta.py:171)
 
@@ -107,7 +139,7 @@ class Meta(nn.Module):
         K = self.update_step_test
         out, P, T = self._run(x_spt[:1], y_spt[:1], x_qry[:1], y_qry[:1], K, False)      # `[0]` of every argument (meta.py:182-191)
         K1 = K + 1
-        return out[P + 2 * K1:P + 3 * K1].cpu().numpy().astype(np.float64)
+        return out[P + 2 * K1 + 1:P + 3 * K1 + 1].cpu().numpy().astype(np.float64)
 
     def finetunning_batch(self, x_spt, y_spt, x_qry, y_qry):
         """All given evaluation tasks in ONE call (the reference loops 100 val/test tasks one at a time,
@@ -115,7 +147,7 @@ class Meta(nn.Module):
         K = self.update_step_test
         out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
         K1 = K + 1
-        return out[P + 2 * K1:P + 2 * K1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
+        return out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
 
     def forward(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
         if self.method == 'G-Meta':

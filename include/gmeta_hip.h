@@ -53,6 +53,8 @@ typedef struct gm_hparams {
     int32_t need_meta_grad;/* 1 = Meta.forward (meta.py:101-173), 0 = finetunning (175-234) */
     int32_t hoist_z1;      /* 0 = reference-equivalent schedule (every forward re-aggregates layer 1);
                               1 = aggregate layer-1 input once per call (loop-invariant)   */
+    int32_t serialize;     /* 0 = support chain and query evaluations on two HIP streams (default);
+                              1 = everything on `stream` (for per-kernel timing / profiling)  */
 } gm_hparams_t;
 
 const char* gm_last_error(void);
@@ -152,12 +154,13 @@ int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32_t n_out, c
  * Meta.finetunning_ProtoMAML (meta.py:175-234) when 0, for ALL sets (tasks) of spt/qry at once.
  * spt and qry must have the same number of sets; set t of each is task t.  y_spt / y_qry: HOST
  * int32 labels per subgraph.  theta: device fp32 [P] (read only).
- * out: device fp32 [P + 2*(K+1) + sets*(K+1)]:
+ * out: device fp32 [P + 2*(K+1) + 1 + sets*(K+1)]:
  *   [0,P)            SUM over tasks of the first-order meta-gradient (query path at fw_K + prototype
  *                    path through the support forward at fw_{K-1}); zeros when need_meta_grad = 0
  *   [P, P+K+1)       SUM over tasks of losses_q[k]   (meta.py:133,140,155)
  *   [P+K+1, P+2K+2)  SUM over tasks of corrects[k]   (meta.py:134,141,157)
- *   [P+2K+2, ...)    per-task query accuracy [sets, K+1]
+ *   [P+2K+2]         the number of tasks (sets) in this call, as a float (rides along with the all-reduce)
+ *   [P+2K+3, ...)    per-task query accuracy [sets, K+1]
  * The caller divides by the (global) task count, applies the NaN guard (meta.py:163) and the
  * optimiser -- after the RCCL all-reduce when tasks are sharded over GPUs. */
 int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry, const gm_model_t* m, const gm_hparams_t* hp);

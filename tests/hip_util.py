@@ -50,7 +50,7 @@ def hip_meta_step(fx, replay=True, hoist=0):
     orig = m.meta_optim.step
 
     def step(*a, **k):
-        grads['g'] = torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy()
+        grads['g'] = torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy().copy()
         return orig(*a, **k)
     m.meta_optim.step = step
     ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]
