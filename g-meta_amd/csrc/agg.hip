@@ -16,6 +16,7 @@ struct AggK {
     const float* s_in; const float* s_out; const float* mask_h; const float* bias; int64_t bias_stride;
     const int32_t* set_row_off; int n_sets; int relu; float* out; int64_t rows; int width; int nblocks;
     const int32_t* heavy; int n_heavy, heavy_deg;
+    int nt;                    // 1: non-temporal output stores (Z is not re-read by this kernel; keep L2 for the X gathers)
     int win;                   // rows per wave window (64 for big batches; smaller when the batch would underfill the chip)
 };
 
@@ -252,7 +253,12 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
                     const float4 m = *reinterpret_cast<const float4*>(a.mask_h + row * a.width + l * 4 + c * LPR * 4);
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                 }
-                *reinterpret_cast<float4*>(a.out + row * a.width + l * 4 + c * LPR * 4) = v;
+                float4* dst = reinterpret_cast<float4*>(a.out + row * a.width + l * 4 + c * LPR * 4);
+                if (a.nt) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));
+                    f4v vv = {v.x, v.y, v.z, v.w};
+                    __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
+                } else *dst = v;
             }
         }
     }
@@ -279,6 +285,11 @@ static void launch_one(const AggK& a0, hipStream_t s) {
     hipLaunchKernelGGL((k_agg<VEC, LPR>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
+static int agg_nt() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_AGG_NT"); v = e ? atoi(e) : 1; }
+    return v;
+}
 static int agg_variant() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("GM_AGG_VARIANT"); v = e ? atoi(e) : 0; }   // 1 = force the generic row-per-group kernel (debug)
@@ -288,7 +299,7 @@ static int agg_variant() {
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
-           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg, 64};
+           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg, agg_nt(), 64};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);

@@ -373,10 +373,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
 template <int TK, int TN, int ZS>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     constexpr int ldA = TK * 32, ldG = TN * 32, ld = ldA + ldG, ld4 = ld / 4;
-    constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
+    // stage = RK rows: its MFMA phase must outlast a loaded HBM round trip (a few microseconds) for the register prefetch
+    // of the next stage to land in time -- 32 rows at ld <= 512 (64 KiB of LDS, one workgroup per CU anyway)
+    constexpr int RK = (16384 / ld) >= 32 ? 32 : (16384 / ld) >= 16 ? 16 : 8;
     constexpr int PER4 = RK * ld4, PF = (PER4 + WG_THREADS - 1) / WG_THREADS;
     constexpr int TT = TK * TN, TPW = (TT + WG_WAVES - 1) / WG_WAVES;
-    static_assert(PF <= 2 && TPW <= 4, "tile grid too large for the fast weight-gradient kernel");
+    static_assert(PF <= 4 && TPW <= 4, "tile grid too large for the fast weight-gradient kernel");
     extern __shared__ __attribute__((aligned(16))) float sm[];
     // gridDim.y = ZS splits this chunk's output tiles over ZS workgroups (each does 1/ZS of the MFMAs): used when a
     // batch has too few row chunks to fill the chip
@@ -459,11 +461,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
 template <int TK, int TN>
 static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     constexpr int ld = (TK + TN) * 32;
-    constexpr int RK = (8192 / ld) >= 32 ? 32 : (8192 / ld) >= 16 ? 16 : 8;
+    constexpr int RK = (16384 / ld) >= 32 ? 32 : (16384 / ld) >= 16 ? 16 : 8;
     constexpr int TPW = (TK * TN + WG_WAVES - 1) / WG_WAVES;
     int zs = 1;
     while (zs < TPW && w.n_chunks * zs < 256) zs <<= 1;       // TPW is 1, 2 or 4
     const size_t lds = RK * ld * sizeof(float);
+    static bool attr_done = false;
+    if (!attr_done) {
+        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
     if (zs == 4 && TPW >= 4) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>), dim3(w.n_chunks, 4), dim3(WG_THREADS), lds, s, w);
     else if (zs >= 2 && TPW >= 2) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>), dim3(w.n_chunks, 2), dim3(WG_THREADS), lds, s, w);
     else hipLaunchKernelGGL((k_wgrad_fast<TK, TN, 1>), dim3(w.n_chunks, 1), dim3(WG_THREADS), lds, s, w);

@@ -1,0 +1,157 @@
+"""GPU (-m gpu): the HIP path at BASELINE.json's full sizes (arxiv shape: 169,343-node graph, F0=128, h=2, hidden 256,
+3-way 3-shot 24-query, sample_nodes=1000), checked through size-independent properties -- the oracle is far too slow
+here (seconds per task), so: extraction invariants + CSR transpose consistency (bit-exact integer work), aggregate
+linearity / degree identity / adjointness <A x, y> = <x, A^T y>, batched == per-task, stream-mode and run-to-run
+determinism, hoisted == full schedule."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+T = 8
+
+
+@pytest.fixture(scope='module')
+def world():
+    import random
+    import gmeta_amd
+    from gmeta_amd import synth
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=T)
+    data = synth.node_dataset(cfg['n'], cfg['m'], cfg['F0'], cfg['classes'])
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=3, k_shot=3, k_query=24, batchsz=T, args=args, adjs=store, h=2,
+                             tables={'train': (data['names'], data['labels'])}, verbose=False)
+    batch = db.get_batch(list(range(T)))
+    return dict(args=args, cfg=cfg, data=data, store=store, db=db, batch=batch)
+
+
+def test_extraction_invariants_full_size(world):
+    """a1/a3 at full size: ascending ids, centre present, size cap, every node within 2 hops (C BFS restatement of
+    sdp.py:300-311), CSR rows/cols inside their subgraph, by-source CSR == exact transpose of the by-destination CSR."""
+    import gmeta_oracle as orc
+    n, src, dst = world['data']['graphs'][0]
+    G = orc.Graph(n, src, dst)
+    lib = orc._load_c()
+    assert lib, 'oracle C kernels not built'
+    seen = np.zeros(n, np.uint8); fa = np.zeros(n, np.int32); fb = np.zeros(n, np.int32)
+    n_sampled = 0
+    for side in (0, 2):
+        B = world['batch'][side][0].view_of
+        par, sub = B.parent(), B.sub_off
+        ip, ix = B.csr(); tp, tx = B.csr(transposed=True)
+        cen = B._read(8, B.subs, np.int32)
+        seeds = np.concatenate([world['db']._seeds(world['db']._task_names(t)[0 if side == 0 else 1]) for t in range(T)])
+        assert ip[0] == 0 and ip[-1] == B.edges and tp[-1] == B.edges and np.all(np.diff(ip) >= 0)
+        rows = np.arange(B.rows)
+        owner = np.searchsorted(sub, rows, side='right') - 1
+        dstrow = np.repeat(rows, np.diff(ip))
+        assert np.array_equal(owner[ix], owner[dstrow])                       # edges never leave their subgraph
+        # transpose consistency: sort (src,dst) pairs both ways
+        a = np.stack([ix, dstrow], 1); b = np.stack([np.repeat(rows, np.diff(tp)), tx], 1)
+        assert np.array_equal(a[np.lexsort((a[:, 1], a[:, 0]))], b)           # by-source lists are (src asc, dst asc)
+        for k in range(0, B.subs, 7):                                         # every 7th subgraph against the BFS restatement
+            nodes = par[sub[k]:sub[k + 1]]
+            i = int(seeds[k, 1])
+            assert np.all(np.diff(nodes) > 0) and nodes[cen[k]] == i
+            cnt = lib.oracle_khop_mark(C.c_int64(n), G.indptr.ctypes.data_as(C.c_void_p), G.indices.ctypes.data_as(C.c_void_p), C.c_int64(i), 2,
+                                       seen.ctypes.data_as(C.c_void_p), fa.ctypes.data_as(C.c_void_p), fb.ctypes.data_as(C.c_void_p))
+            assert seen[nodes].all()
+            if cnt > 1000:
+                n_sampled += 1
+                assert len(nodes) in (1000, 1001)
+                ours = orc.sample_nodes(np.nonzero(seen)[0].astype(np.int32), 1000, 222, 0, i)
+                assert np.array_equal(ours, nodes)                             # the keyed sampler, bit-exact at full size
+            else:
+                assert len(nodes) == cnt and np.array_equal(np.nonzero(seen)[0], nodes)
+            # induced edges of this subgraph == every parent edge with both ends inside
+            lo, hi = sub[k], sub[k + 1]
+            e_hip = ip[hi] - ip[lo]
+            inside = np.zeros(n, bool); inside[nodes] = True
+            e_ref = sum(int(inside[G.preds(v)].sum()) for v in nodes[:: max(1, len(nodes) // 50)])
+            e_hip_s = sum(int(ip[lo + r + 1] - ip[lo + r]) for r in range(0, len(nodes), max(1, len(nodes) // 50)))
+            assert e_ref == e_hip_s and e_hip >= 0
+    assert n_sampled > 0
+
+
+@pytest.mark.parametrize('width', [256, 128])
+def test_aggregate_properties_full_size(world, width):
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    Q = world['batch'][2][0].view_of
+    n = Q.rows
+    g = torch.Generator(device='cuda').manual_seed(width)
+    x = torch.randn(n, width, device='cuda', generator=g); y = torch.randn(n, width, device='cuda', generator=g)
+
+    def agg(v, transposed=0, s_in=None, s_out=None):
+        out = torch.empty_like(v)
+        _lib.check(lib.gm_aggregate(Q.handle, transposed, 0, _lib.ptr(v), width, _lib.ptr(s_in), _lib.ptr(s_out), _lib.ptr(out), _lib.stream_ptr()))
+        return out
+    ax, ay = agg(x), agg(y)
+    # degree identity: A * ones = in-degree (integer-valued sums are exact in fp32 here)
+    deg = torch.from_numpy(np.diff(Q.csr()[0]).astype(np.float32)).cuda()
+    assert torch.equal(agg(torch.ones(n, width, device='cuda'))[:, 0], deg)
+    # linearity
+    lin = agg(2.0 * x - 0.5 * y)
+    assert torch.allclose(lin, 2.0 * ax - 0.5 * ay, atol=2e-4, rtol=1e-5)
+    # adjointness of the two CSR orientations: <A x, y> == <x, A^T y>   (fp64 accumulation of the inner products)
+    lhs = (ax.double() * y.double()).sum().item(); rhs = (x.double() * agg(y, 1).double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(1.0, abs(lhs))
+    # scalings commute with the sum:  s_out * A (s_in * x)
+    si = torch.rand(n, device='cuda', generator=g) + 0.5; so = torch.rand(n, device='cuda', generator=g) + 0.5
+    assert torch.allclose(agg(x, 0, si, so), so[:, None] * agg(si[:, None] * x), atol=2e-4, rtol=1e-5)
+    # run-to-run determinism (bitwise)
+    assert torch.equal(agg(x), ax)
+
+
+def _meta(world, **kw):
+    import argparse
+    import gmeta_amd
+    from gmeta_amd import synth
+    a = argparse.Namespace(**vars(world['args']))
+    for k, v in kw.items():
+        setattr(a, k, v)
+    a.update_step = 3
+    torch.manual_seed(222)
+    cfg = world['cfg']
+    return gmeta_amd.Meta(a, synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])).to('cuda')
+
+
+def _step(m, batch):
+    grads = {}
+    orig = m.meta_optim.step
+    m.meta_optim.step = lambda *a, **k: grads.setdefault('g', torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).clone())
+    accs = m(*batch, None)
+    m.meta_optim.step = orig
+    return accs, grads['g']
+
+
+def test_meta_step_determinism_and_schedule_equivalence(world):
+    b = world['batch']
+    a0, g0 = _step(_meta(world), b)
+    a1, g1 = _step(_meta(world), b)
+    assert np.array_equal(a0, a1) and torch.equal(g0, g1)                      # run-to-run bitwise determinism
+    a2, g2 = _step(_meta(world, serialize=1), b)
+    assert np.array_equal(a0, a2) and torch.equal(g0, g2)                      # two streams == one stream, bitwise
+    a3, g3 = _step(_meta(world, hoist_z1=1), b)
+    assert np.array_equal(a0, a3) and torch.equal(g0, g3)                      # hoisting the layer-1 aggregate changes nothing
+    assert np.isfinite(a0).all() and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
+
+
+def test_batched_tasks_equal_per_task_runs(world):
+    """Tasks are independent inside forward_ProtoMAML (meta.py:118-157): the batched step's meta-gradient is the mean of
+    the single-task steps' and its accs their mean."""
+    b = world['batch']
+    a_all, g_all = _step(_meta(world), b)
+    acc_sum, g_sum = 0, 0
+    db = world['db']
+    for t in range(T):
+        one = db.get_batch([t])
+        # same relabelled targets as in the batched call (labels are re-drawn per get_batch call in Disjoint mode)
+        one = list(one); one[1] = [b[1][t]]; one[3] = [b[3][t]]
+        a, g = _step(_meta(world), tuple(one))
+        acc_sum = acc_sum + a; g_sum = g_sum + g
+    np.testing.assert_allclose(a_all, acc_sum / T, atol=1e-6)
+    assert torch.allclose(g_all, g_sum / T, atol=1e-5, rtol=1e-4)
