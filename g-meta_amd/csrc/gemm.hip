@@ -4,6 +4,7 @@
 // 1e-4 tolerance on logits/meta-grads holds without a reduced-precision path.  MFMA-bound, not HBM-bound
 // (43-64 flop/B at the arxiv config): reported as MFMA utilisation, separately from the aggregate.
 #include <algorithm>
+#include <stdlib.h>
 #include "gm_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -219,7 +220,10 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     } while (0)
     // column-tile width: the widest (A read once) unless that leaves CUs idle -- small batches are latency-bound, so
     // trade A re-reads (L2 hits, same XCD) for parallelism
+    static int bn_cap = -1;
+    if (bn_cap < 0) { const char* e = getenv("GM_GEMM_BN"); bn_cap = e ? atoi(e) : 256; }
     int bn = a.N > 128 ? 256 : a.N > 64 ? 128 : 64;
+    if (bn > bn_cap) bn = bn_cap;
     while (bn > 64 && (int64_t)a.n_tiles * ((a.N + bn - 1) / bn) < 512) bn >>= 1;
     g.n_col_tiles = (a.N + bn - 1) / bn;
     if (bn == 256) GM_LAUNCH_GEMM(4, 512);

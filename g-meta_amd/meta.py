@@ -4,7 +4,7 @@ forward / finetunning, same return values; the whole task loop runs inside one g
 torch.distributed is initialised each rank passes ITS shard of the meta-batch and the first-order
 meta-gradient is summed by one all-reduce (RCCL over xGMI on MI355X) before the NaN guard and Adam."""
 import ctypes as C
-from copy import deepcopy  # noqa: F401  (kept: train.py deep-copies the Meta object)
+import copy
 
 import numpy as np
 import torch
@@ -35,6 +35,19 @@ class Meta(nn.Module):
         self.serialize = int(getattr(args, 'serialize', 0))     # 1: one stream (per-kernel timing)
         self.last_stats = {}
         self._ws = None
+        self._keep = None
+        self._flat_grad = None
+
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad')      # device caches / ctypes handles: never copied
+
+    def __deepcopy__(self, memo):
+        """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
+        state are copied, per-call device caches are not."""
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k in self._TRANSIENT else copy.deepcopy(v, memo)
+        return new
 
     # ---- helpers
     def _make_adam(self):

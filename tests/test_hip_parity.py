@@ -206,6 +206,28 @@ def test_finetunning_matches_reference(case):
     np.testing.assert_allclose(allacc[0], fx.z['ft_accs'], atol=1e-6)
 
 
+def test_deepcopy_snapshot_like_train_py():
+    """train.py:87,125-127 keeps the best model as copy.deepcopy(maml): the copy must be independent and usable."""
+    import copy
+    hu = _imports()
+    fx = Fixture('g2_shared')
+    res = hu.hip_meta_step(fx, replay=True)
+    m = res['meta']
+    snap = copy.deepcopy(m)
+    for a, b in zip(m.net.parameters(), snap.net.parameters()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+    ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]
+    yq = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_qry']]
+    S, Q = res['S'], res['Q']
+    before = [p.detach().clone() for p in snap.net.parameters()]
+    a1 = m(S.views(), ys, Q.views(), yq, None, None, None, None, None, None, fx.feats)         # second step on the original
+    for a, b in zip(before, snap.net.parameters()):
+        assert torch.equal(a, b)                                                                # snapshot untouched
+    f1 = snap.finetunning_batch(S.views(), ys, Q.views(), yq)
+    f2 = copy.deepcopy(snap).finetunning_batch(S.views(), ys, Q.views(), yq)
+    assert np.array_equal(f1, f2) and np.isfinite(a1).all()
+
+
 def gmeta_one(fx, store, tag):
     import gmeta_amd
     return gmeta_amd.SubgraphBatch.from_nodes(store, fx.z[tag + '_seeds'][0], [0, fx.z[tag + '_seeds'].shape[1]], fx.replay_lists(tag, 0), fx.link)

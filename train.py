@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""train.py -- driver with the reference's flags and control flow (G-Meta/train.py:31-179) on the MI355X hot path.
+
+    python train.py --data_dir DIR/ --task_setup Disjoint [--epoch 10 --task_num 32 --update_step 10 ...]
+
+Differences from the reference driver, all at its edges: the graphs come from `graph_csr.npz` (see
+g-meta_amd/datadir.py; DGL pickles cannot be read without DGL) and live in HBM as a GraphStore; a meta-batch is
+extracted by two kernel launches (`Subgraphs.get_batch`) instead of a DataLoader over Python loops; validation/test
+tasks are fine-tuned in ONE batched call.  With torch.distributed.run each rank takes a contiguous shard of every
+meta-batch and the meta-gradient is all-reduced inside Meta.forward."""
+import argparse
+import copy
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import gmeta_amd                                   # noqa: E402
+from gmeta_amd import datadir                      # noqa: E402
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--epoch', type=int, default=10)
+    ap.add_argument('--n_way', type=int, default=3)
+    ap.add_argument('--k_spt', type=int, default=3)
+    ap.add_argument('--k_qry', type=int, default=24)
+    ap.add_argument('--task_num', type=int, default=8)
+    ap.add_argument('--meta_lr', type=float, default=1e-3)
+    ap.add_argument('--update_lr', type=float, default=1e-3)
+    ap.add_argument('--update_step', type=int, default=5)
+    ap.add_argument('--update_step_test', type=int, default=10)
+    ap.add_argument('--input_dim', type=int, default=1)
+    ap.add_argument('--hidden_dim', type=int, default=64)
+    ap.add_argument('--attention_size', type=int, default=32)
+    ap.add_argument('--data_dir', default=None, type=str, required=True)
+    ap.add_argument('--no_finetune', default=True, type=str)
+    ap.add_argument('--task_setup', default='Disjoint', type=str, required=True)
+    ap.add_argument('--method', default='G-Meta', type=str)
+    ap.add_argument('--task_n', type=int, default=1)
+    ap.add_argument('--task_mode', default='False', type=str)
+    ap.add_argument('--val_result_report_steps', default=100, type=int)
+    ap.add_argument('--train_result_report_steps', default=30, type=int)
+    ap.add_argument('--num_workers', default=0, type=int)
+    ap.add_argument('--batchsz', default=1000, type=int)
+    ap.add_argument('--link_pred_mode', default='False', type=str)
+    ap.add_argument('--h', default=2, type=int)
+    ap.add_argument('--sample_nodes', type=int, default=1000)
+    ap.add_argument('--eval_tasks', type=int, default=100, help='validation / test tasks (the reference hard-codes 100, train.py:90-91)')
+    return ap.parse_args(argv)
+
+
+def main(args):
+    torch.manual_seed(222); np.random.seed(222); random.seed(222)          # train.py:33-35 (+ python RNG)
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    if world > 1:
+        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
+        torch.distributed.init_process_group('nccl')
+    root = args.data_dir
+    feat = datadir.load_features(root)
+    graphs = datadir.load_graphs(root)
+    if args.task_setup == 'Shared' and args.task_mode == 'True':            # train.py:49-51
+        root = os.path.join(root, 'task' + str(args.task_n)) + '/'
+    info = datadir.load_labels(root)
+    total_class = len(np.unique(np.array(list(info.values()))))
+    labels_num = args.n_way if args.task_setup == 'Disjoint' else total_class   # train.py:58-61
+    config = [('GraphConv', [feat[0].shape[1], args.hidden_dim])]
+    if args.h > 1:
+        config = config + [('GraphConv', [args.hidden_dim, args.hidden_dim])] * (args.h - 1)
+    config = config + [('Linear', [args.hidden_dim, labels_num])]
+    if args.link_pred_mode == 'True':
+        config.append(('LinkPred', [True]))
+    store = gmeta_amd.GraphStore(graphs, feat)
+    maml = gmeta_amd.Meta(args, config).to('cuda')
+    if rank == 0:
+        print('There are {} classes '.format(total_class))
+        print('Total trainable tensors:', sum(int(np.prod(p.shape)) for p in maml.parameters() if p.requires_grad))
+    mk = lambda mode, b: gmeta_amd.Subgraphs(root, mode, info, n_way=args.n_way, k_shot=args.k_spt, k_query=args.k_qry, batchsz=b,  # noqa: E731
+                                             args=args, adjs=store, h=args.h, verbose=rank == 0)
+    db_train, db_val, db_test = mk('train', args.batchsz), mk('val', args.eval_tasks), mk('test', args.eval_tasks)
+    per = max(1, args.task_num // world)
+    max_acc, model_max = 0, copy.deepcopy(maml)
+    s_start = time.time()
+
+    def evaluate(model, db):
+        x = db.get_batch(list(range(len(db))))
+        return model.finetunning_batch(x[0], x[1], x[2], x[3]).mean(axis=0)        # mean over tasks (train.py:123,136)
+
+    for epoch in range(args.epoch):
+        order = np.random.permutation(len(db_train))                                # DataLoader(shuffle=True), train.py:96
+        for step in range(len(order) // args.task_num):
+            idx = order[step * args.task_num:(step + 1) * args.task_num][rank * per:(rank + 1) * per]
+            s = time.time()
+            batch = db_train.get_batch([int(i) for i in idx])
+            t_load = time.time() - s
+            s = time.time()
+            accs = maml(*batch, feat)
+            if step % args.train_result_report_steps == 0 and rank == 0:
+                print('Epoch:', epoch + 1, ' Step:', step, ' training acc:', str(accs[-1])[:5], ' time elapsed:', str(time.time() - s)[:5],
+                      ' data loading takes:', str(t_load)[:5])
+        accs = evaluate(maml, db_val)
+        if rank == 0:
+            print('Epoch:', epoch + 1, ' Val acc:', str(accs[-1])[:5])
+        if accs[-1] > max_acc:
+            max_acc, model_max = accs[-1], copy.deepcopy(maml)                       # train.py:125-127
+    accs = evaluate(maml, db_test)
+    accs_max = evaluate(model_max, db_test)
+    if rank == 0:
+        print('Test acc:', str(accs[-1])[:5])
+        print('Early Stopped Test acc:', str(accs_max[-1])[:5])
+        print('Total Time:', str(time.time() - s_start)[:5])
+    return {'test_acc': float(accs[-1]), 'early_stopped_test_acc': float(accs_max[-1]), 'val_best': float(max_acc)}
+
+
+if __name__ == '__main__':
+    main(parse())
