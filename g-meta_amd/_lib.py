@@ -20,7 +20,7 @@ class Model(C.Structure):
 
 class HParams(C.Structure):
     _fields_ = [('update_lr', C.c_float), ('update_step', C.c_int32), ('k_spt', C.c_int32), ('need_meta_grad', C.c_int32),
-                ('hoist_z1', C.c_int32), ('serialize', C.c_int32)]
+                ('hoist_z1', C.c_int32), ('serialize', C.c_int32), ('sparse_bwd', C.c_int32)]
 
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64

@@ -304,6 +304,21 @@ __global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list,
         if (indptr[r + 1] - indptr[r] > thr) { const int k = atomicAdd(count, 1); if (k < cap) list[k] = (int32_t)r; }
     }
 }
+// centre rows, their norms and in-degrees (row-sparse backward tables)
+__global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
+                              int32_t* crow, float* cnorm, int32_t* cdeg) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_c) return;
+    const int row = sub_off[k / nc] + centre[k];
+    crow[k] = row; cnorm[k] = norm[row]; cdeg[k] = indptr[row + 1] - indptr[row];
+}
+__global__ void k_centre_edges(const int32_t* crow, const int32_t* eoff, int n_c, const int32_t* indptr, const int32_t* indices,
+                               const float* norm, int32_t* e_row, int32_t* e_par, float* e_norm) {
+    const int k = blockIdx.x;
+    if (k >= n_c) return;
+    const int p0 = indptr[crow[k]], n = eoff[k + 1] - eoff[k], o = eoff[k];
+    for (int j = threadIdx.x; j < n; j += blockDim.x) { const int u = indices[p0 + j]; e_row[o + j] = u; e_par[o + j] = k; e_norm[o + j] = norm[u]; }
+}
 __global__ void k_copy_add(int32_t* dst, const int32_t* src, int64_t n, int32_t add) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k] + add;
 }
@@ -323,6 +338,9 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
     gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s);
+    gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
+    gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
+    gm_dev_free(b->d_e1_chunks, s); gm_dev_free(b->d_e1_set_chunk_off, s);
 }
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
@@ -373,6 +391,43 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
         }
     }
+    // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres
+    const int nc = b->centres; b->n_c = b->subs * nc;
+    int32_t* d_cdeg = nullptr;
+    GM_TRY(gm_alloc(&b->d_crow, b->n_c, s)); GM_TRY(gm_alloc(&b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
+    hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
+                       b->d_crow, b->d_cnorm, d_cdeg);
+    std::vector<int32_t> cdeg(b->n_c), eoff(b->n_c + 1, 0);
+    GM_HIP(hipMemcpyAsync(cdeg.data(), d_cdeg, 4 * (size_t)b->n_c, hipMemcpyDeviceToHost, s));
+    GM_HIP(hipStreamSynchronize(s));
+    gm_dev_free(d_cdeg, s);
+    for (int k = 0; k < b->n_c; ++k) eoff[k + 1] = eoff[k] + cdeg[k];
+    b->n_e1 = eoff[b->n_c];
+    int32_t* d_eoff = nullptr;
+    GM_TRY(gm_alloc(&d_eoff, eoff.size(), s));
+    GM_HIP(hipMemcpyAsync(d_eoff, eoff.data(), 4 * eoff.size(), hipMemcpyHostToDevice, s));
+    GM_TRY(gm_alloc(&b->d_e1_row, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_par, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_norm, b->n_e1, s));
+    hipLaunchKernelGGL(k_centre_edges, dim3(b->n_c), dim3(64), 0, s, b->d_crow, d_eoff, b->n_c, b->d_indptr, b->d_indices, b->d_norm,
+                       b->d_e1_row, b->d_e1_par, b->d_e1_norm);
+    std::vector<int32_t> ct, cc, ccoff(b->sets + 1, 0), ec, ecoff(b->sets + 1, 0);
+    for (int t = 0; t < b->sets; ++t) {
+        const int k0 = b->h_set_sub_off[t] * nc, k1 = b->h_set_sub_off[t + 1] * nc;
+        for (int k = k0; k < k1; k += GM_GEMM_BM) { ct.push_back(t); ct.push_back(k); ct.push_back(std::min(GM_GEMM_BM, k1 - k)); }
+        for (int k = k0; k < k1; k += 512) { cc.push_back(t); cc.push_back(k); cc.push_back(std::min(512, k1 - k)); }
+        ccoff[t + 1] = (int32_t)(cc.size() / 3);
+        for (int q = eoff[k0]; q < eoff[k1]; q += 512) { ec.push_back(t); ec.push_back(q); ec.push_back(std::min(512, eoff[k1] - q)); }
+        ecoff[t + 1] = (int32_t)(ec.size() / 3);
+    }
+    b->n_c_tiles = (int32_t)(ct.size() / 3); b->n_c_chunks = (int32_t)(cc.size() / 3); b->n_e1_chunks = (int32_t)(ec.size() / 3);
+    auto up = [&](int32_t** d, const std::vector<int32_t>& v) -> int {
+        GM_TRY(gm_alloc(d, v.size(), s));
+        if (!v.empty()) GM_HIP(hipMemcpyAsync(*d, v.data(), 4 * v.size(), hipMemcpyHostToDevice, s));
+        return GM_OK;
+    };
+    GM_TRY(up(&b->d_c_tiles, ct)); GM_TRY(up(&b->d_c_chunks, cc)); GM_TRY(up(&b->d_c_set_chunk_off, ccoff));
+    GM_TRY(up(&b->d_e1_chunks, ec)); GM_TRY(up(&b->d_e1_set_chunk_off, ecoff));
+    GM_HIP(hipStreamSynchronize(s));
+    gm_dev_free(d_eoff, s);
     return GM_OK;
 }
 

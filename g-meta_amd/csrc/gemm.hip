@@ -505,7 +505,12 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
 }
 
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
-    if (a.n_chunks <= 0) return GM_OK;
+    if (a.n_chunks <= 0) {      // no rows at all: the gradients are zero
+        const int tot0 = (a.K + 1) * a.N;
+        hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot0 + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off, a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     WgradK w{};
     w.A = a.A; w.lda = a.lda; w.K = a.K; w.a_row = a.a_row; w.G = a.G; w.ldg = a.ldg; w.N = a.N; w.Gb = a.Gb; w.ldgb = a.ldgb;
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;

@@ -75,6 +75,17 @@ struct gm_batch {
     int32_t* d_heavy[2] = {nullptr, nullptr};   // rows with more than gm_heavy_deg() edges, by-destination / by-source CSR
     int32_t n_heavy[2] = {0, 0};
     int32_t heavy_deg = 64;
+    // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
+    int32_t n_c = 0;                   // centre rows: subs * centres
+    int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
+    float* d_cnorm = nullptr;          // [n_c]  norm[centre row]
+    int32_t n_e1 = 0;                  // in-edges of centres, concatenated in centre order
+    int32_t* d_e1_row = nullptr;       // [n_e1] source row of the edge
+    int32_t* d_e1_par = nullptr;       // [n_e1] compact index of the centre it enters
+    float* d_e1_norm = nullptr;        // [n_e1] norm[source row]
+    int32_t* d_c_tiles = nullptr; int32_t n_c_tiles = 0;          // GEMM tiles over centre rows (per set)
+    int32_t* d_c_chunks = nullptr; int32_t* d_c_set_chunk_off = nullptr; int32_t n_c_chunks = 0;
+    int32_t* d_e1_chunks = nullptr; int32_t* d_e1_set_chunk_off = nullptr; int32_t n_e1_chunks = 0;
     hipStream_t stream = nullptr;      // stream the arrays were produced on
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);

@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
 }
 
 // Backward of the head for one set per block: dWl, dbl into dparams; dQ_L (pre-zeroed) at the centre rows,
-// already multiplied by relu'(H_L).
-__global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ) {
+// already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
+__global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ, float* Gc) {
     const int set = blockIdx.x, tid = threadIdx.x;
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits,
                 float v = 0.f;
                 for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
                 const int64_t at = centre_row(k, s, which) * k.ldh + col;
-                if (k.H[at] > 0.f) dQ[at] += v;
+                if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = k.H[at] > 0.f ? v : 0.f;     // compact rows (sparse backward)
+                else if (k.H[at] > 0.f) dQ[at] += v;
             }
         }
     }
@@ -171,6 +172,18 @@ __global__ void k_protos_to_dlogits(const float* dprotos, const int32_t* rows, i
     }
 }
 
+// Row-sparse backward, expansion through the transposed aggregate: for every in-edge e = (u -> centre k)
+//   G1[e,:] = norm[u] * relu'(H1[u,:]) * T2[k,:]      (dQ_{L-1} restricted to the rows that can be non-zero)
+__global__ void k_expand_edges(const float* T2, const float* H1, int F, const int32_t* e_row, const int32_t* e_par, const float* e_norm,
+                               int n_e, float* G1) {
+    const int64_t tot = (int64_t)n_e * F;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
+        const int e = (int)(id / F), f = (int)(id - (int64_t)e * F);
+        const float h = H1[(int64_t)e_row[e] * F + f];
+        G1[id] = h > 0.f ? e_norm[e] * T2[(int64_t)e_par[e] * F + f] : 0.f;
+    }
+}
+
 // dst[t, j] = src[t*src_stride + j] - lr * g[t*stride + j]     (meta.py:126,151)
 __global__ void k_sgd(float* dst, const float* src, int64_t src_stride, const float* g, float lr, int64_t P, int64_t stride, int T) {
     const int64_t tot = (int64_t)T * P;
@@ -228,6 +241,7 @@ struct Carver {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    float* cG2; float* cT2; float* cG1; float* partial_c;      // compact matrices of the row-sparse backward
     const float* x0_user; const int32_t* centre; int z1_valid;
     int zw[GM_MAX_GCN];
 };
@@ -247,6 +261,9 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
     c.bufA = cv.take<float>(rows * maxd);
     c.bufB = cv.take<float>(rows * maxd);
     c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
+    c.cG2 = cv.take<float>((int64_t)c.b->n_c * maxd); c.cT2 = cv.take<float>((int64_t)c.b->n_c * maxd);
+    c.cG1 = cv.take<float>((int64_t)c.b->n_e1 * maxd);
+    c.partial_c = cv.take<float>((int64_t)std::max(c.b->n_c_chunks, c.b->n_e1_chunks) * maxkn);
 }
 
 extern "C" int64_t gm_gcn_ws_bytes(const gm_batch_t* b, const gm_model_t* m) {
@@ -309,13 +326,17 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
     return GM_OK;
 }
 
-static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st);
+static bool sparse_bwd_ok(const gm_layout& L);
+
+static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int sparse = 0) {
+    if (sparse && sparse_bwd_ok(c.L)) return gcn_backward_sparse(c, params, pstride, dlogits, dparams, dstride, st);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     const int Lg = L.n_gcn;
     float* dQ = c.bufA; float* T = c.bufB;
     GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[Lg], st));
     HeadK k = make_head(c, params, pstride);
-    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ);
+    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ, (float*)nullptr);
     GM_HIP(hipGetLastError());
     for (int l = Lg - 1; l >= 0; --l) {
         const int fi = L.dims[l], fo = L.dims[l + 1];
@@ -353,6 +374,46 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             }
         }
     }
+    return GM_OK;
+}
+
+static bool sparse_bwd_ok(const gm_layout& L) {
+    if (L.n_gcn > 2) return false;
+    for (int l = 0; l < L.n_gcn; ++l) if (L.dims[l] > L.dims[l + 1]) return false;      // aggregate-first layers only
+    return true;
+}
+
+// Exact row-sparse backward (see gm_hparams_t.sparse_bwd).  The head is the only consumer of the last GCN layer, so
+// dQ_L lives on the centre rows; one transposed-aggregate step spreads it along the in-edges of the centres.  Every
+// product below is the dense backward's product with the structurally-zero terms removed.
+static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b;
+    const int Lg = L.n_gcn, fiL = L.dims[Lg - 1], foL = L.dims[Lg];
+    HeadK k = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, c.cG2);
+    GM_HIP(hipGetLastError());
+    // dW_L = sum_k norm[c_k] Z_L[c_k]^T G2[k] ; db_L = sum_k G2[k]
+    gm_wgrad_args w{}; w.A = c.Z[Lg - 1]; w.lda = fiL; w.K = fiL; w.a_row = b->d_crow; w.a_scale = b->d_cnorm; w.G = c.cG2; w.ldg = foL; w.N = foL;
+    w.chunks = b->d_c_chunks; w.n_chunks = b->n_c_chunks; w.set_chunk_off = b->d_c_set_chunk_off; w.sets = b->sets; w.partial = c.partial_c;
+    w.dW = dparams + L.w_off[Lg - 1]; w.dw_stride = dstride; w.db = dparams + L.b_off[Lg - 1]; w.db_stride = dstride;
+    GM_TRY(gm_launch_wgrad(w, st));
+    if (Lg == 1) return GM_OK;
+    // T2[k] = norm[c_k] * (G2[k] W_L^T)
+    gm_gemm_args g{}; g.A = c.cG2; g.lda = foL; g.B = params + L.w_off[Lg - 1]; g.b_stride = pstride; g.transB = 1; g.C = c.cT2; g.ldc = fiL; g.K = foL; g.N = fiL;
+    g.row_scale = b->d_cnorm; g.tiles = b->d_c_tiles; g.n_tiles = b->n_c_tiles;
+    GM_TRY(gm_launch_gemm_nn(g, st));
+    if (b->n_e1 > 0) {
+        const int64_t tot = (int64_t)b->n_e1 * fiL;
+        hipLaunchKernelGGL(k_expand_edges, dim3((int)std::min<int64_t>(2048, (tot + 255) / 256)), dim3(256), 0, st, c.cT2, c.H[0], fiL, b->d_e1_row, b->d_e1_par,
+                           b->d_e1_norm, b->n_e1, c.cG1);
+        GM_HIP(hipGetLastError());
+    }
+    // dW_1 = sum_e norm[u_e] Z_1[u_e]^T G1[e] ; db_1 = sum_e G1[e]   (a set without any centre in-edge gets zeros: empty chunk range)
+    const int f0 = L.dims[0];
+    gm_wgrad_args w1{}; w1.A = c.Z[0]; w1.lda = f0; w1.K = f0; w1.a_row = b->d_e1_row; w1.a_scale = b->d_e1_norm; w1.G = c.cG1; w1.ldg = fiL; w1.N = fiL;
+    w1.chunks = b->d_e1_chunks; w1.n_chunks = b->n_e1_chunks; w1.set_chunk_off = b->d_e1_set_chunk_off; w1.sets = b->sets; w1.partial = c.partial_c;
+    w1.dW = dparams + L.w_off[0]; w1.dw_stride = dstride; w1.db = dparams + L.b_off[0]; w1.db_stride = dstride;
+    GM_TRY(gm_launch_wgrad(w1, st));
     return GM_OK;
 }
 
@@ -559,7 +620,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_TRY(gcn_forward(p.S, theta, 0, p.logit_s, st, hoist));
     GM_TRY(spt_loss(0));
     hipEvent_t e_proto0 = signal(st);
-    GM_TRY(gcn_backward(p.S, theta, 0, p.dlog_s, p.g, Pp, st));
+    GM_TRY(gcn_backward(p.S, theta, 0, p.dlog_s, p.g, Pp, st, hp->sparse_bwd));
     hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(1), theta, (int64_t)0, p.g, hp->update_lr, L.P, Pp, T);
     hipEvent_t e_fw = signal(st);                          // fw_1 ready
     GM_TRY(gcn_forward(p.Q, theta, 0, p.logit_q, sq, hoist));
@@ -572,7 +633,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     for (int k = 1; k < K; ++k) {            // meta.py:143-157
         GM_TRY(gcn_forward(p.S, fw(k), Pp, p.logit_s, st, hoist));
         GM_TRY(spt_loss(k));
-        GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.g, Pp, st));
+        GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.g, Pp, st, hp->sparse_bwd));
         hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(k + 1), fw(k), Pp, p.g, hp->update_lr, L.P, Pp, T);
         e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
         wait(sq, e_fw);
@@ -583,11 +644,11 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
             // query forward (on sq) plus d L_q / d fw_{K-1} through the prototypes of the last support forward (on st).
             hipEvent_t e_dp = signal(sq);                  // dprotos ready
-            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq));
+            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq, hp->sparse_bwd));
             wait(st, e_dp);
             GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
             hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, Ct, ns, C, p.dlog_s);
-            GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st));
+            GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st, hp->sparse_bwd));
             have_grad = true;
         }
     }

@@ -55,6 +55,10 @@ typedef struct gm_hparams {
                               1 = aggregate layer-1 input once per call (loop-invariant)   */
     int32_t serialize;     /* 0 = support chain and query evaluations on two HIP streams (default);
                               1 = everything on `stream` (for per-kernel timing / profiling)  */
+    int32_t sparse_bwd;    /* 0 = dense backward over every subgraph row (reference-equivalent schedule, default);
+                              1 = exact row-sparse backward: only the head touches the last layer, so dQ_L is non-zero
+                              at centre rows only and dQ_{L-1} only along in-edges of centres -- same sums without
+                              the structural zeros (models with <= 2 aggregate-first GCN layers; else falls back) */
 } gm_hparams_t;
 
 const char* gm_last_error(void);
