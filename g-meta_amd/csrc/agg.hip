@@ -269,8 +269,10 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     AggK a = a0;
     // window = 64 rows per wave when that still gives >= ~8 waves per CU; otherwise shrink it so that small batches
     // (the support sets, or a 4-task shard) are spread over the whole chip instead of being walked serially
+    static int min_waves = -1;
+    if (min_waves < 0) { const char* e = getenv("GM_AGG_MIN_WAVES"); min_waves = e ? atoi(e) : 8192; }
     a.win = 64;
-    while (a.win > 8 && a.rows / a.win < 2048) a.win >>= 1;
+    while (a.win > 8 && a.rows / a.win < min_waves) a.win >>= 1;
     const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
     a.nblocks = (int)((a.rows + RPB - 1) / RPB);
     if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);

@@ -202,6 +202,135 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant of the forward GEMM (C = epi(A W_t), W row-major [K,N], K % 16 == 0, N % (64*WC) == 0):
+// tiles are DMA-ed HBM -> LDS with global_load_lds_dwordx4 (no staging registers), three LDS stages, and a COUNTED
+// s_waitcnt vmcnt so that the loads of chunks k+1 and k+2 stay in flight across the single barrier of chunk k.
+// LDS images are lane-linear (the DMA writes wave-uniform base + lane*16 B): A tile [128][16] floats unpadded (the
+// b128 fragment reads are 4-way bank conflicted -- irrelevant next to 64-cycle f32 MFMAs), B tile [16][64*WC].
+template <int WC>
+__global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
+    constexpr int NT = 128 * WC, NW = 2 * WC, BN = 64 * WC;
+    constexpr int A_FLOATS = GM_GEMM_BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
+    constexpr int EP_LD = 68, EPI_FLOATS = NW * 32 * EP_LD;
+    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE > EPI_FLOATS ? 3 * STAGE : EPI_FLOATS];
+    const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
+    const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb / g.n_col_tiles, ct = lb % g.n_col_tiles;
+    const int set = g.tiles[tile * 3], row0 = g.tiles[tile * 3 + 1], nrows = g.tiles[tile * 3 + 2];
+    const int n0 = ct * BN;
+    const float* Bp = g.B + (int64_t)set * g.b_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, kh = lane >> 5;
+    // DMA pieces of 1 KiB (64 lanes x 16 B).  A tile = 8 pieces (16 rows x 16 floats each), B tile = BK*BN*4/1024 pieces.
+    constexpr int A_PIECES = A_FLOATS / 256, B_PIECES = B_FLOATS / 256, PIECES = A_PIECES + B_PIECES;
+    constexpr int PPW = (PIECES + NW - 1) / NW;                         // pieces per wave per chunk
+    static_assert(PIECES % NW == 0, "tile pieces must divide evenly over the waves");
+    // per-lane source pointers of this wave's pieces (advance by k0 / k0*N per chunk)
+    const float* src[PPW]; int dstoff[PPW]; int64_t kstep[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+        const int piece = wave * PPW + p;
+        if (piece < A_PIECES) {                                        // rows piece*16 .. +15, lane -> (row, k4)
+            const int rr = piece * 16 + (lane >> 2);
+            src[p] = g.A + (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + (lane & 3) * 4;
+            kstep[p] = BK; dstoff[p] = piece * 256;
+        } else {                                                       // B: piece -> 256 consecutive floats of the [16][BN] tile
+            const int e = (piece - A_PIECES) * 256 + lane * 4;
+            const int kk = e / BN, n = e % BN;
+            src[p] = Bp + (int64_t)kk * g.N + n0 + n;
+            kstep[p] = (int64_t)BK * g.N; dstoff[p] = A_FLOATS + (piece - A_PIECES) * 256;
+        }
+    }
+    // The DMA is issued through inline asm: with the builtin, hipcc cannot prove that the (dynamic) stage being filled
+    // does not alias the stage being read and drains vmcnt(0) before the first ds_read, which serialises the pipeline.
+    // An asm statement is outside its vmcnt bookkeeping; completion is counted by hand below (cdna_hip_programming.md 5.7).
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)smem);
+    auto issue = [&](int chunk) {
+        const unsigned st = lds_base + (unsigned)((chunk % 3) * STAGE * 4);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const float* gsrc = src[p] + chunk * kstep[p];
+            const unsigned dst = __builtin_amdgcn_readfirstlane(st + (unsigned)dstoff[p] * 4u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nchunks = g.K / BK;
+    issue(0);
+    if (nchunks > 1) issue(1);
+    for (int c = 0; c < nchunks; ++c) {
+        // this wave's pieces of chunk c have landed once at most the PPW pieces of chunk c+1 are still outstanding
+        if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave's pieces of chunk c landed; everyone is done reading chunk c-1
+        if (c + 2 < nchunks) issue(c + 2);             // into the stage chunk c-1 occupied
+        const float* As = smem + (c % 3) * STAGE;
+        const float* Bs = As + A_FLOATS;
+        float4 af[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+                af[i][qq] = *reinterpret_cast<const float4*>(&As[(wr * 64 + i * 32 + li) * BK + qq * 8 + kh * 4]);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int kk = qq * 8 + kh * 4 + rr;
+                const float b0 = Bs[kk * BN + wc * 64 + li], b1 = Bs[kk * BN + wc * 64 + 32 + li];
+                const float a0 = rr == 0 ? af[0][qq].x : rr == 1 ? af[0][qq].y : rr == 2 ? af[0][qq].z : af[0][qq].w;
+                const float a1 = rr == 0 ? af[1][qq].x : rr == 1 ? af[1][qq].y : rr == 2 ? af[1][qq].z : af[1][qq].w;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // all MFMAs' LDS reads done before the epilogue reuses the stages
+    const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+    float* E = smem + wave * (32 * EP_LD);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int col = n0 + wc * 64 + ec;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (biasp) b4 = *reinterpret_cast<const float4*>(biasp + col);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = wr * 64 + i * 32 + it * 4 + er;
+            if (rl >= nrows) continue;
+            const int64_t row = row0 + rl;
+            const float sc = g.row_scale ? g.row_scale[row] : 1.f;
+            float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+            v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+            if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+            if (g.mask_h) {
+                const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+        }
+    }
+}
+
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
@@ -226,6 +355,17 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (bn > bn_cap) bn = bn_cap;
     while (bn > 64 && (int64_t)a.n_tiles * ((a.N + bn - 1) / bn) < 512) bn >>= 1;
     g.n_col_tiles = (a.N + bn - 1) / bn;
+    static int use_glds = -1;
+    if (use_glds < 0) { const char* e = getenv("GM_GEMM_GLDS"); use_glds = e ? atoi(e) : 1; }
+    const bool bias_al = !a.bias || ((((uintptr_t)a.bias & 15) == 0) && (a.bias_stride % 4 == 0));
+    if (use_glds && vec && !a.transB && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
+        const dim3 grid(g.n_tiles * g.n_col_tiles);
+        if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);
+        else if (bn == 128) hipLaunchKernelGGL((k_gemm_glds<2>), grid, dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((k_gemm_glds<1>), grid, dim3(128), 0, s, g);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (bn == 256) GM_LAUNCH_GEMM(4, 512);
     else if (bn == 128) GM_LAUNCH_GEMM(2, 256);
     else GM_LAUNCH_GEMM(1, 128);
