@@ -161,10 +161,9 @@ __global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
 // per row); then the row loads are issued from register-held addresses (broadcast by ds_bpermute), UNR rows at a
 // time, so up to 2*UNR independent 16-B loads per lane are in flight.  Edges beyond the second (p99 ~ 19) take a
 // conventional loop.  LPR = width/4 lanes own a row (width 256: the whole wave, 1 KiB per access).
-template <int LPR, int NCH>
+template <int LPR, int NCH, int UNR, int MB>
 __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     constexpr int G = GM_WAVE / LPR;           // rows processed side by side
-    constexpr int UNR = 4;
     const int nb = a.nblocks, b = blockIdx.x;
     const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
     const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -217,10 +216,10 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
                 int mu = 0; float mw = 0.f;
                 if (eb + l < eend) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
                 const int cnt = min(LPR, eend - eb);
-                for (int j = 0; j < cnt; j += 8) {
-                    float4 v[8][NCH]; float ww[8];
+                for (int j = 0; j < cnt; j += MB) {
+                    float4 v[MB][NCH]; float ww[MB];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < MB; ++i) {
                         const int sl = g * LPR + ((j + i) & (LPR - 1));
                         const int uu = __shfl(mu, sl, 64);
                         ww[i] = (j + i < cnt) ? __shfl(mw, sl, 64) : 0.f;      // out-of-range slots re-read a valid row with weight 0
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
                         for (int c = 0; c < NCH; ++c) v[i][c] = *reinterpret_cast<const float4*>(xl + (int64_t)uu * a.ldx + c * LPR * 4);
                     }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
+                    for (int i = 0; i < MB; ++i)
 #pragma unroll
                         for (int c = 0; c < NCH; ++c) vfma(acc[k][c], v[i][c], ww[i]);
                 }
@@ -276,7 +275,12 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
     a.nblocks = (int)((a.rows + RPB - 1) / RPB);
     if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
-    hipLaunchKernelGGL((k_agg_win<LPR, NCH>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
+    static int unr = -1;
+    if (unr < 0) { const char* e = getenv("GM_AGG_UNR"); unr = e ? atoi(e) : 24; }
+#define GM_AGG_CASE(U_, M_) if (unr == U_ * 10 + M_) { hipLaunchKernelGGL((k_agg_win<LPR, NCH, U_, M_>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a); return; }
+    GM_AGG_CASE(1, 2) GM_AGG_CASE(1, 4) GM_AGG_CASE(2, 2) GM_AGG_CASE(2, 4) GM_AGG_CASE(4, 2) GM_AGG_CASE(4, 4) GM_AGG_CASE(3, 4) GM_AGG_CASE(2, 6)
+#undef GM_AGG_CASE
+    hipLaunchKernelGGL((k_agg_win<LPR, NCH, 2, 4>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
 template <int VEC, int LPR>
