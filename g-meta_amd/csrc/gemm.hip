@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GemmK {
     const float* A; int64_t lda; const float* B; int64_t b_stride; int transB; float* C; int64_t ldc; int K, N;
     const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
-    const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec, c_vec;
+    const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec, c_vec; int nt_store;
 };
 
 // Block tile 128 x (64*WC); 2 x WC waves, each wave a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks.
@@ -326,7 +326,11 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
                 const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
                 v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
             }
-            *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+            if (g.nt_store) {     // C is re-read by the NEXT kernel only (>> L2): keep L2 for the A rows and the weights
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+            } else *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
         }
     }
 }
@@ -334,7 +338,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
-            a.tiles, a.n_tiles, 0, 0, 0, 0};
+            a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
     g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
     g.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.mask_h || (((uintptr_t)a.mask_h & 15) == 0));
@@ -358,6 +362,9 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("GM_GEMM_GLDS"); use_glds = e ? atoi(e) : 1; }
     const bool bias_al = !a.bias || ((((uintptr_t)a.bias & 15) == 0) && (a.bias_stride % 4 == 0));
+    static int nts = -1;
+    if (nts < 0) { const char* e = getenv("GM_GEMM_NT"); nts = e ? atoi(e) : 1; }
+    g.nt_store = nts;
     if (use_glds && vec && !a.transB && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
         const dim3 grid(g.n_tiles * g.n_col_tiles);
         if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);

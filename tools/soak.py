@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Soak test at the arxiv shape: N meta-steps, each with a FRESH extraction (get_batch) + Meta.forward, then a batched
+finetunning; checks finite outputs and that device memory does not grow."""
+import os, sys, time, random
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gmeta_amd
+from gmeta_amd import synth
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+T = 32
+args, cfg = synth.make_args('arxiv')
+np.random.seed(222); random.seed(222); torch.manual_seed(222)
+data = synth.node_dataset(cfg['n'], cfg['m'], cfg['F0'], cfg['classes'])
+store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+maml = gmeta_amd.Meta(args, synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])).to('cuda')
+db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=3, k_shot=3, k_query=24, batchsz=T * N, args=args, adjs=store, h=2,
+                         tables={'train': (data['names'], data['labels'])}, verbose=False)
+free0 = None
+t0 = time.perf_counter()
+for s in range(N):
+    b = db.get_batch(list(range(s * T, (s + 1) * T)))
+    accs = maml(*b, None)
+    assert np.isfinite(accs).all(), accs
+    if s == 4:
+        torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    if s % 10 == 0:
+        print('step %3d acc0 %.3f accK %.3f loss %.4f free %.1f GB' % (s, accs[0], accs[-1], maml.last_stats['loss_q'], torch.cuda.mem_get_info()[0] / 2**30), flush=True)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+free1 = torch.cuda.mem_get_info()[0]
+print('%d steps incl. extraction: %.1f ms/step = %.0f tasks/s ; free memory drift %.1f MB' % (N, dt / N * 1e3, T * N / dt, (free0 - free1) / 2**20))
+ev = db.get_batch(list(range(8)))
+fa = maml.finetunning_batch(ev[0], ev[1], ev[2], ev[3])
+print('finetunning_batch over 8 tasks, K_test=%d: mean accs first/last %.3f %.3f' % (maml.update_step_test, fa[:, 0].mean(), fa[:, -1].mean()))
+assert abs(free0 - free1) < 512 * 2**20, 'device memory grows'
