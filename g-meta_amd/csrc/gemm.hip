@@ -556,45 +556,73 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     }
     float4 pf[PF]; float pfs[PF];
     float bsum = 0.f;
+    int nr_loaded = 0;
+    // load_stage only ISSUES loads (clamped rows, no select on a loaded value, no divergent branch), so nothing forces a
+    // vmcnt wait before the MFMA loop; A/G selection, the norm scale and the row-validity zeroing happen in store_stage.
     auto load_stage = [&](int r0) {
-        const int nr = min(RK, nrows - r0);
+        nr_loaded = min(RK, nrows - r0);
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
-            const int64_t row = row0 + r0 + min(rrp[p], nr - 1);
+            const int64_t row = row0 + r0 + min(rrp[p], nr_loaded - 1);
             const float* src = isA[p] ? w.A + row * w.lda + colp[p] : w.G + row * w.ldg + colp[p];
             pf[p] = *reinterpret_cast<const float4*>(src);
-            pfs[p] = (isA[p] && w.a_scale) ? w.a_scale[row] : 1.f;
-            if (!(inr[p] && rrp[p] < nr)) pfs[p] = 0.f;          // rows past the chunk end contribute zeros
+            if (w.a_scale) pfs[p] = w.a_scale[row];            // wave-uniform branch (kernel argument)
         }
     };
-    auto store_stage = [&]() {
+    // Pipeline per stage (RK rows), LDS double-buffered:
+    //   issue HBM loads of stage s+1 -> first half of the MFMAs of stage s -> regs of s+1 -> LDS buffer (s+1)&1
+    //   -> second half of the MFMAs -> ONE barrier.
+    // Fragments are register double-buffered: the ds_reads of k-pair j+1 are issued before the MFMAs of k-pair j.
+    constexpr int BUF = RK * ld;
+    auto store_stage_to = [&](float* dst) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (inr[p]) *reinterpret_cast<float4*>(&sm[(tid + p * WG_THREADS) * 4]) = make_float4(pf[p].x * pfs[p], pf[p].y * pfs[p], pf[p].z * pfs[p], pf[p].w * pfs[p]);
+        for (int p = 0; p < PF; ++p) {
+            float sc = (isA[p] && w.a_scale) ? pfs[p] : 1.f;
+            if (rrp[p] >= nr_loaded) sc = 0.f;
+            if (inr[p]) *reinterpret_cast<float4*>(&dst[(tid + p * WG_THREADS) * 4]) = make_float4(pf[p].x * sc, pf[p].y * sc, pf[p].z * sc, pf[p].w * sc);
+        }
     };
+    int aoff[TPW], goff[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        const int tt = t * WG_WAVES + wave;
+        const int tq = (TT % WG_WAVES == 0 || tt < TT) ? tt : 0;
+        aoff[t] = kh * ld + (tq / TN) * 32 + li; goff[t] = kh * ld + ldA + (tq % TN) * 32 + li;
+    }
     load_stage(0);
-    store_stage();
+    store_stage_to(sm);
     __syncthreads();
-    for (int r0 = 0; r0 < nrows; r0 += RK) {
+    int cur = 0;
+    for (int r0 = 0; r0 < nrows; r0 += RK, cur ^= 1) {
         const bool more = r0 + RK < nrows;
+        const float* S = sm + cur * BUF;
         if (more) load_stage(r0 + RK);
         if (zs == 0 && tid < ldG) {
 #pragma unroll
-            for (int rr = 0; rr < RK; ++rr) bsum += sm[rr * ld + ldA + tid];
+            for (int rr = 0; rr < RK; ++rr) bsum += S[rr * ld + ldA + tid];
         }
-#pragma unroll 2
-        for (int kk = 0; kk < RK; kk += 2) {
+        float fa[TPW], fg[TPW], na[TPW], ng[TPW];
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) {
-                const int tt = t * WG_WAVES + wave;
-                if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs)) {
-                    const int tk = tt / TN, tn = tt % TN;
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(sm[(kk + kh) * ld + tk * 32 + li], sm[(kk + kh) * ld + ldA + tn * 32 + li], acc[t], 0, 0, 0);
+        for (int t = 0; t < TPW; ++t) { fa[t] = S[aoff[t]]; fg[t] = S[goff[t]]; }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int kk = half * (RK / 2); kk < (half + 1) * (RK / 2); kk += 2) {
+                const int kn = (kk + 2 < RK) ? kk + 2 : kk;                 // last pair re-reads itself (harmless)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) { na[t] = S[kn * ld + aoff[t]]; ng[t] = S[kn * ld + goff[t]]; }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const int tt = t * WG_WAVES + wave;
+                    if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs))
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fg[t], acc[t], 0, 0, 0);
                 }
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) { fa[t] = na[t]; fg[t] = ng[t]; }
             }
+            if (half == 0 && more) store_stage_to(sm + (cur ^ 1) * BUF);    // other buffer: last read before the previous barrier
         }
         __syncthreads();
-        if (more) { store_stage(); __syncthreads(); }
     }
     float* out = w.partial + (int64_t)chunk * (ldA + 1) * ldG;
 #pragma unroll
@@ -616,7 +644,7 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     constexpr int TPW = (TK * TN + WG_WAVES - 1) / WG_WAVES;
     int zs = 1;
     while (zs < TPW && w.n_chunks * zs < 256) zs <<= 1;       // TPW is 1, 2 or 4
-    const size_t lds = RK * ld * sizeof(float);
+    const size_t lds = 2 * RK * ld * sizeof(float);   // double-buffered stages
     static bool attr_done = false;
     if (!attr_done) {
         GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -662,10 +690,10 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.A = a.A; w.lda = a.lda; w.K = a.K; w.a_row = a.a_row; w.G = a.G; w.ldg = a.ldg; w.N = a.N; w.Gb = a.Gb; w.ldgb = a.ldgb;
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
     w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
+    bool launched = false;
     const bool fast_ok = (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
                          (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
-    bool launched = false;
-    if (fast_ok) {
+    if (fast_ok && !launched) {
 #define GM_WG_CASE(TK_, TN_) if (!launched && w.TK == TK_ && w.TN == TN_) { launch_wgrad_fast<TK_, TN_>(w, s); launched = true; }
         GM_WG_CASE(8, 8) GM_WG_CASE(4, 8) GM_WG_CASE(8, 4) GM_WG_CASE(4, 4) GM_WG_CASE(2, 4) GM_WG_CASE(4, 2) GM_WG_CASE(2, 2)
         GM_WG_CASE(1, 2) GM_WG_CASE(2, 1) GM_WG_CASE(1, 4) GM_WG_CASE(1, 8) GM_WG_CASE(1, 1)
