@@ -213,7 +213,8 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
     constexpr int NT = 128 * WC, NW = 2 * WC, BN = 64 * WC;
     constexpr int A_FLOATS = GM_GEMM_BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
     constexpr int EP_LD = 68, EPI_FLOATS = NW * 32 * EP_LD;
-    __shared__ __attribute__((aligned(16))) float smem[3 * STAGE > EPI_FLOATS ? 3 * STAGE : EPI_FLOATS];
+    constexpr int MAIN_FLOATS = 3 * STAGE > EPI_FLOATS ? 3 * STAGE : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS + GM_GEMM_BM];      // + the tile's 128 row scales
     const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
     const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
     const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -222,6 +223,10 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
     const int n0 = ct * BN;
     const float* Bp = g.B + (int64_t)set * g.b_stride;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The epilogue's per-row scales (norm) are fetched now and parked in LDS: as dependent loads inside the epilogue they
+    // cost 16 exposed L2 round trips per tile.
+    float my_scale = 1.f;
+    if (tid < GM_GEMM_BM && g.row_scale) my_scale = g.row_scale[row0 + min(tid, nrows - 1)];
     const int wr = wave / WC, wc = wave % WC;
     const int li = lane & 31, kh = lane >> 5;
     // DMA pieces of 1 KiB (64 lanes x 16 B).  A tile = 8 pieces (16 rows x 16 floats each), B tile = BK*BN*4/1024 pieces.
@@ -269,6 +274,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
     const int nchunks = g.K / BK;
     issue(0);
     if (nchunks > 1) issue(1);
+    if (tid < GM_GEMM_BM) smem[MAIN_FLOATS + tid] = my_scale;      // visible to everyone after the first barrier of the main loop
     for (int c = 0; c < nchunks; ++c) {
         // this wave's pieces of chunk c have landed once at most the PPW pieces of chunk c+1 are still outstanding
         if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
             const int rl = wr * 64 + i * 32 + it * 4 + er;
             if (rl >= nrows) continue;
             const int64_t row = row0 + rl;
-            const float sc = g.row_scale ? g.row_scale[row] : 1.f;
+            const float sc = smem[MAIN_FLOATS + rl];
             float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
             v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
             if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
