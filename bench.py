@@ -90,8 +90,9 @@ def main():
     if a.gpus > 1 and world != a.gpus:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    use_dist = world > 1 or os.environ.get('GMETA_FORCE_DIST') == '1'      # the latter: exercise the RCCL path with one rank
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
     over = {'hoist_z1': a.hoist_z1, 'serialize': a.serialize, 'sparse_bwd': a.sparse_bwd}
@@ -108,6 +109,7 @@ def main():
     store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
     config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
     maml = gmeta_amd.Meta(args, config).to('cuda')
+    maml.force_allreduce = os.environ.get('GMETA_FORCE_DIST') == '1' and os.environ.get('GMETA_SKIP_ALLREDUCE') != '1'
     db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'],
                              batchsz=T * a.n_batches, args=args, adjs=store, h=cfg['h'],
                              tables={'train': (data['names'], data['labels'])}, verbose=False)
@@ -224,7 +226,7 @@ def main():
             except Exception as e:   # the baseline is a reported number, never the product path
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

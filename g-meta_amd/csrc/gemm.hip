@@ -530,24 +530,34 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
 template <int TK, int TN, int ZS>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     constexpr int ldA = TK * 32, ldG = TN * 32, ld = ldA + ldG, ld4 = ld / 4;
-    // stage = RK rows: its MFMA phase must outlast a loaded HBM round trip (a few microseconds) for the register prefetch
-    // of the next stage to land in time -- 32 rows at ld <= 512 (64 KiB of LDS, one workgroup per CU anyway)
+    // stage = RK rows: its MFMA phase must outlast a loaded HBM round trip for the register prefetch of the next stage to
+    // land in time -- 32 rows at ld <= 512 (two 64-KiB LDS buffers, one workgroup per CU anyway)
     constexpr int RK = (16384 / ld) >= 32 ? 32 : (16384 / ld) >= 16 ? 16 : 8;
     constexpr int PER4 = RK * ld4, PF = (PER4 + WG_THREADS - 1) / WG_THREADS;
     constexpr int TT = TK * TN, TPW = (TT + WG_WAVES - 1) / WG_WAVES;
-    static_assert(PF <= 4 && TPW <= 4, "tile grid too large for the fast weight-gradient kernel");
+    static_assert(PF <= 4 && TPW <= 4 && TPW % ZS == 0, "tile grid too large for the fast weight-gradient kernel");
+    // gridDim.y = ZS splits this chunk's output tiles over ZS workgroups (each does 1/ZS of the MFMAs): used when a batch
+    // has too few row chunks to fill the chip.  A wave's NACC active tiles are t = j*ZS + zs (compile-time count).
+    constexpr int NACC = TPW / ZS;
+    constexpr int BUF = RK * ld;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    // gridDim.y = ZS splits this chunk's output tiles over ZS workgroups (each does 1/ZS of the MFMAs): used when a
-    // batch has too few row chunks to fill the chip
     const int zs = ZS > 1 ? (int)blockIdx.y : 0;
     const int chunk = blockIdx.x;
     const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-    f32x16 acc[TPW];
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int t = 0; t < TPW; ++t)
+    for (int t = 0; t < NACC; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+    int aoff[NACC], goff[NACC], tile_id[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t) {
+        const int tt = (t * ZS + zs) * WG_WAVES + wave;
+        tile_id[t] = tt < TT ? tt : -1;
+        const int tq = tt < TT ? tt : 0;                       // inactive slots compute on tile 0 and are never written
+        aoff[t] = kh * ld + (tq / TN) * 32 + li; goff[t] = kh * ld + ldA + (tq % TN) * 32 + li;
+    }
     // stage-invariant staging coordinates of this thread's PF float4 slots
     int rrp[PF], colp[PF]; bool isA[PF], inr[PF];
 #pragma unroll
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     float bsum = 0.f;
     int nr_loaded = 0;
     // load_stage only ISSUES loads (clamped rows, no select on a loaded value, no divergent branch), so nothing forces a
-    // vmcnt wait before the MFMA loop; A/G selection, the norm scale and the row-validity zeroing happen in store_stage.
+    // vmcnt wait before the MFMA loop; A/G selection, the norm scale and the row-validity zeroing happen at LDS-store time.
     auto load_stage = [&](int r0) {
         nr_loaded = min(RK, nrows - r0);
 #pragma unroll
@@ -575,26 +585,16 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
             if (w.a_scale) pfs[p] = w.a_scale[row];            // wave-uniform branch (kernel argument)
         }
     };
-    // Pipeline per stage (RK rows), LDS double-buffered:
-    //   issue HBM loads of stage s+1 -> first half of the MFMAs of stage s -> regs of s+1 -> LDS buffer (s+1)&1
-    //   -> second half of the MFMAs -> ONE barrier.
-    // Fragments are register double-buffered: the ds_reads of k-pair j+1 are issued before the MFMAs of k-pair j.
-    constexpr int BUF = RK * ld;
     auto store_stage_to = [&](float* dst) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {
             float sc = (isA[p] && w.a_scale) ? pfs[p] : 1.f;
-            if (rrp[p] >= nr_loaded) sc = 0.f;
+            if (rrp[p] >= nr_loaded) sc = 0.f;                  // rows past the chunk end contribute zeros
             if (inr[p]) *reinterpret_cast<float4*>(&dst[(tid + p * WG_THREADS) * 4]) = make_float4(pf[p].x * sc, pf[p].y * sc, pf[p].z * sc, pf[p].w * sc);
         }
     };
-    int aoff[TPW], goff[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tt = t * WG_WAVES + wave;
-        const int tq = (TT % WG_WAVES == 0 || tt < TT) ? tt : 0;
-        aoff[t] = kh * ld + (tq / TN) * 32 + li; goff[t] = kh * ld + ldA + (tq % TN) * 32 + li;
-    }
+    // Pipeline per stage, LDS double-buffered: issue HBM loads of stage s+1 -> first half of the MFMAs of stage s ->
+    // registers of s+1 -> LDS buffer (s+1)&1 -> second half of the MFMAs -> ONE barrier.
     load_stage(0);
     store_stage_to(sm);
     __syncthreads();
@@ -607,24 +607,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
 #pragma unroll
             for (int rr = 0; rr < RK; ++rr) bsum += S[rr * ld + ldA + tid];
         }
-        float fa[TPW], fg[TPW], na[TPW], ng[TPW];
-#pragma unroll
-        for (int t = 0; t < TPW; ++t) { fa[t] = S[aoff[t]]; fg[t] = S[goff[t]]; }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-#pragma unroll
+#pragma unroll 4
             for (int kk = half * (RK / 2); kk < (half + 1) * (RK / 2); kk += 2) {
-                const int kn = (kk + 2 < RK) ? kk + 2 : kk;                 // last pair re-reads itself (harmless)
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) { na[t] = S[kn * ld + aoff[t]]; ng[t] = S[kn * ld + goff[t]]; }
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    const int tt = t * WG_WAVES + wave;
-                    if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs))
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fg[t], acc[t], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) { fa[t] = na[t]; fg[t] = ng[t]; }
+                for (int t = 0; t < NACC; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[kk * ld + aoff[t]], S[kk * ld + goff[t]], acc[t], 0, 0, 0);
             }
             if (half == 0 && more) store_stage_to(sm + (cur ^ 1) * BUF);    // other buffer: last read before the previous barrier
         }
@@ -632,10 +621,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     }
     float* out = w.partial + (int64_t)chunk * (ldA + 1) * ldG;
 #pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        const int tt = t * WG_WAVES + wave;
-        if ((TT % WG_WAVES == 0 || tt < TT) && (ZS == 1 || (t % ZS) == zs)) {
-            const int tk = tt / TN, tn = tt % TN;
+    for (int t = 0; t < NACC; ++t) {
+        if (tile_id[t] >= 0) {
+            const int tk = tile_id[t] / TN, tn = tile_id[t] % TN;
 #pragma unroll
             for (int e = 0; e < 16; ++e) out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * ldG + tn * 32 + li] = acc[t][e];
         }

@@ -4,6 +4,7 @@
 // meta-step and nothing returns to the host until the accuracies are read back.
 #include <algorithm>
 #include <map>
+#include <stdlib.h>
 #include "gm_internal.h"
 
 void gm_prof_reset();
@@ -519,7 +520,22 @@ struct MetaStreams {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;
     int ensure(int n) {
-        if (!side) GM_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        if (!side) {
+            // The query stream carries bulk, throughput-bound work; the caller's stream carries the latency-critical
+            // support chain.  A lower priority (a) lets support kernels win CUs when both have work and (b) gives this
+            // stream a hardware queue of its own: HIP multiplexes same-priority streams onto a small pool of HW queues
+            // (GPU_MAX_HW_QUEUES, default 4), and once RCCL/torch have created their streams an ordinary stream created
+            // here was observed to alias the caller's queue, silently serialising the whole step.
+            int lo = 0, hi = 0;
+            static int use_prio = -1;
+            if (use_prio < 0) { const char* e = getenv("GM_SIDE_STREAM_PRIORITY"); use_prio = e ? atoi(e) : 1; }
+            if (use_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+                GM_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));      // `lo` = least priority
+            } else {
+                (void)hipGetLastError();
+                GM_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            }
+        }
         while ((int)ev.size() < n) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev.push_back(e); }
         return GM_OK;
     }

@@ -161,3 +161,25 @@ def test_synthetic_generator_is_seeded_and_sane():
     args, cfg = synth.make_args('arxiv')
     assert (args.task_num, args.update_step, cfg['hidden'], cfg['F0']) == (32, 10, 256, 128)
     assert synth.make_config(128, 256, 2, 3) == [('GraphConv', [128, 256]), ('GraphConv', [256, 256]), ('Linear', [256, 3])]
+
+
+def test_hot_kernels_do_not_spill():
+    """Compile the two hot translation units with -Rpass-analysis=kernel-resource-usage and require ScratchSize == 0 for
+    every specialised kernel (a silent spill made k_wgrad_fast<4,8,2> 15x slower once).  The generic fallback k_wgrad is
+    exempt (cold path for odd shapes)."""
+    import subprocess
+    csrc = os.path.join(ROOT, 'g-meta_amd', 'csrc')
+    bad = []
+    for unit in ('gemm.hip', 'agg.hip'):
+        r = subprocess.run(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', os.path.join(csrc, unit), '-o', os.devnull,
+                            '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        name = None
+        for line in r.stderr.splitlines():
+            m = re.search(r'Function Name: (\S+)', line)
+            if m:
+                name = m.group(1)
+            m = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', line)
+            if m and int(m.group(1)) > 0 and name and not name.startswith('_Z7k_wgrad6'):
+                bad.append((name, int(m.group(1))))
+    assert not bad, 'kernels spilling to scratch: %s' % bad
