@@ -160,7 +160,7 @@ def main():
     # the GPU on two streams, which stretches every kernel; the kernel-alone duration is measured on extra steps with
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
-    if not a.serialize and a.roofline_steps > 0 and rank == 0:
+    if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         maml.serialize = 1
         step(0)
         agg_ms, agg_n, agg_bytes = 0.0, 0, 0
@@ -220,7 +220,7 @@ def main():
         }
         if extra:
             out['extra'] = {'note': 'flagged exact schedules (same accs/meta-gradient, golden-tested); not the headline value', **extra}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:           # rank 0 at N=1 only
             try:
                 out['cpu_baseline'] = cpu_baseline(data, cfg, config)
             except Exception as e:   # the baseline is a reported number, never the product path
