@@ -4,6 +4,7 @@
 // over the parent graph's nodes, so the node list comes out in ascending order for free and
 // local ids are prefix popcounts.  Edge lists are read from HBM coalesced (wave per frontier node).
 #include <algorithm>
+#include <stdlib.h>
 #include "gm_internal.h"
 
 #define EX_BLOCK 512
@@ -27,10 +28,21 @@ __device__ __forceinline__ int wave_sum(int v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ bool bit_test(const uint32_t* bm, int v) { return (bm[v >> 5] >> (v & 31)) & 1u; }
+// Bitmap words live in LDS (G = false) or, for parent graphs too large for it, in a per-workgroup slab of global memory
+// (G = true).  In the global case every word access is an agent-scope relaxed atomic: the bits are set with L2 atomics, and a
+// CU's L1 is not coherent with those, so plain loads could return stale words.
+template <bool G> __device__ __forceinline__ uint32_t wld(const uint32_t* p) {
+    if (G) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool G> __device__ __forceinline__ void wst(uint32_t* p, uint32_t v) {
+    if (G) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool G> __device__ __forceinline__ bool bit_test(const uint32_t* bm, int v) { return (wld<G>(&bm[v >> 5]) >> (v & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t* bm, int v) { atomicOr(&bm[v >> 5], 1u << (v & 31)); }
-__device__ __forceinline__ int bit_rank(const uint32_t* bm, const uint32_t* pref, int v) {
-    return (int)pref[v >> 5] + __popc(bm[v >> 5] & ((1u << (v & 31)) - 1u));
+template <bool G> __device__ __forceinline__ int bit_rank(const uint32_t* bm, const uint32_t* pref, int v) {
+    return (int)wld<G>(&pref[v >> 5]) + __popc(wld<G>(&bm[v >> 5]) & ((1u << (v & 31)) - 1u));
 }
 
 // Exclusive scan of part[0..EX_BLOCK) in LDS by wave 0; returns the total through *total (LDS).
@@ -54,15 +66,16 @@ __device__ __forceinline__ void scan_partials(int* part, int* total) {
 }
 
 // pref[w] = number of set bits in seen[0..w); returns the total.
+template <bool G>
 __device__ __forceinline__ int bitmap_prefix(const uint32_t* seen, uint32_t* pref, int W, int* part, int* total) {
     const int chunk = (W + EX_BLOCK - 1) / EX_BLOCK;
     const int w0 = threadIdx.x * chunk, w1 = min(W, w0 + chunk);
     int s = 0;
-    for (int w = w0; w < w1; ++w) s += __popc(seen[w]);
+    for (int w = w0; w < w1; ++w) s += __popc(wld<G>(&seen[w]));
     part[threadIdx.x] = s;
     scan_partials(part, total);
     int run = part[threadIdx.x];
-    for (int w = w0; w < w1; ++w) { pref[w] = run; run += __popc(seen[w]); }
+    for (int w = w0; w < w1; ++w) { wst<G>(&pref[w], (uint32_t)run); run += __popc(wld<G>(&seen[w])); }
     __syncthreads();
     return *total;
 }
@@ -80,14 +93,15 @@ __device__ __forceinline__ void wave_mark_preds(const ExStore& S, int64_t base, 
 }
 
 // Phase A: node set (BFS or given), sampling, sorted node list, induced in/out degrees.
+template <bool G>
 __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* seeds, int n_seeds, int h, int sample_n,
                                                     uint64_t rng_seed, int link, const int32_t* given, const int64_t* given_off,
                                                     int cap, int32_t* nodes_slab, int32_t* degi_slab, int32_t* dego_slab,
-                                                    int32_t* n_sub, int32_t* e_sub, int Wmax) {
+                                                    int32_t* n_sub, int32_t* e_sub, int Wmax, uint32_t* gbits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* seen = lds;
-    uint32_t* pref = lds + Wmax;              // doubles as the `expanded` bitmap during the BFS
-    int* part = (int*)(lds + 2 * Wmax);       // [EX_BLOCK]
+    uint32_t* seen = G ? gbits + (size_t)blockIdx.x * 2 * Wmax : lds;
+    uint32_t* pref = seen + Wmax;             // doubles as the `expanded` bitmap during the BFS
+    int* part = (int*)(G ? lds : lds + 2 * Wmax);       // [EX_BLOCK]
     uint32_t* hist = (uint32_t*)(part + EX_BLOCK);   // [256]
     int* sc = (int*)(hist + 256);             // scalars: 0 total, 1 kk, 2 prefix, 3 edge count in, 4 edge count out
     const int seed = blockIdx.x;
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
     const int W = (n + 31) >> 5;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
 
-    for (int w = tid; w < W; w += EX_BLOCK) { seen[w] = 0; pref[w] = 0; }
+    for (int w = tid; w < W; w += EX_BLOCK) { wst<G>(&seen[w], 0u); wst<G>(&pref[w], 0u); }
     if (tid < 8) sc[tid] = 0;
     __syncthreads();
     if (given) {
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         }
         // ---- count, and sample if above the threshold (strict '>' at sdp.py:312,337)
         int c = 0;
-        for (int w = tid; w < W; w += EX_BLOCK) c += __popc(seen[w]);
+        for (int w = tid; w < W; w += EX_BLOCK) c += __popc(wld<G>(&seen[w]));
         c = wave_sum(c);
         if (lane == 0) atomicAdd(&sc[0], c);
         __syncthreads();
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
                 __syncthreads();
                 const uint32_t prefix = (uint32_t)sc[2];
                 for (int w = tid; w < W; w += EX_BLOCK) {
-                    uint32_t bits = seen[w];
+                    uint32_t bits = wld<G>(&seen[w]);
                     while (bits) {
                         const int b = __ffs(bits) - 1; bits &= bits - 1;
                         const uint32_t key = lowbias32((uint32_t)(w * 32 + b) ^ salt);
@@ -183,12 +197,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
             }
             const uint32_t tau = (uint32_t)sc[2];
             for (int w = tid; w < W; w += EX_BLOCK) {
-                uint32_t bits = seen[w], keep = 0;
+                uint32_t bits = wld<G>(&seen[w]), keep = 0;
                 while (bits) {
                     const int b = __ffs(bits) - 1; bits &= bits - 1;
                     if (lowbias32((uint32_t)(w * 32 + b) ^ salt) <= tau) keep |= 1u << b;
                 }
-                seen[w] = keep;
+                wst<G>(&seen[w], keep);
             }
             __syncthreads();
             if (tid == 0) { bit_set(seen, ci); if (cj >= 0) bit_set(seen, cj); }   // np.unique(np.append(., centres))
@@ -196,12 +210,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         }
     }
     // ---- ascending node list + local-id prefix
-    const int ns = bitmap_prefix(seen, pref, W, part, &sc[0]);
+    const int ns = bitmap_prefix<G>(seen, pref, W, part, &sc[0]);
     if (ns > cap) { if (tid == 0) { n_sub[seed] = -ns; e_sub[seed] = 0; } return; }   // host reports the error
     int32_t* nodes = nodes_slab + (int64_t)seed * cap;
     for (int w = tid; w < W; w += EX_BLOCK) {
-        uint32_t bits = seen[w];
-        int r = pref[w];
+        uint32_t bits = wld<G>(&seen[w]);
+        int r = (int)wld<G>(&pref[w]);
         while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; nodes[r++] = w * 32 + b; }
     }
     __syncthreads();
@@ -210,8 +224,8 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
     for (int r = wave; r < ns; r += EX_WAVES) {
         const int v = nodes[r];
         int ci_ = 0, co_ = 0;
-        for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test(seen, S.in_idx[q]);
-        for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test(seen, S.out_idx[q]);
+        for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test<G>(seen, S.in_idx[q]);
+        for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test<G>(seen, S.out_idx[q]);
         ci_ = wave_sum(ci_); co_ = wave_sum(co_);
         if (lane == 0) { degi_slab[(int64_t)seed * cap + r] = ci_; dego_slab[(int64_t)seed * cap + r] = co_; }
         ein += ci_; eout += co_;
@@ -234,29 +248,31 @@ __device__ __forceinline__ void scan_degrees(const int32_t* deg, int ns, int32_t
 }
 
 // Ordered compaction of the neighbours of v that are inside the subgraph, remapped to batch rows.
+template <bool G>
 __device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t* idx, int64_t base, int v, const uint32_t* seen,
                                               const uint32_t* pref, int row0, int32_t* out, int pos, int lane) {
     const int64_t a = ptr[base + v], b = ptr[base + v + 1];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int64_t q = a; q < b; q += GM_WAVE) {
         int u = 0, hit = 0;
-        if (q + lane < b) { u = idx[q + lane]; hit = bit_test(seen, u); }
+        if (q + lane < b) { u = idx[q + lane]; hit = bit_test<G>(seen, u); }
         const unsigned long long m = __ballot(hit);
-        if (hit) out[pos + __popcll(m & lt)] = row0 + bit_rank(seen, pref, u);
+        if (hit) out[pos + __popcll(m & lt)] = row0 + bit_rank<G>(seen, pref, u);
         pos += __popcll(m);
     }
 }
 
 // Phase B: write the batched CSR (by destination and by source), parents, feature rows, norm, centres.
+template <bool G>
 __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* seeds, int n_seeds, int link, int cap,
                                                    const int32_t* nodes_slab, const int32_t* degi_slab, const int32_t* dego_slab,
                                                    const int32_t* sub_off, const int32_t* sub_eoff, int32_t* parent, int32_t* feat_row,
                                                    float* norm, int32_t* indptr, int32_t* indices, int32_t* indptr_t,
-                                                   int32_t* indices_t, int32_t* centre, int Wmax) {
+                                                   int32_t* indices_t, int32_t* centre, int Wmax, uint32_t* gbits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t* seen = lds;
-    uint32_t* pref = lds + Wmax;
-    int* part = (int*)(lds + 2 * Wmax);
+    uint32_t* seen = G ? gbits + (size_t)blockIdx.x * 2 * Wmax : lds;
+    uint32_t* pref = seen + Wmax;
+    int* part = (int*)(G ? lds : lds + 2 * Wmax);
     int* sc = part + EX_BLOCK;
     const int seed = blockIdx.x;
     if (seed >= n_seeds) return;
@@ -270,7 +286,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
     const int32_t* degi = degi_slab + (int64_t)seed * cap;
     const int32_t* dego = dego_slab + (int64_t)seed * cap;
 
-    for (int w = tid; w < W; w += EX_BLOCK) seen[w] = 0;
+    for (int w = tid; w < W; w += EX_BLOCK) wst<G>(&seen[w], 0u);
     __syncthreads();
     for (int r = tid; r < ns; r += EX_BLOCK) {
         const int v = nodes[r];
@@ -281,20 +297,20 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
         norm[row0 + r] = 1.0f / sqrtf((float)(d > 1 ? d : 1));          // in_degrees().clamp(min=1) ** -0.5 (learner.py:29)
     }
     __syncthreads();
-    bitmap_prefix(seen, pref, W, part, &sc[0]);
+    bitmap_prefix<G>(seen, pref, W, part, &sc[0]);
     scan_degrees(degi, ns, indptr + row0, e0, part, &sc[0]);
     scan_degrees(dego, ns, indptr_t + row0, e0, part, &sc[1]);
     if (seed == n_seeds - 1 && tid == 0) { indptr[row0 + ns] = e0 + sc[0]; indptr_t[row0 + ns] = e0 + sc[1]; }
     __syncthreads();
     if (tid == 0) {
         const int nc = link ? 2 : 1;
-        centre[seed * nc] = bit_rank(seen, pref, seeds[seed].i);
-        if (link) centre[seed * nc + 1] = bit_rank(seen, pref, seeds[seed].j);
+        centre[seed * nc] = bit_rank<G>(seen, pref, seeds[seed].i);
+        if (link) centre[seed * nc + 1] = bit_rank<G>(seen, pref, seeds[seed].j);
     }
     for (int r = wave; r < ns; r += EX_WAVES) {
         const int v = nodes[r];
-        wave_fill_row(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, indptr[row0 + r], lane);
-        wave_fill_row(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, indptr_t[row0 + r], lane);
+        wave_fill_row<G>(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, indptr[row0 + r], lane);
+        wave_fill_row<G>(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, indptr_t[row0 + r], lane);
     }
 }
 
@@ -489,15 +505,17 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     }
     if (!given) cap = std::min<int64_t>(store->max_nodes, (int64_t)sample_nodes + 2);
     const int Wmax = (int)((store->max_nodes + 31) >> 5);
-    const size_t lds_a = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 256 + 16);
-    GM_REQUIRE(lds_a <= 160 * 1024, GM_ERANGE,
-               "extract: parent graph with %lld nodes needs %zu B of LDS bitmap (> 160 KiB); global-bitmap path not implemented",
-               (long long)store->max_nodes, lds_a);
+    size_t lds_a = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 256 + 16);
+    static int force_global = -1;
+    if (force_global < 0) { const char* ev = getenv("GM_EXTRACT_GLOBAL_BITMAP"); force_global = ev ? atoi(ev) : 0; }
+    // parent graphs beyond ~650k nodes do not fit the LDS bitmap pair: fall back to a per-workgroup slab in HBM
+    const bool gpath = force_global || lds_a > 160 * 1024;
+    if (gpath) lds_a = sizeof(uint32_t) * (EX_BLOCK + 256 + 16);
     hipStream_t st = (hipStream_t)stream;
     static bool attr_set = false;
     if (!attr_set) {
-        GM_HIP(hipFuncSetAttribute((const void*)k_nodes, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GM_HIP(hipFuncSetAttribute((const void*)k_fill, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GM_HIP(hipFuncSetAttribute((const void*)k_nodes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GM_HIP(hipFuncSetAttribute((const void*)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx};
@@ -505,9 +523,11 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     gm_seed_t* d_seeds = nullptr; int32_t *d_nodes = nullptr, *d_degi = nullptr, *d_dego = nullptr, *d_nsub = nullptr, *d_esub = nullptr;
     int32_t* d_given = nullptr; int64_t* d_given_off = nullptr, *dummy = nullptr; (void)dummy;
     int32_t* d_eoff = nullptr;
+    uint32_t* d_gbits = nullptr;
     gm_batch* b = new gm_batch();
     int rc = GM_OK;
     auto cleanup = [&]() {
+        gm_dev_free(d_gbits, st);
         gm_dev_free(d_seeds, st); gm_dev_free(d_nodes, st); gm_dev_free(d_degi, st); gm_dev_free(d_dego, st);
         gm_dev_free(d_nsub, st); gm_dev_free(d_esub, st); gm_dev_free(d_given, st); gm_dev_free(d_given_off, st); gm_dev_free(d_eoff, st);
     };
@@ -524,8 +544,14 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
         EX_HIP(hipMemcpyAsync(d_given, nodes_flat, sizeof(int32_t) * tot, hipMemcpyHostToDevice, st));
         EX_HIP(hipMemcpyAsync(d_given_off, nodes_off, sizeof(int64_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(k_nodes, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
-                       d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax);
+    if (gpath) {
+        EX_TRY(gm_alloc(&d_gbits, (size_t)n_seeds * 2 * Wmax, st));
+        hipLaunchKernelGGL(k_nodes<true>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
+                           d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, d_gbits);
+    } else {
+        hipLaunchKernelGGL(k_nodes<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
+                           d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, (uint32_t*)nullptr);
+    }
     EX_HIP(hipGetLastError());
     std::vector<int32_t> nsub(n_seeds), esub(n_seeds);
     EX_HIP(hipMemcpyAsync(nsub.data(), d_nsub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
@@ -555,10 +581,16 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     EX_TRY(upload_small(b, st));
     EX_TRY(gm_alloc(&d_eoff, n_seeds + 1, st));
     EX_HIP(hipMemcpyAsync(d_eoff, eoff.data(), sizeof(int32_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
-    const size_t lds_b = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 16);
-    hipLaunchKernelGGL(k_fill, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
-                       b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t,
-                       b->d_indices_t, b->d_centre, Wmax);
+    if (gpath) {
+        hipLaunchKernelGGL(k_fill<true>, dim3(n_seeds), dim3(EX_BLOCK), sizeof(uint32_t) * (EX_BLOCK + 16), st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap,
+                           d_nodes, d_degi, d_dego, b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices,
+                           b->d_indptr_t, b->d_indices_t, b->d_centre, Wmax, d_gbits);
+    } else {
+        const size_t lds_b = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 16);
+        hipLaunchKernelGGL(k_fill<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
+                           b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t,
+                           b->d_indices_t, b->d_centre, Wmax, (uint32_t*)nullptr);
+    }
     EX_HIP(hipGetLastError());
     EX_HIP(hipStreamSynchronize(st));   // eoff (host vector) must outlive the async copy; also surfaces kernel faults here
     EX_TRY(gm_batch_finalize(b, st));

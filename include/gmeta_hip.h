@@ -26,7 +26,7 @@ extern "C" {
 #define GM_EINVAL (-1)  /* bad argument (also: update_step < 2, unequal class counts)      */
 #define GM_ENOMEM (-2)  /* HBM / workspace too small                                      */
 #define GM_EHIP (-3)    /* a HIP runtime call failed                                      */
-#define GM_ERANGE (-4)  /* size outside what the kernels support (e.g. graph > LDS bitmap) */
+#define GM_ERANGE (-4)  /* size outside what the kernels support (e.g. a batch above 2^31 rows) */
 #define GM_MAX_GCN 4
 
 typedef struct gm_store gm_store_t; /* parent graphs (in/out CSR) + node features, resident in HBM */
