@@ -114,3 +114,43 @@ def test_meta_step_matches_oracle(kind):
         o = orc.finetune(c['og'], c['feats'], c['ospt'][t], c['oqry'][t], ys[t], yq[t], theta1, c['config'], c['args'].k_spt,
                          c['args'].update_lr, 3)
         np.testing.assert_allclose(ft[t], o, atol=1e-6)
+
+
+def test_dataloader_getitem_path_equals_batched_extraction():
+    """The reference's own loop shape (train.py:96-108): DataLoader -> Subgraphs.__getitem__ per task -> collate ->
+    Meta.forward (which dgl.batch-es the per-task handles with gm_batch_concat) must give bit-identical results to the
+    batched get_batch fast path, and the 10-tuple must have the reference's slot types."""
+    import random
+    import gmeta_amd
+    from gmeta_amd import synth
+    from torch.utils.data import DataLoader
+    rng = np.random.default_rng(9)
+    np.random.seed(9); random.seed(9); torch.manual_seed(9)
+    graphs, feats, info, tabs = _tissue(rng, n_graphs=3, n=400, F0=16)
+    args = argparse.Namespace(update_lr=0.05, meta_lr=5e-3, n_way=2, k_spt=3, k_qry=6, task_num=3, update_step=3, update_step_test=3,
+                              method='G-Meta', sample_nodes=50, link_pred_mode='False', task_setup='Shared', h=2)
+    store = gmeta_amd.GraphStore(graphs, feats)
+    db = gmeta_amd.Subgraphs(None, 'train', info, n_way=2, k_shot=3, k_query=6, batchsz=3, args=args, adjs=store, h=2, tables=tabs, verbose=False)
+    config = synth.make_config(16, 32, 2, 2)
+    batch_dl = next(iter(DataLoader(db, 3, shuffle=False, collate_fn=gmeta_amd.collate)))
+    x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry = batch_dl
+    assert len(batch_dl) == 10 and all(len(s) == 3 for s in batch_dl)
+    assert isinstance(x_spt[0], gmeta_amd.SubgraphBatch) and x_spt[0].batch_num_nodes == [len(n) for n in n_spt[0]]
+    assert y_spt[0].dtype == torch.int64 and c_spt[0].dtype == torch.int64 and isinstance(g_spt[0], list)
+    par = x_spt[0].parent(); off = x_spt[0].sub_off
+    for k in range(len(n_spt[0])):                                        # slot 6 == list(sub.parent_nid) per subgraph (sdp.py:317)
+        ids = np.asarray(n_spt[0][k])
+        assert np.array_equal(ids, par[off[k]:off[k + 1]])
+        assert ids[int(c_spt[0][k])] == int(db._task_names(0)[0][k].split('_')[1])   # centre index points at the seed node
+    batch_fast = db.get_batch([0, 1, 2])
+
+    def run(b):
+        torch.manual_seed(4)
+        m = gmeta_amd.Meta(args, config).to('cuda')
+        g = {}
+        orig = m.meta_optim.step
+        m.meta_optim.step = lambda *a, **k: (g.setdefault('g', torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).clone()), orig(*a, **k))[1]
+        return m(*b, feats), g['g']
+    a1, g1 = run(batch_dl)
+    a2, g2 = run(batch_fast)
+    assert np.array_equal(a1, a2) and torch.equal(g1, g2)
