@@ -76,6 +76,7 @@ def main():
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--n_batches', type=int, default=2, help='distinct pre-extracted meta-batches cycled through')
     ap.add_argument('--sparse_bwd', type=int, default=0, help='1: time the flagged exact row-sparse backward schedule instead of the default dense one')
+    ap.add_argument('--cone', type=int, default=0, help='1: time the flagged receptive-field schedule (layer l only on the rows that reach a centre)')
     ap.add_argument('--serialize', type=int, default=0, help='1: run the timed region on one stream (what the rocprofv3 per-kernel summaries use)')
     ap.add_argument('--extra_steps', type=int, default=3, help='steps per flagged exact schedule reported under "extra" (N=1 only; 0 = skip)')
     ap.add_argument('--roofline_steps', type=int, default=2, help='extra serialised steps after the timed region for the per-kernel roofline')
@@ -95,7 +96,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local))
 
-    over = {'hoist_z1': a.hoist_z1, 'serialize': a.serialize, 'sparse_bwd': a.sparse_bwd}
+    over = {'hoist_z1': a.hoist_z1, 'serialize': a.serialize, 'sparse_bwd': a.sparse_bwd, 'cone': a.cone}
     if a.task_num:
         over['task_num'] = a.task_num
     args, cfg = synth.make_args(a.config, **over)
@@ -173,8 +174,9 @@ def main():
     # ---- secondary numbers: the flagged schedules that produce identical results without the structural zeros /
     # loop-invariant recomputation (never the headline `value`)
     extra = {}
-    if world == 1 and a.extra_steps > 0 and not (a.sparse_bwd or a.hoist_z1 or a.serialize):
-        for name, kw in (('sparse_bwd', dict(sparse_bwd=1)), ('sparse_bwd+hoist_z1', dict(sparse_bwd=1, hoist_z1=1))):
+    if world == 1 and a.extra_steps > 0 and not (a.sparse_bwd or a.hoist_z1 or a.serialize or a.cone):
+        for name, kw in (('sparse_bwd', dict(sparse_bwd=1)), ('sparse_bwd+hoist_z1', dict(sparse_bwd=1, hoist_z1=1)),
+                         ('cone', dict(sparse_bwd=0, hoist_z1=0, cone=1)), ('cone+hoist_z1', dict(cone=1, hoist_z1=1))):
             for k_, v_ in kw.items():
                 setattr(maml, k_, v_)
             step(0)
@@ -184,7 +186,7 @@ def main():
             torch.cuda.synchronize()
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
-        maml.sparse_bwd = 0; maml.hoist_z1 = 0
+        maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
 
     if rank == 0:
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
@@ -203,7 +205,8 @@ def main():
                                    '%d-way %d-shot %d-qry, task_num=%d, update_step=%d, sample_nodes=%d; subgraphs pre-extracted in HBM'
                                    % (cfg['n'], cfg['m'], cfg['F0'], cfg['h'], cfg['hidden'], cfg['n_way'], cfg['k_spt'], cfg['k_qry'], T,
                                       cfg['update_step'], cfg['sample_nodes']),
-                       'schedule': ('hoist_z1 ' if a.hoist_z1 else '') + ('sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
+                       'schedule': ('hoist_z1 ' if a.hoist_z1 else '') + ('cone (receptive-field rows only, forward and backward)' if a.cone else
+                                    'sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
                                     'full (reference-equivalent: every forward/backward dense over all subgraph rows)'),
                        'streams': 1 if a.serialize else 2,
                        'parallelism': 'tasks sharded over %d rank(s), one all-reduce of the meta-gradient per step' % world,

@@ -20,7 +20,7 @@ class Model(C.Structure):
 
 class HParams(C.Structure):
     _fields_ = [('update_lr', C.c_float), ('update_step', C.c_int32), ('k_spt', C.c_int32), ('need_meta_grad', C.c_int32),
-                ('hoist_z1', C.c_int32), ('serialize', C.c_int32), ('sparse_bwd', C.c_int32)]
+                ('hoist_z1', C.c_int32), ('serialize', C.c_int32), ('sparse_bwd', C.c_int32), ('cone', C.c_int32)]
 
 
 vp, i32, i64, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64
@@ -33,6 +33,9 @@ PROTOTYPES = {
     'gm_batch_from_nodes': (C.c_int, [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp]),
     'gm_batch_concat': (C.c_int, [vp, i32, vp, vp]),
     'gm_batch_destroy': (None, [vp]),
+    'gm_batch_prepare_cone': (C.c_int, [vp, i32, vp]),
+    'gm_batch_cone_dims': (C.c_int, [vp, i32, vp, vp, vp]),
+    'gm_batch_cone_read': (C.c_int, [vp, i32, i32, i32, vp, i64]),
     'gm_batch_dims': (C.c_int, [vp, vp, vp, vp, vp, vp]),
     'gm_batch_read': (C.c_int, [vp, i32, vp, i64]),
     'gm_batch_device_ptr': (C.c_int, [vp, i32, vp]),

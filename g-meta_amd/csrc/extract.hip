@@ -357,6 +357,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
     gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
     gm_dev_free(b->d_e1_chunks, s); gm_dev_free(b->d_e1_set_chunk_off, s);
+    for (int l = 0; l <= GM_MAX_GCN; ++l) { gm_cone_free(b->cone[l], s); b->cone[l] = nullptr; }
 }
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
@@ -699,6 +700,15 @@ extern "C" int gm_batch_device_ptr(const gm_batch_t* b, int32_t field, void** dp
     GM_REQUIRE(b && dptr, GM_EINVAL, "batch_device_ptr: NULL argument");
     int64_t bytes;
     return field_ptr(b, field, dptr, &bytes);
+}
+
+int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, float* out, hipStream_t st) {
+    if (n <= 0) return GM_OK;
+    const int F = store->feat_dim;
+    const int blocks = (int)std::min<int64_t>(256 * 8, (n * F + 255) / 256);
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, store->d_feat, feat_row, out, n, F);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
 }
 
 extern "C" int gm_gather_features(const gm_batch_t* b, float* x_out, void* stream) {

@@ -46,6 +46,28 @@ struct gm_store {
     float* d_feat = nullptr;         // [total_nodes, feat_dim]
 };
 
+// Receptive-field tables (cone.hip): level l = rows whose layer-l activation reaches a centre.
+struct gm_cone_level {
+    int32_t n = 0, nnz = 0;            // rows of this level; edges from level l-1 into it
+    int32_t* d_row = nullptr;          // [n]  batch row (ascending; level L: centre order)
+    float* d_norm = nullptr;           // [n]  norm[row]
+    int32_t* d_feat_row = nullptr;     // level 0 only: [n] feature row in the store
+    int32_t* d_set_off = nullptr;      // [sets+1] compact row range of every set
+    std::vector<int32_t> h_set_off;
+    int32_t* d_tiles = nullptr; int32_t n_tiles = 0;                 // GEMM row tiles over the compact rows
+    int32_t* d_chunks = nullptr; int32_t* d_set_chunk_off = nullptr; int32_t n_chunks = 0;
+    int32_t* d_indptr = nullptr; int32_t* d_indices = nullptr;       // [n+1], [nnz]: in-edges, sources = compact ids of level l-1
+    int32_t* d_indptr_t = nullptr; int32_t* d_indices_t = nullptr;   // [n_{l-1}+1], [nnz]: the same edges by source, destinations = compact ids of level l
+    int32_t* d_heavy[2] = {nullptr, nullptr}; int32_t n_heavy[2] = {0, 0};
+};
+struct gm_cone {
+    int L = 0; bool ok = false; int heavy_deg = 64;
+    gm_cone_level lv[GM_MAX_GCN + 1];
+};
+struct gm_batch;
+int gm_batch_cone(const gm_batch* b, int L, hipStream_t s, const gm_cone** out);   // built on first use, cached in the batch
+void gm_cone_free(gm_cone* c, hipStream_t s);
+
 struct gm_batch {
     const gm_store* store = nullptr;
     int64_t rows = 0, edges = 0;
@@ -86,6 +108,7 @@ struct gm_batch {
     int32_t* d_c_tiles = nullptr; int32_t n_c_tiles = 0;          // GEMM tiles over centre rows (per set)
     int32_t* d_c_chunks = nullptr; int32_t* d_c_set_chunk_off = nullptr; int32_t n_c_chunks = 0;
     int32_t* d_e1_chunks = nullptr; int32_t* d_e1_set_chunk_off = nullptr; int32_t n_e1_chunks = 0;
+    mutable gm_cone* cone[GM_MAX_GCN + 1] = {};     // receptive-field tables per number of GCN layers (gm_hparams_t.cone)
     hipStream_t stream = nullptr;      // stream the arrays were produced on
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);

@@ -20,9 +20,12 @@ struct HeadK {
     const float* H; int64_t ldh; int Hd;            // last GCN activation [rows, Hd]
     const int32_t* sub_off; const int32_t* centre; int nc; const int32_t* sub_set; const int32_t* set_sub_off;
     const float* params; int64_t pstride; int64_t wl_off, bl_off; int hc, C; int subs;
+    int compact;                                    // 1: H holds only the centre rows, [subs*nc, Hd] in centre order (cone schedule)
 };
 
-__device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) { return (int64_t)k.sub_off[s] + k.centre[s * k.nc + which]; }
+__device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) {
+    return k.compact ? (int64_t)s * k.nc + which : (int64_t)k.sub_off[s] + k.centre[s * k.nc + which];
+}
 
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
 __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
@@ -194,20 +197,12 @@ __global__ void k_sgd(float* dst, const float* src, int64_t src_stride, const fl
     }
 }
 
-__global__ void k_colsum_partial(const float* G, int64_t ldg, int N, const int32_t* chunks, float* partial, int64_t pstride, int64_t poff) {
-    const int chunk = blockIdx.x;
-    const int row0 = chunks[chunk * 3 + 1], nrows = chunks[chunk * 3 + 2];
+// db[set, n] = sum over the set's rows [set_off[set], set_off[set+1]) of G[row, n]   (cone schedule, multiply-first layers)
+__global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t* set_off, float* db, int64_t db_stride) {
+    const int set = blockIdx.x, r0 = set_off[set], r1 = set_off[set + 1];
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
-        for (int r = 0; r < nrows; ++r) s += G[(int64_t)(row0 + r) * ldg + n];
-        partial[(int64_t)chunk * pstride + poff + n] = s;
-    }
-}
-__global__ void k_colsum_reduce(const float* partial, int64_t pstride, int64_t poff, const int32_t* set_chunk_off, int N, float* db, int64_t db_stride) {
-    const int set = blockIdx.x;
-    for (int n = threadIdx.x; n < N; n += blockDim.x) {
-        float s = 0.f;
-        for (int c = set_chunk_off[set]; c < set_chunk_off[set + 1]; ++c) s += partial[(int64_t)c * pstride + poff + n];
+        for (int r = r0; r < r1; ++r) s += G[(int64_t)r * ldg + n];
         db[(int64_t)set * db_stride + n] = s;
     }
 }
@@ -245,11 +240,31 @@ struct GcnCtx {
     float* cG2; float* cT2; float* cG1; float* partial_c;      // compact matrices of the row-sparse backward
     const float* x0_user; const int32_t* centre; int z1_valid;
     int zw[GM_MAX_GCN];
+    const gm_cone* cone;       // non-NULL: receptive-field schedule, every buffer is compact (gm_hparams_t.cone)
 };
 
 static void gcn_carve(GcnCtx& c, Carver& cv) {
     const gm_layout& L = c.L; const int64_t rows = c.b->rows;
     int maxd = 0; int64_t maxkn = 0;
+    if (c.cone) {
+        const gm_cone* cn = c.cone;
+        int64_t maxn = 1; int maxc = 1;
+        for (int l = 0; l <= L.n_gcn; ++l) { maxn = std::max<int64_t>(maxn, cn->lv[l].n); maxc = std::max(maxc, cn->lv[l].n_chunks); }
+        for (int l = 0; l < L.n_gcn; ++l) {
+            const int fi = L.dims[l], fo = L.dims[l + 1];
+            c.zw[l] = fi > fo ? fo : fi;
+            c.Z[l] = cv.take<float>((int64_t)(fi > fo ? cn->lv[l].n : cn->lv[l + 1].n) * c.zw[l]);   // multiply-first: Y lives on the source level
+            c.H[l] = cv.take<float>((int64_t)cn->lv[l + 1].n * fo);
+            maxd = std::max(maxd, std::max(fi, fo));
+            maxkn = std::max<int64_t>(maxkn, (int64_t)(fi + 1) * fo);
+        }
+        c.X0 = (L.dims[0] > L.dims[1]) ? cv.take<float>((int64_t)cn->lv[0].n * L.dims[0]) : nullptr;
+        c.bufA = cv.take<float>(maxn * maxd);
+        c.bufB = cv.take<float>(maxn * maxd);
+        c.partial = cv.take<float>((int64_t)maxc * maxkn);
+        c.cG2 = c.cT2 = c.cG1 = c.partial_c = nullptr;
+        return;
+    }
     for (int l = 0; l < L.n_gcn; ++l) {
         const int fi = L.dims[l], fo = L.dims[l + 1];
         c.zw[l] = fi > fo ? fo : fi;
@@ -281,11 +296,15 @@ static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
     k.H = c.H[L.n_gcn - 1]; k.ldh = L.dims[L.n_gcn]; k.Hd = L.dims[L.n_gcn];
     k.sub_off = b->d_sub_off; k.centre = c.centre ? c.centre : b->d_centre; k.nc = b->centres; k.sub_set = b->d_sub_set;
     k.set_sub_off = b->d_set_sub_off; k.params = params; k.pstride = pstride; k.wl_off = L.wl_off; k.bl_off = L.bl_off;
-    k.hc = L.hc; k.C = L.n_out; k.subs = b->subs;
+    k.hc = L.hc; k.C = L.n_out; k.subs = b->subs; k.compact = c.cone ? 1 : 0;
     return k;
 }
 
+static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1);
+static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st);
+
 static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1) {
+    if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     GM_REQUIRE(L.dims[0] == b->store->feat_dim || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
@@ -331,6 +350,7 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
 static bool sparse_bwd_ok(const gm_layout& L);
 
 static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int sparse = 0) {
+    if (c.cone) return cone_backward(c, params, pstride, dlogits, dparams, dstride, st);
     if (sparse && sparse_bwd_ok(c.L)) return gcn_backward_sparse(c, params, pstride, dlogits, dparams, dstride, st);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     const int Lg = L.n_gcn;
@@ -415,6 +435,104 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
     w1.chunks = b->d_e1_chunks; w1.n_chunks = b->n_e1_chunks; w1.set_chunk_off = b->d_e1_set_chunk_off; w1.sets = b->sets; w1.partial = c.partial_c;
     w1.dW = dparams + L.w_off[0]; w1.dw_stride = dstride; w1.db = dparams + L.b_off[0]; w1.db_stride = dstride;
     GM_TRY(gm_launch_wgrad(w1, st));
+    return GM_OK;
+}
+
+
+// ================================================================================ receptive-field ("cone") schedule
+// The same layer formulas as gcn_forward/gcn_backward, evaluated only on the rows that can reach a centre
+// (cone.hip): layer l maps level l (sources) to level l+1 (destinations); all matrices are compact.
+int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, float* out, hipStream_t st);
+
+static gm_agg_args cone_agg(const gm_cone* cn, const gm_cone_level& up, int transposed) {
+    gm_agg_args a{};
+    a.indptr = transposed ? up.d_indptr_t : up.d_indptr; a.indices = transposed ? up.d_indices_t : up.d_indices;
+    a.heavy = up.d_heavy[transposed]; a.n_heavy = up.n_heavy[transposed]; a.heavy_deg = cn->heavy_deg;
+    return a;
+}
+
+static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b; const gm_cone* cn = c.cone;
+    GM_REQUIRE(L.dims[0] == b->store->feat_dim, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
+    GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
+    GM_REQUIRE(!c.x0_user && !c.centre, GM_EINVAL, "forward: the cone schedule reads features and centres from the batch");
+    const float* xin = nullptr;
+    for (int l = 0; l < L.n_gcn; ++l) {
+        const gm_cone_level& lo = cn->lv[l]; const gm_cone_level& up = cn->lv[l + 1];
+        const int fi = L.dims[l], fo = L.dims[l + 1];
+        if (fi > fo) {                      // multiply on the source level, then aggregate into the destination level
+            const float* A = xin;
+            if (l == 0) { GM_TRY(gm_gather_rows(b->store, lo.d_feat_row, lo.n, c.X0, st)); A = c.X0; }
+            gm_gemm_args g{}; g.A = A; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
+            g.row_scale = lo.d_norm; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles;
+            GM_TRY(gm_launch_gemm_nn(g, st));
+            gm_agg_args a = cone_agg(cn, up, 0);
+            a.x = c.Z[l]; a.ldx = fo; a.s_out = up.d_norm; a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = up.d_set_off; a.n_sets = b->sets;
+            a.relu = 1; a.out = c.H[l]; a.rows = up.n; a.width = fo;
+            GM_TRY(gm_launch_aggregate(a, st));
+        } else {
+            if (!(l == 0 && reuse_z1 && c.z1_valid)) {
+                gm_agg_args a = cone_agg(cn, up, 0);
+                a.s_in = lo.d_norm; a.out = c.Z[l]; a.rows = up.n; a.width = fi; a.ldx = fi;
+                if (l == 0) { a.x = b->store->d_feat; a.x_row = lo.d_feat_row; } else a.x = xin;
+                GM_TRY(gm_launch_aggregate(a, st));
+                if (l == 0) c.z1_valid = 1;
+            }
+            gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
+            g.row_scale = up.d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles;
+            GM_TRY(gm_launch_gemm_nn(g, st));
+        }
+        xin = c.H[l];
+    }
+    HeadK k = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_fwd, dim3((b->subs + 3) / 4), dim3(256), 0, st, k, logits);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+    const gm_layout& L = c.L; const gm_batch* b = c.b; const gm_cone* cn = c.cone;
+    const int Lg = L.n_gcn;
+    float* dQ = c.bufA; float* T = c.bufB;
+    HeadK k = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, dQ);   // dQ_L on the centre rows
+    GM_HIP(hipGetLastError());
+    for (int l = Lg - 1; l >= 0; --l) {
+        const gm_cone_level& lo = cn->lv[l]; const gm_cone_level& up = cn->lv[l + 1];
+        const int fi = L.dims[l], fo = L.dims[l + 1];
+        const float* maskprev = l > 0 ? c.H[l - 1] : nullptr;
+        gm_wgrad_args w{}; w.sets = b->sets; w.partial = c.partial; w.K = fi; w.N = fo;
+        w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
+        if (fi > fo) {
+            // dY = A^T (norm * dQ) on the source level ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
+            gm_agg_args a = cone_agg(cn, up, 1);
+            a.x = dQ; a.ldx = fo; a.s_in = up.d_norm; a.out = T; a.rows = lo.n; a.width = fo;
+            GM_TRY(gm_launch_aggregate(a, st));
+            w.A = l > 0 ? c.H[l - 1] : c.X0; w.lda = fi; w.a_scale = lo.d_norm; w.G = T; w.ldg = fo; w.db = nullptr;
+            w.chunks = lo.d_chunks; w.n_chunks = lo.n_chunks; w.set_chunk_off = lo.d_set_chunk_off;
+            GM_TRY(gm_launch_wgrad(w, st));
+            hipLaunchKernelGGL(k_colsum_rows, dim3(b->sets), dim3(256), 0, st, dQ, (int64_t)fo, fo, up.d_set_off, dparams + L.b_off[l], dstride);
+            GM_HIP(hipGetLastError());
+            if (l > 0) {
+                gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
+                g.row_scale = lo.d_norm; g.mask_h = maskprev; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles;
+                GM_TRY(gm_launch_gemm_nn(g, st));
+            }
+        } else {
+            // dW = (norm*Z)^T dQ ; db = colsum(dQ) ; dZ = norm * (dQ W^T) ; dQ_prev = relu'(H_prev) * norm * A^T dZ
+            w.A = c.Z[l]; w.lda = fi; w.a_scale = up.d_norm; w.G = dQ; w.ldg = fo;
+            w.chunks = up.d_chunks; w.n_chunks = up.n_chunks; w.set_chunk_off = up.d_set_chunk_off;
+            GM_TRY(gm_launch_wgrad(w, st));
+            if (l > 0) {
+                gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
+                g.row_scale = up.d_norm; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles;
+                GM_TRY(gm_launch_gemm_nn(g, st));
+                gm_agg_args a = cone_agg(cn, up, 1);
+                a.x = T; a.ldx = fi; a.s_out = lo.d_norm; a.mask_h = maskprev; a.out = dQ; a.rows = lo.n; a.width = fi;
+                GM_TRY(gm_launch_aggregate(a, st));
+            }
+        }
+    }
     return GM_OK;
 }
 
@@ -555,6 +673,12 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     GM_TRY(gm_make_layout(m, &p.L));
     p.T = spt->sets; p.K = hp->update_step; p.Pp = (p.L.P + 63) / 64 * 64;
     p.S = GcnCtx{}; p.Q = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.S.L = p.L; p.Q.L = p.L;
+    if (hp->cone) {                      // receptive-field tables: built on first use, cached in the batch
+        const gm_cone *cs = nullptr, *cq = nullptr;
+        GM_TRY(gm_batch_cone(spt, p.L.n_gcn, spt->stream, &cs));
+        GM_TRY(gm_batch_cone(qry, p.L.n_gcn, qry->stream, &cq));
+        if (cs->ok && cq->ok) { p.S.cone = cs; p.Q.cone = cq; }      // else: a self pair among the centres -> dense schedule
+    }
     Carver cv(ws, ws_bytes);
     const int64_t TP = (int64_t)p.T * p.Pp; const int C = p.L.n_out; const int K1 = p.K + 1;
     p.TP = TP; p.proto_sz = (int64_t)p.T * 256 * C;

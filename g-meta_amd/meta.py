@@ -34,6 +34,7 @@ class Meta(nn.Module):
         self.hoist_z1 = int(getattr(args, 'hoist_z1', 0))
         self.serialize = int(getattr(args, 'serialize', 0))     # 1: one stream (per-kernel timing)
         self.sparse_bwd = int(getattr(args, 'sparse_bwd', 0))   # 1: exact row-sparse backward (flagged schedule)
+        self.cone = int(getattr(args, 'cone', 0))               # 1: receptive-field schedule, forward and backward (flagged)
         self.last_stats = {}
         self._ws = None
         self._keep = None
@@ -114,7 +115,8 @@ class Meta(nn.Module):
         if len(ys) != S.subs or len(yq) != Q.subs:
             raise ValueError('label count does not match the number of subgraphs')
         model = self.net.model
-        hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd))
+        hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd),
+                          int(self.cone))
         P = int(lib.gm_model_param_count(C.byref(model)))
         n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
         ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))

@@ -62,7 +62,7 @@ def make_args(cfg, **over):
     return argparse.Namespace(update_lr=c['update_lr'], meta_lr=c['meta_lr'], n_way=c['n_way'], k_spt=c['k_spt'], k_qry=c['k_qry'],
                               task_num=c['task_num'], update_step=c['update_step'], update_step_test=c['update_step_test'],
                               method='G-Meta', sample_nodes=c['sample_nodes'], link_pred_mode='False', task_setup='Disjoint',
-                              h=c['h'], hidden_dim=c['hidden'], hoist_z1=c.get('hoist_z1', 0), serialize=c.get('serialize', 0), sparse_bwd=c.get('sparse_bwd', 0)), c
+                              h=c['h'], hidden_dim=c['hidden'], hoist_z1=c.get('hoist_z1', 0), serialize=c.get('serialize', 0), sparse_bwd=c.get('sparse_bwd', 0), cone=c.get('cone', 0)), c
 
 
 def make_config(F0, hidden, h, n_out, link=False):

@@ -59,6 +59,12 @@ typedef struct gm_hparams {
                               1 = exact row-sparse backward: only the head touches the last layer, so dQ_L is non-zero
                               at centre rows only and dQ_{L-1} only along in-edges of centres -- same sums without
                               the structural zeros (models with <= 2 aggregate-first GCN layers; else falls back) */
+    int32_t cone;          /* 0 = every layer is evaluated on every subgraph row, as DGL does (reference-equivalent
+                              schedule, default); 1 = receptive-field schedule: only the centre rows of the last GCN layer
+                              reach the head (learner.py:159-170), so layer l is evaluated only on the rows that are
+                              (L-l) in-hops upstream of a centre, forward and backward -- the same sums for every row
+                              that matters, nothing for the rows that cannot influence logits or gradients.
+                              Supersedes sparse_bwd; falls back to the dense schedule if a pair has i == j */
 } gm_hparams_t;
 
 const char* gm_last_error(void);
@@ -92,6 +98,14 @@ int gm_batch_from_nodes(const gm_store_t* store, const gm_seed_t* seeds, int32_t
                         const int64_t* nodes_off, int32_t link_pred, void* stream, gm_batch_t** out);
 /* dgl.batch over already-built batches (sets are appended in order).  Inputs stay valid. */
 int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, void* stream, gm_batch_t** out);
+/* Receptive-field tables for gm_hparams_t.cone with an n_gcn-layer model (built on `stream`, cached in the
+ * batch; gm_meta_ws_bytes/gm_meta_step build them on first use otherwise).  level_rows/level_edges
+ * (host int64[n_gcn+1]): rows of level l and edges from level l-1 into level l; *ok = 0 when the batch
+ * cannot use the schedule.  gm_batch_cone_read copies one table to the host (tests): what = 0 rows,
+ * 1 indptr, 2 indices, 3 indptr_t, 4 indices_t, 5 set offsets. */
+int gm_batch_prepare_cone(const gm_batch_t* b, int32_t n_gcn, void* stream);
+int gm_batch_cone_dims(const gm_batch_t* b, int32_t n_gcn, int32_t* ok, int64_t* level_rows, int64_t* level_edges);
+int gm_batch_cone_read(const gm_batch_t* b, int32_t n_gcn, int32_t level, int32_t what, void* host, int64_t host_bytes);
 void gm_batch_destroy(gm_batch_t* b);
 
 /* Sizes: rows = total nodes, edges = total induced edges, subs = subgraphs, sets = task sets,

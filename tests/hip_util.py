@@ -39,7 +39,7 @@ def fixture_meta(fx):
     return m
 
 
-def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0):
+def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0, cone=0):
     """Meta.forward on the fixture's meta-batch.  Returns accs, the meta-gradient that reached Adam,
     the updated weights and the node lists."""
     store = make_store(fx)
@@ -47,6 +47,7 @@ def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0):
     m = fixture_meta(fx)
     m.hoist_z1 = hoist
     m.sparse_bwd = sparse_bwd
+    m.cone = cone
     grads = {}
     orig = m.meta_optim.step
 

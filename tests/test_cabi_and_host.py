@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert _lib.lib().gm_version() >= 100
     m = _lib.make_model([('GraphConv', [128, 256]), ('GraphConv', [256, 256]), ('Linear', [256, 3])])
     assert _lib.lib().gm_model_param_count(ctypes.byref(m)) == 99587        # == the reference's printed count (test.ipynb)
-    assert _lib.HParams._fields_[-1][0] == 'sparse_bwd' and ctypes.sizeof(_lib.HParams) == 28
+    assert _lib.HParams._fields_[-1][0] == 'cone' and ctypes.sizeof(_lib.HParams) == 32
     assert ctypes.sizeof(_lib.Model) == 4 * (1 + 5 + 2) and ctypes.sizeof(_lib.Seed) == 12
 
 

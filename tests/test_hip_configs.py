@@ -87,12 +87,14 @@ def test_sampled_extraction_bit_exact(kind):
     assert sizes.max() <= 62 and (sizes >= 60).any()          # sampling really fired (size k, k+1 or k+2)
 
 
+@pytest.mark.parametrize('cone', [0, 1])
 @pytest.mark.parametrize('kind', ['tissue', 'firstmm'])
-def test_meta_step_matches_oracle(kind):
+def test_meta_step_matches_oracle(kind, cone):
     import gmeta_amd
     c = _run_case(kind, sample_nodes=100000)                  # no sampling: every centre keeps its neighbourhood (well conditioned)
     torch.manual_seed(11)
     m = gmeta_amd.Meta(c['args'], c['config']).to('cuda')
+    m.cone = cone                                             # receptive-field schedule (link-pred: two centres per subgraph)
     theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
     grads = {}
     orig = m.meta_optim.step

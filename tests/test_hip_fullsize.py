@@ -140,6 +140,65 @@ def test_meta_step_determinism_and_schedule_equivalence(world):
     assert np.isfinite(a0).all() and torch.isfinite(g0).all() and float(g0.abs().max()) > 0
 
 
+def test_cone_schedule_equals_full_schedule(world):
+    """gm_hparams_t.cone: layer l only on the rows (L-l) in-hops upstream of a centre.  Same accuracies, same
+    meta-gradient up to summation order; deterministic; composes with the layer-1 hoist bit for bit."""
+    b = world['batch']
+    a0, g0 = _step(_meta(world), b)
+    a1, g1 = _step(_meta(world, cone=1), b)
+    a2, g2 = _step(_meta(world, cone=1), b)
+    a3, g3 = _step(_meta(world, cone=1, hoist_z1=1), b)
+    a4, g4 = _step(_meta(world, cone=1, serialize=1), b)
+    assert np.array_equal(a1, a2) and torch.equal(g1, g2)
+    assert np.array_equal(a1, a3) and torch.equal(g1, g3)
+    assert np.array_equal(a1, a4) and torch.equal(g1, g4)
+    np.testing.assert_allclose(a1, a0, atol=1e-6)
+    assert torch.allclose(g1, g0, atol=2e-6, rtol=1e-4), float((g1 - g0).abs().max())
+
+
+def test_cone_tables_match_numpy_construction(world):
+    """The receptive-field tables are integer work: bit-exact against a numpy construction from the batch CSR."""
+    import ctypes as C
+    import gmeta_amd
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    q = gmeta_amd.SubgraphBatch.concat(list(world['batch'][2]))
+    L = world['cfg']['h']
+    _lib.check(lib.gm_batch_prepare_cone(q.handle, L, None), 'prepare_cone')
+    ok = C.c_int32(); nrows = (C.c_int64 * (L + 1))(); nedges = (C.c_int64 * (L + 1))()
+    _lib.check(lib.gm_batch_cone_dims(q.handle, L, C.byref(ok), nrows, nedges), 'cone_dims')
+    assert ok.value == 1
+
+    def rd(level, what, n):
+        a = np.empty(n, np.int32)
+        _lib.check(lib.gm_batch_cone_read(q.handle, L, level, what, a.ctypes.data, a.nbytes), 'cone_read')
+        return a
+    (indptr, indices), (indptr_t, indices_t) = q.csr(), q.csr(True)
+    sub_off = q.sub_off
+    up = (sub_off[:-1] + np.asarray(q.centres_local()).reshape(-1)).astype(np.int64)      # level L: centre rows, centre order
+    set_row_off = sub_off[q.set_sub_off]
+    row_of_edge_t = np.repeat(np.arange(q.rows), np.diff(indptr_t))
+    for l in range(L, 0, -1):
+        rows_up = rd(l, 0, nrows[l])
+        assert np.array_equal(rows_up, up)
+        deg = indptr[up + 1] - indptr[up]
+        src = np.concatenate([indices[indptr[r]:indptr[r + 1]] for r in up]) if len(up) else np.zeros(0, np.int64)
+        lo = np.unique(src)
+        assert nrows[l - 1] == len(lo) and nedges[l] == len(src)
+        pos_lo = np.full(q.rows, -1, np.int64); pos_lo[lo] = np.arange(len(lo))
+        pos_up = np.full(q.rows, -1, np.int64); pos_up[up] = np.arange(len(up))
+        assert np.array_equal(rd(l, 1, len(up) + 1), np.concatenate([[0], np.cumsum(deg)]))
+        assert np.array_equal(rd(l, 2, len(src)), pos_lo[src])
+        # by-source CSR: out-edges of every lower row that end in the upper level, in the batch's by-source order
+        keep = (pos_lo[row_of_edge_t] >= 0) & (pos_up[indices_t] >= 0)
+        cnt = np.bincount(pos_lo[row_of_edge_t[keep]], minlength=len(lo))
+        assert np.array_equal(rd(l, 3, len(lo) + 1), np.concatenate([[0], np.cumsum(cnt)]))
+        assert np.array_equal(rd(l, 4, len(src)), pos_up[indices_t[keep]])
+        assert np.array_equal(rd(l - 1, 5, q.sets + 1), np.searchsorted(lo, set_row_off))
+        up = lo
+    assert np.array_equal(rd(0, 0, nrows[0]), up)
+
+
 def test_batched_tasks_equal_per_task_runs(world):
     """Tasks are independent inside forward_ProtoMAML (meta.py:118-157): the batched step's meta-gradient is the mean of
     the single-task steps' and its accs their mean."""

@@ -165,13 +165,14 @@ def test_classifier_forward_backward_autograd(case):
 
 
 @pytest.mark.parametrize('case', CASES)
-@pytest.mark.parametrize('hoist,sparse', [(0, 0), (1, 0), (0, 1)])
-def test_meta_step_matches_reference(case, hoist, sparse):
+@pytest.mark.parametrize('hoist,sparse,cone', [(0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1)])
+def test_meta_step_matches_reference(case, hoist, sparse, cone):
     """a8-a10 against the reference's own outputs (golden): accs, theta.grad, post-Adam weights, NaN skip -- for the
-    default schedule and for the two flagged exact variants (hoisted layer-1 aggregate, row-sparse backward)."""
+    default schedule and for the flagged exact variants (hoisted layer-1 aggregate, row-sparse backward, receptive-field
+    schedule with and without the hoist)."""
     hu = _imports()
     fx = Fixture(case)
-    res = hu.hip_meta_step(fx, replay=True, hoist=hoist, sparse_bwd=sparse)
+    res = hu.hip_meta_step(fx, replay=True, hoist=hoist, sparse_bwd=sparse, cone=cone)
     if case == 'g6_nan_skip':
         assert res['grad'] is None and np.isnan(res['stats']['loss_q'])
         for a, b in zip(res['vars1'], fx.vars1):
