@@ -187,6 +187,13 @@ def main():
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
+        import ctypes as C_
+        lv = {}
+        for side, x in (('spt', batches[0][0][0].view_of), ('qry', batches[0][2][0].view_of)):      # what the cone schedule touches
+            ok = C_.c_int32(); nr = (C_.c_int64 * (cfg['h'] + 1))(); ne = (C_.c_int64 * (cfg['h'] + 1))()
+            _lib.check(lib.gm_batch_cone_dims(x.handle, cfg['h'], C_.byref(ok), nr, ne), 'cone_dims')
+            lv[side] = {'batch_rows': int(x.rows), 'batch_edges': int(x.edges), 'level_rows': list(nr), 'level_edges': list(ne)}
+        extra['cone']['receptive_field'] = lv
 
     if rank == 0:
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None

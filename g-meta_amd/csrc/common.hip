@@ -15,8 +15,22 @@ void gm_set_error(const char* fmt, ...) {
 extern "C" const char* gm_last_error(void) { return g_err; }
 extern "C" int gm_version(void) { return 100; }
 
+// The stream-ordered pool returns freed memory to the OS at every synchronisation point by default (release
+// threshold 0), so each batch build would re-map its arrays: keep freed blocks in the pool instead.
+static void pool_keep_memory() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev == done_for) { (void)hipGetLastError(); return; }
+    done_for = dev;
+    hipMemPool_t pool;
+    uint64_t keep = UINT64_MAX;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess)
+        (void)hipGetLastError();
+}
+
 int gm_dev_alloc(void** p, size_t bytes, hipStream_t s) {
     *p = nullptr;
+    pool_keep_memory();
     hipError_t e = hipMallocAsync(p, bytes, s);
     if (e != hipSuccess) {
         (void)hipGetLastError();

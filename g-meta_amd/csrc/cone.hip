@@ -280,6 +280,7 @@ int gm_batch_cone(const gm_batch* b, int L, hipStream_t s, const gm_cone** out) 
     *out = nullptr;
     GM_REQUIRE(b && L >= 1 && L <= GM_MAX_GCN, GM_EINVAL, "cone: n_gcn=%d outside [1,%d]", L, GM_MAX_GCN);
     if (b->cone[L]) { *out = b->cone[L]; return GM_OK; }
+    gm_phase_timer tm("cone");
     gm_cone* c = new gm_cone();
     int32_t *posA = nullptr, *posB = nullptr, *flags = nullptr, *d_bad = nullptr;
     int rc = gm_alloc(&posA, b->rows, s);

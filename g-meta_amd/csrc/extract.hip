@@ -363,6 +363,7 @@ static void batch_free(gm_batch* b) {
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
 // fast weights), weight-gradient chunks are sized so that a batch yields roughly 768 blocks.
 int gm_batch_finalize(gm_batch* b, hipStream_t s) {
+    gm_phase_timer tm("finalize");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
     for (int t = 0; t < b->sets; ++t)
         for (int k = b->h_set_sub_off[t]; k < b->h_set_sub_off[t + 1]; ++k) sub_set[k] = t;
@@ -384,6 +385,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     if (!chunks.empty()) GM_HIP(hipMemcpyAsync(b->d_chunks, chunks.data(), 4 * chunks.size(), hipMemcpyHostToDevice, s));
     GM_HIP(hipMemcpyAsync(b->d_set_chunk_off, set_chunk_off.data(), 4 * set_chunk_off.size(), hipMemcpyHostToDevice, s));
     GM_HIP(hipStreamSynchronize(s));     // host vectors go out of scope
+    tm.lap("tables");
     // heavy-row lists for both CSR orientations (a row can have at most rows-1... edges: cap = edges / heavy_deg + 1)
     b->heavy_deg = gm_heavy_deg();
     const int cap = (int)(b->edges / b->heavy_deg + 1);
@@ -408,6 +410,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
         }
     }
+    tm.lap("heavy");
     // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres
     const int nc = b->centres; b->n_c = b->subs * nc;
     int32_t* d_cdeg = nullptr;
@@ -477,6 +480,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
                         const int64_t* nodes_off, void* stream, gm_batch_t** out) {
     GM_REQUIRE(out, GM_EINVAL, "extract: out is NULL");
     *out = nullptr;
+    gm_phase_timer tm("extract");
     GM_REQUIRE(store && seeds && set_offsets && n_seeds >= 1 && n_sets >= 1, GM_EINVAL, "extract: bad arguments");
     GM_REQUIRE(set_offsets[0] == 0 && set_offsets[n_sets] == n_seeds, GM_EINVAL, "extract: set_offsets must span [0,n_seeds]");
     const bool given = nodes_flat != nullptr;
@@ -534,6 +538,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     };
 #define EX_TRY(x) do { rc = (x); if (rc != GM_OK) { cleanup(); batch_free(b); delete b; return rc; } } while (0)
 #define EX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm_set_error("%s: %s", #x, hipGetErrorString(e_)); cleanup(); batch_free(b); delete b; return GM_EHIP; } } while (0)
+    tm.lap("validate");
     EX_TRY(gm_alloc(&d_seeds, n_seeds, st));
     EX_TRY(gm_alloc(&d_nodes, (size_t)n_seeds * cap, st)); EX_TRY(gm_alloc(&d_degi, (size_t)n_seeds * cap, st));
     EX_TRY(gm_alloc(&d_dego, (size_t)n_seeds * cap, st));
@@ -559,6 +564,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     EX_HIP(hipMemcpyAsync(esub.data(), d_esub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
     EX_HIP(hipStreamSynchronize(st));
 
+    tm.lap("k_nodes+sizes");
     b->store = store; b->subs = n_seeds; b->sets = n_sets; b->centres = link ? 2 : 1; b->stream = st;
     b->h_sub_off.assign(n_seeds + 1, 0); b->h_graph.resize(n_seeds);
     std::vector<int32_t> eoff(n_seeds + 1, 0);
@@ -594,7 +600,9 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     }
     EX_HIP(hipGetLastError());
     EX_HIP(hipStreamSynchronize(st));   // eoff (host vector) must outlive the async copy; also surfaces kernel faults here
+    tm.lap("alloc+k_fill");
     EX_TRY(gm_batch_finalize(b, st));
+    tm.lap("finalize");
     cleanup();
 #undef EX_TRY
 #undef EX_HIP

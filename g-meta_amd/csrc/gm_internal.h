@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/gmeta_hip.h"
@@ -112,6 +113,26 @@ struct gm_batch {
     hipStream_t stream = nullptr;      // stream the arrays were produced on
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);
+
+// ---- host phase timing for the setup paths (env GM_TIMING=1 prints to stderr)
+#include <chrono>
+struct gm_phase_timer {
+    const char* what; bool on; std::chrono::steady_clock::time_point t0, t;
+    explicit gm_phase_timer(const char* w) : what(w) {
+        static int en = -1;
+        if (en < 0) { const char* e = getenv("GM_TIMING"); en = e ? atoi(e) : 0; }
+        on = en != 0; t0 = t = std::chrono::steady_clock::now();
+    }
+    void lap(const char* phase) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[gm timing] %s/%s %.1f us\n", what, phase, std::chrono::duration<double, std::micro>(n - t).count());
+        t = n;
+    }
+    ~gm_phase_timer() {
+        if (on) fprintf(stderr, "[gm timing] %s total %.1f us\n", what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
 
 // ---- device allocation helpers (stream-ordered pool so that per-batch builds do not sync the device)
 int gm_dev_alloc(void** p, size_t bytes, hipStream_t s);

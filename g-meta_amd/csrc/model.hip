@@ -720,6 +720,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
                "meta_step: update_step must be >= 2 for training (losses_q[0..1] are computed under no_grad, meta.py:129-141)");
     GM_REQUIRE(((uintptr_t)theta & 15) == 0, GM_EINVAL, "meta_step: theta must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
+    gm_phase_timer tm("meta_step");
     std::vector<int32_t> rows_s, rows_q; int Ct, ns, Ctq, nq;
     GM_TRY(class_tables(spt, y_spt, hp->k_spt, rows_s, &Ct, &ns));
     GM_TRY(class_tables(qry, y_qry, 0, rows_q, &Ctq, &nq));
@@ -731,6 +732,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_HIP(hipMemcpyAsync(p.rows_q, rows_q.data(), 4 * rows_q.size(), hipMemcpyHostToDevice, st));
     GM_HIP(hipStreamSynchronize(st));       // pageable host vectors: make the copies complete before they go out of scope
     gm_prof_reset();
+    tm.lap("plan");
     const int sgd_blocks = (int)std::min<int64_t>(2048, ((int64_t)T * L.P + 255) / 256);
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the

@@ -37,6 +37,25 @@ class _NodeIds(collections.abc.Sequence):
         return a.astype(dtype) if dtype is not None else a
 
 
+class _NodeLists(collections.abc.Sequence):
+    """The list of per-subgraph id lists of slots 6/7 (sdp.py:402,408), materialised on access."""
+
+    def __init__(self, owner, a, b):
+        self._o, self._a, self._b = owner, a, b
+
+    def __len__(self):
+        return self._b - self._a
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError(k)
+        return _NodeIds(self._o, self._a + k)
+
+
 class SubgraphBatch:
     """Device-resident batched induced subgraphs: stands where the reference has a batched DGLGraph
     (slots 0 and 2 of the task tuple, sdp.py:399-408).  `sets` > 1 when it holds several tasks.
@@ -46,6 +65,9 @@ class SubgraphBatch:
         self.handle, self.store, self._owner = handle, store, owner
         self.view_of, self.view_index = view_of, view_index
         self._cache = {}
+        if view_of is not None:          # a view shares the parent's handle and dimensions
+            self.rows, self.edges, self.subs, self.sets, self.centres = view_of.rows, view_of.edges, view_of.subs, view_of.sets, view_of.centres
+            return
         rows, edges, subs, sets, cen = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(_lib.lib().gm_batch_dims(handle, C.byref(rows), C.byref(edges), C.byref(subs), C.byref(sets), C.byref(cen)))
         self.rows, self.edges, self.subs, self.sets, self.centres = rows.value, edges.value, subs.value, sets.value, cen.value
@@ -53,18 +75,15 @@ class SubgraphBatch:
     # ---- construction
     @staticmethod
     def _seed_array(seeds):
-        seeds = np.asarray(seeds, np.int32).reshape(-1, 3)
-        arr = (_lib.Seed * len(seeds))()
-        for k, (g, i, j) in enumerate(seeds):
-            arr[k].graph, arr[k].i, arr[k].j = int(g), int(i), int(j)
-        return arr
+        # gm_seed_t is three packed int32 (graph, i, j): a C-contiguous int32 [n, 3] array has the same layout
+        return np.ascontiguousarray(np.asarray(seeds, np.int32).reshape(-1, 3))
 
     @classmethod
     def extract(cls, store, seeds, set_offsets, h, sample_nodes, rng_seed, link_pred):
         arr = cls._seed_array(seeds)
         so = np.ascontiguousarray(set_offsets, np.int32)
         out = C.c_void_p()
-        _lib.check(_lib.lib().gm_extract(store.handle, arr, len(arr), _lib.ptr(so), len(so) - 1, int(h), int(sample_nodes),
+        _lib.check(_lib.lib().gm_extract(store.handle, _lib.ptr(arr), len(arr), _lib.ptr(so), len(so) - 1, int(h), int(sample_nodes),
                                          C.c_uint64(int(rng_seed) & (2 ** 64 - 1)), int(bool(link_pred)), _lib.stream_ptr(), C.byref(out)),
                    'gm_extract')
         return cls(out, store)
@@ -77,7 +96,7 @@ class SubgraphBatch:
         flat = np.ascontiguousarray(np.concatenate(lists), np.int32)
         off = np.ascontiguousarray(np.cumsum([0] + [len(x) for x in lists]), np.int64)
         out = C.c_void_p()
-        _lib.check(_lib.lib().gm_batch_from_nodes(store.handle, arr, len(arr), _lib.ptr(so), len(so) - 1, _lib.ptr(flat), _lib.ptr(off),
+        _lib.check(_lib.lib().gm_batch_from_nodes(store.handle, _lib.ptr(arr), len(arr), _lib.ptr(so), len(so) - 1, _lib.ptr(flat), _lib.ptr(off),
                                                   int(bool(link_pred)), _lib.stream_ptr(), C.byref(out)), 'gm_batch_from_nodes')
         return cls(out, store)
 
@@ -152,7 +171,7 @@ class SubgraphBatch:
 
     def node_lists(self):
         a, b = self._sub_range()
-        return [_NodeIds(self, k) for k in range(a, b)]
+        return _NodeLists(self, a, b)
 
     def csr(self, transposed=False):
         ip = self._read(_lib.F_INDPTR_T if transposed else _lib.F_INDPTR, self.rows + 1, np.int32)
@@ -225,6 +244,7 @@ class Subgraphs(Dataset):
                 self.create_batch_shared(batchsz)
         else:
             raise ValueError("task_setup must be 'Disjoint' or 'Shared'")
+        self._task_memo = {}          # per-task seed / raw-label arrays (the names never change after create_batch_*)
 
     # ---- CSV index (sdp.py:119-148): columns (pandas index, name, label); label kept as string
     @staticmethod
@@ -298,55 +318,123 @@ class Subgraphs(Dataset):
             self.support_x_batch.append(support_x); self.query_x_batch.append(query_x)
 
     # ---- extraction
-    @staticmethod
-    def _seeds(names):
+    _seed_memo = {}
+
+    @classmethod
+    def _seeds(cls, names):
+        memo = cls._seed_memo          # 'g_i' / 'g_i_j' -> (g, i, j): names recur across tasks and epochs
         out = []
         for item in names:
-            p = [int(x) for x in item.split('_')]
-            out.append(p + [-1] if len(p) == 2 else p)
-        return np.array(out, np.int32)
+            v = memo.get(item)
+            if v is None:
+                p = [int(x) for x in item.split('_')]
+                v = memo[item] = tuple(p + [-1] if len(p) == 2 else p)
+            out.append(v)
+        return np.array(out, np.int32).reshape(-1, 3)
 
     def _task_names(self, index):
         spt = [item for sub in self.support_x_batch[index] for item in sub]
         qry = [item for sub in self.query_x_batch[index] for item in sub]
         return spt, qry
 
-    def _labels(self, spt, qry):
-        support_y = np.array([self.subgraph2label[i] for i in spt]).astype(np.int32)
-        query_y = np.array([self.subgraph2label[i] for i in qry]).astype(np.int32)
+    def _task_arrays(self, index):
+        """Per-task host tables, computed once: seeds int32 [n,3] and raw int labels of the support and query names."""
+        c = self._task_memo.get(index)
+        if c is None:
+            spt, qry = self._task_names(index)
+            lab = self.subgraph2label
+            c = self._task_memo[index] = (self._seeds(spt), self._seeds(qry), np.array([lab[i] for i in spt]).astype(np.int32),
+                                          np.array([lab[i] for i in qry]).astype(np.int32))
+        return c
+
+    def _labels(self, support_y, query_y):
         if self.task_setup == 'Disjoint':                                     # sdp.py:389-397
             unique = np.unique(support_y)
-            random.shuffle(unique)
-            sy, qy = np.zeros(self.setsz), np.zeros(self.querysz)
-            for idx, l in enumerate(unique):
-                sy[support_y == l] = idx
-                qy[query_y == l] = idx
-            return torch.LongTensor(sy), torch.LongTensor(qy)
-        return torch.LongTensor(support_y), torch.LongTensor(query_y)
+            # random.shuffle(unique) of the reference, applied to an index list: the same draws, the same permutation
+            order = list(range(len(unique)))
+            random.shuffle(order)
+            rank = np.empty(len(unique), np.int64)
+            rank[order] = np.arange(len(unique))                               # class unique[order[idx]] -> idx
+            sy = rank[np.searchsorted(unique, support_y)]
+            pos = np.minimum(np.searchsorted(unique, query_y), len(unique) - 1)
+            qy = np.where(unique[pos] == query_y, rank[pos], 0)                # a query class absent from the support keeps 0 (np.zeros, sdp.py:393)
+            return torch.from_numpy(sy), torch.from_numpy(qy.astype(np.int64))
+        return torch.from_numpy(support_y.astype(np.int64)), torch.from_numpy(query_y.astype(np.int64))
 
     def _tuple(self, bs, bq, ys, yq):
-        return (bs, ys, bq, yq, torch.LongTensor(bs.centres_local().astype(np.int64)), torch.LongTensor(bq.centres_local().astype(np.int64)),
-                bs.node_lists(), bq.node_lists(), [int(g) for g in bs.graph_ids()], [int(g) for g in bq.graph_ids()])
+        return (bs, ys, bq, yq, torch.from_numpy(bs.centres_local().astype(np.int64)), torch.from_numpy(bq.centres_local().astype(np.int64)),
+                bs.node_lists(), bq.node_lists(), bs.graph_ids().tolist(), bq.graph_ids().tolist())
 
     def __getitem__(self, index):
         """One task (sdp.py:348-408): the 10-tuple with SubgraphBatch handles in slots 0 and 2."""
-        spt, qry = self._task_names(index)
-        ys, yq = self._labels(spt, qry)
-        bs = SubgraphBatch.extract(self.G, self._seeds(spt), [0, len(spt)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
-        bq = SubgraphBatch.extract(self.G, self._seeds(qry), [0, len(qry)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        seeds_s, seeds_q, lab_s, lab_q = self._task_arrays(index)
+        ys, yq = self._labels(lab_s, lab_q)
+        bs = SubgraphBatch.extract(self.G, seeds_s, [0, len(seeds_s)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        bq = SubgraphBatch.extract(self.G, seeds_q, [0, len(seeds_q)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
         return self._tuple(bs, bq, ys, yq)
 
     def get_batch(self, indices):
         """MI355X-first counterpart of DataLoader(..., collate_fn=collate): the subgraphs of ALL tasks of a
         meta-batch are extracted by two launches (support / query); returns the collated 10-tuple of lists."""
-        names = [self._task_names(i) for i in indices]
-        ys_yq = [self._labels(s, q) for s, q in names]
-        off_s = np.cumsum([0] + [len(s) for s, _ in names]); off_q = np.cumsum([0] + [len(q) for _, q in names])
-        S = SubgraphBatch.extract(self.G, np.concatenate([self._seeds(s) for s, _ in names]), off_s, self.h, self.sample_nodes,
-                                  self.rng_seed, self.link_pred_mode)
-        Q = SubgraphBatch.extract(self.G, np.concatenate([self._seeds(q) for _, q in names]), off_q, self.h, self.sample_nodes,
-                                  self.rng_seed, self.link_pred_mode)
+        arrs = [self._task_arrays(i) for i in indices]
+        ys_yq = [self._labels(a[2], a[3]) for a in arrs]
+        off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
+        S = SubgraphBatch.extract(self.G, np.concatenate([a[0] for a in arrs]), off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        Q = SubgraphBatch.extract(self.G, np.concatenate([a[1] for a in arrs]), off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
         return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])
+
+    def batches(self, index_lists, prefetch=1, cone_layers=0):
+        """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being extracted by a
+        background thread on its own HIP stream while the caller runs the meta-step on the current one -- what
+        DataLoader(num_workers>0) does for the reference (train.py:96,173), minus the per-worker copy of the memo cache
+        (sdp.py:296-297,319).  cone_layers = n_gcn also builds the receptive-field tables (gm_hparams_t.cone) there."""
+        import queue
+        import threading
+        index_lists = [list(int(i) for i in idx) for idx in index_lists]
+        if prefetch <= 0 or len(index_lists) <= 1:
+            for idx in index_lists:
+                yield self.get_batch(idx)
+            return
+        dev = torch.cuda.current_device()
+        q = queue.Queue(maxsize=prefetch)
+        stop = threading.Event()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    for idx in index_lists:
+                        if stop.is_set():
+                            break
+                        b = self.get_batch(idx)
+                        if cone_layers:
+                            for x in (b[0][0], b[2][0]):
+                                root = x.view_of if x.view_of is not None else x
+                                _lib.check(_lib.lib().gm_batch_prepare_cone(root.handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone')
+                        side.synchronize()
+                        q.put(('ok', b))
+                q.put(('end', None))
+            except BaseException as e:      # surface worker failures in the consumer
+                q.put(('err', e))
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        try:
+            while True:
+                kind, val = q.get()
+                if kind == 'end':
+                    break
+                if kind == 'err':
+                    raise val
+                yield val
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
 
     def __len__(self):
         return self.batchsz

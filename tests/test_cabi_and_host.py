@@ -118,7 +118,18 @@ def test_disjoint_task_sampler_distribution(monkeypatch):
         cls_s = [info[n] for n in spt]
         assert len(set(cls_s)) == 3 and all(cls_s.count(c) == 2 for c in set(cls_s))
         assert set(info[n] for n in qry) == set(cls_s)
-        ys, yq = db._labels(spt, qry)
+        raw_s, raw_q = db._task_arrays(t)[2:]
+        assert raw_s.tolist() == cls_s
+        import random
+        random.seed(100 + t)
+        ys, yq = db._labels(raw_s, raw_q)
+        # the reference's relabelling loop (sdp.py:389-397) on the same Python-RNG state gives the same mapping
+        random.seed(100 + t)
+        uniq = np.unique(raw_s); random.shuffle(uniq)
+        ref_s, ref_q = np.zeros(len(raw_s)), np.zeros(len(raw_q))
+        for idx, l in enumerate(uniq):
+            ref_s[raw_s == l] = idx; ref_q[raw_q == l] = idx
+        assert ys.dtype == torch.int64 and ys.tolist() == ref_s.tolist() and yq.tolist() == ref_q.tolist()
         assert sorted(set(ys.tolist())) == [0, 1, 2] and sorted(set(yq.tolist())) == [0, 1, 2]      # relabelled 0..n_way-1 (sdp.py:389-397)
         m = {}
         for n, y in zip(spt, ys.tolist()):
@@ -136,7 +147,7 @@ def test_shared_and_linkpred_samplers(monkeypatch):
     for t in range(10):
         spt, qry = db._task_names(t)
         assert len({n.split('_')[0] for n in spt + qry}) == 1                  # one graph per task (sdp.py:198)
-        ys, yq = db._labels(spt, qry)
+        ys, yq = db._labels(*db._task_arrays(t)[2:])
         assert ys.tolist() == [info[n] for n in spt]                           # raw labels in Shared (sdp.py:408)
     pn = ['%d_%d_%d' % (g, a, a + 1) for g in range(2) for a in range(40)]
     pl = [str((a // 2) % 2) for g in range(2) for a in range(40)]

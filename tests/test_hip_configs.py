@@ -156,3 +156,40 @@ def test_dataloader_getitem_path_equals_batched_extraction():
     a1, g1 = run(batch_dl)
     a2, g2 = run(batch_fast)
     assert np.array_equal(a1, a2) and torch.equal(g1, g2)
+
+
+def test_prefetching_iterator_equals_sequential_get_batch():
+    """Subgraphs.batches(prefetch=1): meta-batches extracted by a background thread on its own stream (the reference's
+    DataLoader num_workers, train.py:96,173) are the same objects get_batch builds, in order, with the cone tables ready."""
+    import ctypes as C
+    import random
+    import gmeta_amd
+    from gmeta_amd import _lib, synth
+    rng = np.random.default_rng(5)
+    np.random.seed(5)
+    graphs, feats, info, tabs = _tissue(rng, n_graphs=3, n=300, F0=16)
+    args = argparse.Namespace(update_lr=0.05, meta_lr=5e-3, n_way=2, k_spt=3, k_qry=6, task_num=2, update_step=3, update_step_test=3,
+                              method='G-Meta', sample_nodes=40, link_pred_mode='False', task_setup='Disjoint', h=2)
+    store = gmeta_amd.GraphStore(graphs, feats)
+    db = gmeta_amd.Subgraphs(None, 'train', info, n_way=2, k_shot=3, k_query=6, batchsz=8, args=args, adjs=store, h=2, tables=tabs, verbose=False)
+    lists = [[0, 1], [2, 3], [4, 5], [6, 7]]
+    random.seed(77)
+    seq = [db.get_batch(idx) for idx in lists]
+    random.seed(77)
+    pre = list(db.batches(lists, prefetch=2, cone_layers=2))
+    assert len(pre) == len(seq)
+    for a, b in zip(seq, pre):
+        A, B = a[0][0].view_of, b[0][0].view_of
+        assert np.array_equal(A.parent(), B.parent()) and np.array_equal(A.csr()[1], B.csr()[1])
+        assert all(torch.equal(x, y) for x, y in zip(a[1] + a[3], b[1] + b[3]))           # relabelled targets: same Python-RNG order
+        ok = C.c_int32()
+        _lib.check(_lib.lib().gm_batch_cone_dims(B.handle, 2, C.byref(ok), None, None), 'cone_dims')     # built by the worker
+        assert ok.value == 1
+    config = synth.make_config(16, 32, 2, 2)
+    torch.manual_seed(1); m1 = gmeta_amd.Meta(args, config).to('cuda'); m1.cone = 1
+    torch.manual_seed(1); m2 = gmeta_amd.Meta(args, config).to('cuda'); m2.cone = 1
+    for a, b in zip(seq, pre):
+        assert np.array_equal(m1(*a, feats), m2(*b, feats))
+    # a failure inside the worker surfaces in the consumer
+    with pytest.raises(Exception):
+        list(db.batches([[0, 1], [999, 1000]], prefetch=1))

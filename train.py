@@ -52,6 +52,10 @@ def parse(argv=None):
     ap.add_argument('--h', default=2, type=int)
     ap.add_argument('--sample_nodes', type=int, default=1000)
     ap.add_argument('--eval_tasks', type=int, default=100, help='validation / test tasks (the reference hard-codes 100, train.py:90-91)')
+    # schedules of the MI355X build that return the same results faster (include/gmeta_hip.h, gm_hparams_t); 0 = as the reference computes
+    ap.add_argument('--hoist_z1', type=int, default=0, help='1: aggregate the layer-1 input once per meta-step instead of in every forward')
+    ap.add_argument('--sparse_bwd', type=int, default=0, help='1: backward only over the rows whose gradient is structurally non-zero')
+    ap.add_argument('--cone', type=int, default=0, help='1: evaluate each layer only on the rows that can reach a centre (forward and backward)')
     return ap.parse_args(argv)
 
 
@@ -93,10 +97,12 @@ def main(args):
 
     for epoch in range(args.epoch):
         order = np.random.permutation(len(db_train))                                # DataLoader(shuffle=True), train.py:96
-        for step in range(len(order) // args.task_num):
-            idx = order[step * args.task_num:(step + 1) * args.task_num][rank * per:(rank + 1) * per]
+        n_steps = len(order) // args.task_num
+        shards = [order[step * args.task_num:(step + 1) * args.task_num][rank * per:(rank + 1) * per] for step in range(n_steps)]
+        it = iter(db_train.batches(shards, prefetch=args.num_workers, cone_layers=args.h if getattr(args, 'cone', 0) else 0))
+        for step in range(n_steps):
             s = time.time()
-            batch = db_train.get_batch([int(i) for i in idx])
+            batch = next(it)            # extracted by the prefetch thread while the previous meta-step ran (num_workers > 0)
             t_load = time.time() - s
             s = time.time()
             accs = maml(*batch, feat)
