@@ -209,6 +209,9 @@ struct gm_wgrad_args {
     float* partial;                     // workspace [n_chunks, (K+1)*N]  (row K = bias partial)
     float* dW; int64_t dw_stride;       // dW_t = dW + t*dw_stride   [K,N]
     float* db; int64_t db_stride;       // db_t                      [N]
+    // optional fused inner-loop SGD (meta.py:126,151): next_t[off + j] = cur_t[off + j] - lr * grad, written together with the gradient
+    const float* sgd_cur; int64_t sgd_cur_stride; float* sgd_next; int64_t sgd_next_stride; float sgd_lr;
+    int64_t w_off, b_off;               // offsets of this layer's W and b inside a parameter vector
 };
 #define GM_WGRAD_ROWS 1024
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);

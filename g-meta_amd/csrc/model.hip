@@ -27,10 +27,11 @@ __device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) 
     return k.compact ? (int64_t)s * k.nc + which : (int64_t)k.sub_off[s] + k.centre[s * k.nc + which];
 }
 
+// Optional fused inner-loop SGD (meta.py:126,151): next_t[j] = cur_t[j] - lr * grad_t[j], written with the gradient.
+struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; };
+
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
-__global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= k.subs) return;
+__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits) {
     const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
     const float* h0 = k.H + centre_row(k, s, 0) * k.ldh;
     const float* h1 = k.nc == 2 ? k.H + centre_row(k, s, 1) * k.ldh : nullptr;
@@ -42,15 +43,20 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
         if (lane == 0) logits[(int64_t)s * k.C + c] = acc + P[k.bl_off + c];
     }
 }
+__global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s < k.subs) head_fwd_sub(k, s, threadIdx.x & 63, logits);
+}
 
 // Backward of the head for one set per block: dWl, dbl into dparams; dQ_L (pre-zeroed) at the centre rows,
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
-__global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ, float* Gc) {
-    const int set = blockIdx.x, tid = threadIdx.x;
+template <int NT>
+__device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
+                                             float* Gc, const SgdK& u) {
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
     float* D = dparams + (int64_t)set * dstride;
-    for (int id = tid; id < k.C * k.hc; id += 256) {
+    for (int id = tid; id < k.C * k.hc; id += NT) {
         const int c = id / k.hc, h = id - c * k.hc;
         float acc = 0.f;
         for (int s = s0; s < s1; ++s) {
@@ -58,23 +64,28 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits,
             acc += dlogits[(int64_t)s * k.C + c] * hv;
         }
         D[k.wl_off + id] = acc;
+        if (u.next) u.next[(int64_t)set * u.next_stride + k.wl_off + id] = u.cur[(int64_t)set * u.cur_stride + k.wl_off + id] - u.lr * acc;
     }
-    for (int c = tid; c < k.C; c += 256) {
+    for (int c = tid; c < k.C; c += NT) {
         float acc = 0.f;
         for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)s * k.C + c];
         D[k.bl_off + c] = acc;
+        if (u.next) u.next[(int64_t)set * u.next_stride + k.bl_off + c] = u.cur[(int64_t)set * u.cur_stride + k.bl_off + c] - u.lr * acc;
     }
-    for (int col = tid; col < k.Hd; col += 256) {
-        for (int s = s0; s < s1; ++s) {
-            for (int which = 0; which < k.nc; ++which) {
-                float v = 0.f;
-                for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
-                const int64_t at = centre_row(k, s, which) * k.ldh + col;
-                if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = k.H[at] > 0.f ? v : 0.f;     // compact rows (sparse backward)
-                else if (k.H[at] > 0.f) dQ[at] += v;
-            }
+    // one thread per (subgraph, column); both centres of a pair stay in one thread (they may share a row)
+    for (int id = tid; id < (s1 - s0) * k.Hd; id += NT) {
+        const int s = s0 + id / k.Hd, col = id % k.Hd;
+        for (int which = 0; which < k.nc; ++which) {
+            float v = 0.f;
+            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
+            const int64_t at = centre_row(k, s, which) * k.ldh + col;
+            if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = k.H[at] > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
+            else if (k.H[at] > 0.f) dQ[at] += v;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ, float* Gc) {
+    head_bwd_set<256>(k, blockIdx.x, threadIdx.x, dlogits, dparams, dstride, dQ, Gc, SgdK{nullptr, 0, nullptr, 0, 0.f});
 }
 
 // Prototypical loss for one set per block (meta.py:28-79).  rows: [sets, Ct, n] global subgraph ids grouped by
@@ -91,14 +102,14 @@ __device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
     return d;
 }
 
-__global__ __launch_bounds__(256) void k_proto(ProtoK k) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int set = blockIdx.x, tid = threadIdx.x, Q = k.Ct * k.n, D = k.D;
+template <int NT>
+__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, float* sm) {
+    const int Q = k.Ct * k.n, D = k.D;
     float* protos = sm;                 // [Ct*D]
     float* lse = sm + k.Ct * D;         // [Q]
-    float* red = lse + Q;               // [512]
+    float* red = lse + Q;               // [2 * NT]
     const int32_t* rows = k.rows + (int64_t)set * Q;
-    for (int id = tid; id < k.Ct * D; id += 256) {
+    for (int id = tid; id < k.Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float p;
         if (k.mode == 0) {
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
     }
     __syncthreads();
     float lpart = 0.f, apart = 0.f;
-    for (int q = tid; q < Q; q += 256) {
+    for (int q = tid; q < Q; q += NT) {
         const float* x = k.logits + (int64_t)rows[q] * D;
         const int tgt = q / k.n;
         float m = -INFINITY, at = 0.f; int best = 0;
@@ -129,17 +140,17 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
         lpart += -(at - l);                                                          // -log_p[q, class(q)]
         apart += (best == tgt) ? 1.f : 0.f;
     }
-    red[tid] = lpart; red[256 + tid] = apart;
+    red[tid] = lpart; red[NT + tid] = apart;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if (tid < o) { red[tid] += red[tid + o]; red[256 + tid] += red[256 + tid + o]; } __syncthreads(); }
+    for (int o = NT / 2; o > 0; o >>= 1) { if (tid < o) { red[tid] += red[tid + o]; red[NT + tid] += red[NT + tid + o]; } __syncthreads(); }
     if (tid == 0) {
         k.loss[(int64_t)set * k.ld_out + k.col_out] = red[0] / (float)Q;
-        k.acc[(int64_t)set * k.ld_out + k.col_out] = red[256] / (float)Q;
+        k.acc[(int64_t)set * k.ld_out + k.col_out] = red[NT] / (float)Q;
     }
     if (!k.dlogits) return;
     // G[q,c] = (softmax(-d)[q,c] - [c == tgt(q)]) / Q ;  d(-d_qc)/dx_q = -2 (x_q - p_c) ; d(-d_qc)/dp_c = +2 (x_q - p_c)
     const float invQ = 1.f / (float)Q;
-    for (int id = tid; id < Q * D; id += 256) {
+    for (int id = tid; id < Q * D; id += NT) {
         const int q = id / D, d = id - q * D;
         const float* x = k.logits + (int64_t)rows[q] * D;
         const int tgt = q / k.n;
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
         k.dlogits[(int64_t)rows[q] * D + d] = s;
     }
     __syncthreads();
-    for (int id = tid; id < k.Ct * D; id += 256) {
+    for (int id = tid; id < k.Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float s = 0.f;
         for (int q = 0; q < Q; ++q) {
@@ -165,6 +176,28 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
             k.dprotos[(int64_t)set * k.Ct * D + id] = s;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_proto(ProtoK k) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    proto_set<256>(k, blockIdx.x, threadIdx.x, sm);
+}
+
+// Head forward + prototypical loss (+ head backward and the SGD of the head's own parameters) of one set per block: the
+// five launches between the last GCN layer of a forward and the first weight gradient of its backward, in one.
+#define HL_THREADS 1024
+__global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
+                                                          float* Gc, SgdK u) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int set = blockIdx.x, tid = threadIdx.x;
+    const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1];
+    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, logits);
+    if (pk.dlogits) for (int id = tid; id < (s1 - s0) * pk.D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * pk.D + id] = 0.f;   // rows outside the class tables
+    __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
+    proto_set<HL_THREADS>(pk, set, tid, sm);
+    if (!do_bwd) return;
+    __syncthreads();
+    head_bwd_set<HL_THREADS>(hk, set, tid, pk.dlogits, dparams, dstride, dQ, Gc, u);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -188,22 +221,14 @@ __global__ void k_expand_edges(const float* T2, const float* H1, int F, const in
     }
 }
 
-// dst[t, j] = src[t*src_stride + j] - lr * g[t*stride + j]     (meta.py:126,151)
-__global__ void k_sgd(float* dst, const float* src, int64_t src_stride, const float* g, float lr, int64_t P, int64_t stride, int T) {
-    const int64_t tot = (int64_t)T * P;
-    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t t = id / P, j = id - t * P;
-        dst[t * stride + j] = src[t * src_stride + j] - lr * g[t * stride + j];
-    }
-}
-
 // db[set, n] = sum over the set's rows [set_off[set], set_off[set+1]) of G[row, n]   (cone schedule, multiply-first layers)
-__global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t* set_off, float* db, int64_t db_stride) {
+__global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t* set_off, float* db, int64_t db_stride, SgdK u, int64_t b_off) {
     const int set = blockIdx.x, r0 = set_off[set], r1 = set_off[set + 1];
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         float s = 0.f;
         for (int r = r0; r < r1; ++r) s += G[(int64_t)r * ldg + n];
         db[(int64_t)set * db_stride + n] = s;
+        if (u.next) u.next[(int64_t)set * u.next_stride + b_off + n] = u.cur[(int64_t)set * u.cur_stride + b_off + n] - u.lr * s;
     }
 }
 
@@ -241,7 +266,13 @@ struct GcnCtx {
     const float* x0_user; const int32_t* centre; int z1_valid;
     int zw[GM_MAX_GCN];
     const gm_cone* cone;       // non-NULL: receptive-field schedule, every buffer is compact (gm_hparams_t.cone)
+    SgdK sgd;                  // next != NULL: the backward also writes the SGD-updated parameters (inner loop)
 };
+
+static void wgrad_sgd(gm_wgrad_args& w, const GcnCtx& c, int l) {
+    w.sgd_cur = c.sgd.cur; w.sgd_cur_stride = c.sgd.cur_stride; w.sgd_next = c.sgd.next; w.sgd_next_stride = c.sgd.next_stride; w.sgd_lr = c.sgd.lr;
+    w.w_off = c.L.w_off[l]; w.b_off = c.L.b_off[l];
+}
 
 static void gcn_carve(GcnCtx& c, Carver& cv) {
     const gm_layout& L = c.L; const int64_t rows = c.b->rows;
@@ -300,11 +331,12 @@ static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
     return k;
 }
 
-static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1);
-static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st);
+static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head);
+static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head);
 
-static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1) {
-    if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1);
+// skip_head: the head (centre gather + linear) is evaluated by the fused k_head_loss launch that follows
+static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head = 0) {
+    if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1, skip_head);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     GM_REQUIRE(L.dims[0] == b->store->feat_dim || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
@@ -340,25 +372,30 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
         }
         xin = c.H[l];
     }
+    if (skip_head) return GM_OK;
     HeadK k = make_head(c, params, pstride);
     hipLaunchKernelGGL(k_head_fwd, dim3((b->subs + 3) / 4), dim3(256), 0, st, k, logits);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
 
-static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st);
+static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head);
 static bool sparse_bwd_ok(const gm_layout& L);
 
-static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int sparse = 0) {
-    if (c.cone) return cone_backward(c, params, pstride, dlogits, dparams, dstride, st);
-    if (sparse && sparse_bwd_ok(c.L)) return gcn_backward_sparse(c, params, pstride, dlogits, dparams, dstride, st);
+// skip_head: dQ_L / the compact G2 and the head's own gradients were already produced by k_head_loss (head_loss below)
+static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int sparse = 0,
+                        int skip_head = 0) {
+    if (c.cone) return cone_backward(c, params, pstride, dlogits, dparams, dstride, st, skip_head);
+    if (sparse && sparse_bwd_ok(c.L)) return gcn_backward_sparse(c, params, pstride, dlogits, dparams, dstride, st, skip_head);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     const int Lg = L.n_gcn;
     float* dQ = c.bufA; float* T = c.bufB;
-    GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[Lg], st));
-    HeadK k = make_head(c, params, pstride);
-    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ, (float*)nullptr);
-    GM_HIP(hipGetLastError());
+    if (!skip_head) {
+        GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[Lg], st));
+        HeadK k = make_head(c, params, pstride);
+        hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ, (float*)nullptr);
+        GM_HIP(hipGetLastError());
+    }
     for (int l = Lg - 1; l >= 0; --l) {
         const int fi = L.dims[l], fo = L.dims[l + 1];
         const float* Xprev = l > 0 ? c.H[l - 1] : (c.x0_user ? c.x0_user : c.X0);
@@ -366,6 +403,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         gm_wgrad_args w{}; w.chunks = b->d_chunks; w.n_chunks = b->n_chunks; w.set_chunk_off = b->d_set_chunk_off; w.sets = b->sets;
         w.partial = c.partial; w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
         w.a_scale = b->d_norm; w.K = fi; w.N = fo;
+        wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
             gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
@@ -407,16 +445,19 @@ static bool sparse_bwd_ok(const gm_layout& L) {
 // Exact row-sparse backward (see gm_hparams_t.sparse_bwd).  The head is the only consumer of the last GCN layer, so
 // dQ_L lives on the centre rows; one transposed-aggregate step spreads it along the in-edges of the centres.  Every
 // product below is the dense backward's product with the structurally-zero terms removed.
-static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head) {
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     const int Lg = L.n_gcn, fiL = L.dims[Lg - 1], foL = L.dims[Lg];
-    HeadK k = make_head(c, params, pstride);
-    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, c.cG2);
-    GM_HIP(hipGetLastError());
+    if (!skip_head) {
+        HeadK k = make_head(c, params, pstride);
+        hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, c.cG2);
+        GM_HIP(hipGetLastError());
+    }
     // dW_L = sum_k norm[c_k] Z_L[c_k]^T G2[k] ; db_L = sum_k G2[k]
     gm_wgrad_args w{}; w.A = c.Z[Lg - 1]; w.lda = fiL; w.K = fiL; w.a_row = b->d_crow; w.a_scale = b->d_cnorm; w.G = c.cG2; w.ldg = foL; w.N = foL;
     w.chunks = b->d_c_chunks; w.n_chunks = b->n_c_chunks; w.set_chunk_off = b->d_c_set_chunk_off; w.sets = b->sets; w.partial = c.partial_c;
     w.dW = dparams + L.w_off[Lg - 1]; w.dw_stride = dstride; w.db = dparams + L.b_off[Lg - 1]; w.db_stride = dstride;
+    wgrad_sgd(w, c, Lg - 1);
     GM_TRY(gm_launch_wgrad(w, st));
     if (Lg == 1) return GM_OK;
     // T2[k] = norm[c_k] * (G2[k] W_L^T)
@@ -434,6 +475,7 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
     gm_wgrad_args w1{}; w1.A = c.Z[0]; w1.lda = f0; w1.K = f0; w1.a_row = b->d_e1_row; w1.a_scale = b->d_e1_norm; w1.G = c.cG1; w1.ldg = fiL; w1.N = fiL;
     w1.chunks = b->d_e1_chunks; w1.n_chunks = b->n_e1_chunks; w1.set_chunk_off = b->d_e1_set_chunk_off; w1.sets = b->sets; w1.partial = c.partial_c;
     w1.dW = dparams + L.w_off[0]; w1.dw_stride = dstride; w1.db = dparams + L.b_off[0]; w1.db_stride = dstride;
+    wgrad_sgd(w1, c, 0);
     GM_TRY(gm_launch_wgrad(w1, st));
     return GM_OK;
 }
@@ -451,7 +493,7 @@ static gm_agg_args cone_agg(const gm_cone* cn, const gm_cone_level& up, int tran
     return a;
 }
 
-static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1) {
+static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head) {
     const gm_layout& L = c.L; const gm_batch* b = c.b; const gm_cone* cn = c.cone;
     GM_REQUIRE(L.dims[0] == b->store->feat_dim, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
@@ -484,25 +526,29 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
         }
         xin = c.H[l];
     }
+    if (skip_head) return GM_OK;
     HeadK k = make_head(c, params, pstride);
     hipLaunchKernelGGL(k_head_fwd, dim3((b->subs + 3) / 4), dim3(256), 0, st, k, logits);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
 
-static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st) {
+static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head) {
     const gm_layout& L = c.L; const gm_batch* b = c.b; const gm_cone* cn = c.cone;
     const int Lg = L.n_gcn;
     float* dQ = c.bufA; float* T = c.bufB;
-    HeadK k = make_head(c, params, pstride);
-    hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, dQ);   // dQ_L on the centre rows
-    GM_HIP(hipGetLastError());
+    if (!skip_head) {
+        HeadK k = make_head(c, params, pstride);
+        hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, (float*)nullptr, dQ);   // dQ_L on the centre rows
+        GM_HIP(hipGetLastError());
+    }
     for (int l = Lg - 1; l >= 0; --l) {
         const gm_cone_level& lo = cn->lv[l]; const gm_cone_level& up = cn->lv[l + 1];
         const int fi = L.dims[l], fo = L.dims[l + 1];
         const float* maskprev = l > 0 ? c.H[l - 1] : nullptr;
         gm_wgrad_args w{}; w.sets = b->sets; w.partial = c.partial; w.K = fi; w.N = fo;
         w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
+        wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) on the source level ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
             gm_agg_args a = cone_agg(cn, up, 1);
@@ -511,7 +557,7 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
             w.A = l > 0 ? c.H[l - 1] : c.X0; w.lda = fi; w.a_scale = lo.d_norm; w.G = T; w.ldg = fo; w.db = nullptr;
             w.chunks = lo.d_chunks; w.n_chunks = lo.n_chunks; w.set_chunk_off = lo.d_set_chunk_off;
             GM_TRY(gm_launch_wgrad(w, st));
-            hipLaunchKernelGGL(k_colsum_rows, dim3(b->sets), dim3(256), 0, st, dQ, (int64_t)fo, fo, up.d_set_off, dparams + L.b_off[l], dstride);
+            hipLaunchKernelGGL(k_colsum_rows, dim3(b->sets), dim3(256), 0, st, dQ, (int64_t)fo, fo, up.d_set_off, dparams + L.b_off[l], dstride, c.sgd, L.b_off[l]);
             GM_HIP(hipGetLastError());
             if (l > 0) {
                 gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
@@ -590,7 +636,7 @@ static int class_tables(const gm_batch* b, const int32_t* y, int limit, std::vec
     return GM_OK;
 }
 
-static size_t proto_lds(int Ct, int n, int D) { return sizeof(float) * ((size_t)Ct * D + (size_t)Ct * n + 512); }
+static size_t proto_lds(int Ct, int n, int D, int nt = 256) { return sizeof(float) * ((size_t)Ct * D + (size_t)Ct * n + 2 * (size_t)nt); }
 
 static int launch_proto(const gm_batch* b, ProtoK k, hipStream_t st) {
     hipLaunchKernelGGL(k_proto, dim3(b->sets), dim3(256), proto_lds(k.Ct, k.n, k.D), st, k);
@@ -631,6 +677,28 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
     GM_HIP(hipStreamSynchronize(st));
     gm_dev_free(d_rows, st);
     return rc;
+}
+
+// Head forward + loss (+ head backward) in one launch (k_head_loss) after a gcn_forward(..., skip_head = 1).  With
+// bwd != 0 the matching gcn_backward(..., skip_head = 1) continues from dQ_L / the compact G2 written here; c.sgd (if
+// set) makes the head's own parameters take their SGD step in the same launch.
+static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* logits, const ProtoK& pk, int bwd, float* dparams, int64_t dstride, int sparse,
+                     hipStream_t st) {
+    const gm_batch* b = c.b; const gm_layout& L = c.L;
+    float* dQ = nullptr; float* Gc = nullptr;
+    if (bwd) {
+        if (c.cone) Gc = c.bufA;
+        else if (sparse && sparse_bwd_ok(L)) Gc = c.cG2;
+        else {
+            dQ = c.bufA;
+            GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[L.n_gcn], st));
+        }
+    }
+    HeadK hk = make_head(c, params, pstride);
+    hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), proto_lds(pk.Ct, pk.n, pk.D, HL_THREADS), st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
+                       bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f});
+    GM_HIP(hipGetLastError());
+    return GM_OK;
 }
 
 // ================================================================================ the fused meta-step
@@ -733,7 +801,6 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_HIP(hipStreamSynchronize(st));       // pageable host vectors: make the copies complete before they go out of scope
     gm_prof_reset();
     tm.lap("plan");
-    const int sgd_blocks = (int)std::min<int64_t>(2048, ((int64_t)T * L.P + 255) / 256);
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the
     // prototypes of step k-1.  The small latency-bound support kernels thus overlap the throughput-bound query work.
@@ -747,50 +814,58 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
 
     auto fw = [&](int k) -> float* { return p.fw + (int64_t)(k - 1) * p.TP; };       // fw_k, k = 1..K
     auto protos = [&](int k) -> float* { return p.protos + (int64_t)k * p.proto_sz; };   // prototypes of support step k
-    auto spt_loss = [&](int k) -> int {        // proto_loss_spt (meta.py:123,146): loss, prototypes, dlogits
-        GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
+    const int hoist = hp->hoist_z1, sparse = hp->sparse_bwd;
+    const SgdK no_sgd{nullptr, 0, nullptr, 0, 0.f};
+    // One support step (meta.py:122-126,145-151): forward -> [head + proto_loss_spt + head backward, one launch] -> backward,
+    // with the SGD step w_next = w - lr * grad written by the kernels that produce each gradient.
+    auto spt_step = [&](int k, const float* w, int64_t wstride, float* w_next) -> int {
+        GM_TRY(gcn_forward(p.S, w, wstride, p.logit_s, st, hoist, 1));
+        p.S.sgd = SgdK{w, wstride, w_next, Pp, hp->update_lr};
         ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr};
-        return launch_proto(spt, pk, st);
+        GM_TRY(head_loss(p.S, w, wstride, p.logit_s, pk, 1, p.g, Pp, sparse, st));
+        return GM_OK;
     };
-    auto qry_loss = [&](int col, int kproto, bool grad) -> int {   // proto_loss_qry (meta.py:132,139,154)
-        if (grad) GM_HIP(hipMemsetAsync(p.dlog_q, 0, sizeof(float) * qry->subs * C, sq));
+    auto spt_step_bwd = [&](const float* w, int64_t wstride) -> int {
+        GM_TRY(gcn_backward(p.S, w, wstride, p.dlog_s, p.g, Pp, st, sparse, 1));
+        p.S.sgd = no_sgd;
+        return GM_OK;
+    };
+    // One query evaluation (meta.py:129-141,152-154): forward on sq, then head + proto_loss_qry (+ head backward when the
+    // meta-gradient is wanted) once the prototypes / weights it needs are ready.
+    auto qry_fwd = [&](const float* w, int64_t wstride) -> int { return gcn_forward(p.Q, w, wstride, p.logit_q, sq, hoist, 1); };
+    auto qry_loss = [&](const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
         ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr};
-        return launch_proto(qry, pk, sq);
+        return head_loss(p.Q, w, wstride, p.logit_q, pk, grad ? 1 : 0, p.gq, Pp, sparse, sq);
     };
-    const int hoist = hp->hoist_z1;
     // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq
-    GM_TRY(gcn_forward(p.S, theta, 0, p.logit_s, st, hoist));
-    GM_TRY(spt_loss(0));
+    GM_TRY(spt_step(0, theta, 0, fw(1)));
     hipEvent_t e_proto0 = signal(st);
-    GM_TRY(gcn_backward(p.S, theta, 0, p.dlog_s, p.g, Pp, st, hp->sparse_bwd));
-    hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(1), theta, (int64_t)0, p.g, hp->update_lr, L.P, Pp, T);
+    GM_TRY(spt_step_bwd(theta, 0));
     hipEvent_t e_fw = signal(st);                          // fw_1 ready
-    GM_TRY(gcn_forward(p.Q, theta, 0, p.logit_q, sq, hoist));
+    GM_TRY(qry_fwd(theta, 0));
     wait(sq, e_proto0);
-    GM_TRY(qry_loss(0, 0, false));
+    GM_TRY(qry_loss(theta, 0, 0, 0, false));
     wait(sq, e_fw);
-    GM_TRY(gcn_forward(p.Q, fw(1), Pp, p.logit_q, sq, hoist));
-    GM_TRY(qry_loss(1, 0, false));
+    GM_TRY(qry_fwd(fw(1), Pp));
+    GM_TRY(qry_loss(fw(1), Pp, 1, 0, false));
     bool have_grad = false;
     for (int k = 1; k < K; ++k) {            // meta.py:143-157
-        GM_TRY(gcn_forward(p.S, fw(k), Pp, p.logit_s, st, hoist));
-        GM_TRY(spt_loss(k));
-        GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.g, Pp, st, hp->sparse_bwd));
-        hipLaunchKernelGGL(k_sgd, dim3(sgd_blocks), dim3(256), 0, st, fw(k + 1), fw(k), Pp, p.g, hp->update_lr, L.P, Pp, T);
+        GM_TRY(spt_step(k, fw(k), Pp, fw(k + 1)));
+        GM_TRY(spt_step_bwd(fw(k), Pp));
         e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
         wait(sq, e_fw);
-        GM_TRY(gcn_forward(p.Q, fw(k + 1), Pp, p.logit_q, sq, hoist));
+        GM_TRY(qry_fwd(fw(k + 1), Pp));
         const bool last = hp->need_meta_grad && k == K - 1;
-        GM_TRY(qry_loss(k + 1, k, last));
+        GM_TRY(qry_loss(fw(k + 1), Pp, k + 1, k, last));
         if (last) {
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
             // query forward (on sq) plus d L_q / d fw_{K-1} through the prototypes of the last support forward (on st).
             hipEvent_t e_dp = signal(sq);                  // dprotos ready
-            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq, hp->sparse_bwd));
+            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq, sparse, 1));
             wait(st, e_dp);
             GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
             hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, Ct, ns, C, p.dlog_s);
-            GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st, hp->sparse_bwd));
+            GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st, sparse));
             have_grad = true;
         }
     }

@@ -31,12 +31,15 @@ x = torch.randn(Q.rows, width, device='cuda'); out = torch.empty_like(x)
 norm = torch.empty(Q.rows, device='cuda'); 
 p = C.c_void_p(); lib.gm_batch_device_ptr(Q.handle, _lib.F_NORM, C.byref(p))
 bytes_ = lib.gm_aggregate_bytes(Q.handle, width)
+gather = int(os.environ.get('AGG_GATHER', '0'))       # 1: layer-1 mode, rows gathered from the store's feature table (width must be F0)
 for transposed in (0, 1):
+    if gather and transposed:
+        continue
     for rep in range(2):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 20
         for _ in range(n):
-            _lib.check(lib.gm_aggregate(Q.handle, transposed, 0, _lib.ptr(x), width, p, None, _lib.ptr(out), _lib.stream_ptr()))
+            _lib.check(lib.gm_aggregate(Q.handle, transposed, gather, None if gather else _lib.ptr(x), width, p, None, _lib.ptr(out), _lib.stream_ptr()))
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print('variant %s width %d transposed %d: %.3f ms  %.0f GB/s algorithmic (%.1f%% of 8 TB/s)' % (os.environ.get('GM_AGG_VARIANT', '0'), width, transposed,
           dt * 1e3, bytes_ / dt / 1e9, 100 * bytes_ / dt / 8e12))
