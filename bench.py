@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+MFMA_F32_PEAK_TFLOPS = 157.3        # dense fp32 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
@@ -131,9 +132,9 @@ def main():
 
     lib = _lib.lib()
 
-    def prof_read():
+    def prof_read(cat=0):       # 0 aggregate (bytes), 1 grouped GEMM (flops), 2 weight gradient (flops)
         ms, n, by = C.c_double(), C.c_int64(), C.c_int64()
-        lib.gm_profile_aggregate(C.byref(ms), C.byref(n), C.byref(by))
+        lib.gm_profile_read(cat, C.byref(ms), C.byref(n), C.byref(by))
         return ms.value, n.value, by.value
 
     for k in range(a.warmup):
@@ -161,6 +162,7 @@ def main():
     # the GPU on two streams, which stretches every kernel; the kernel-alone duration is measured on extra steps with
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
+    mm = {1: [0.0, 0, 0], 2: [0.0, 0, 0]}          # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         maml.serialize = 1
         step(0)
@@ -169,6 +171,9 @@ def main():
             step(k)
             ms, n, by = prof_read()
             agg_ms += ms; agg_n += n; agg_bytes += by
+            for cat in (1, 2):
+                ms, n, fl = prof_read(cat)
+                mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
         maml.serialize = 0
     lib.gm_profile_enable(0)
     # ---- secondary numbers: the flagged schedules that produce identical results without the structural zeros /
@@ -228,6 +233,16 @@ def main():
                                      '%d serialised steps run right after the timed region' % a.roofline_steps),
                          'achieved_while_overlapped': round(ov_bytes / (ov_ms * 1e-3) / 1e9, 1) if ov_ms > 0 else None},
         }
+        if mm[1][0] > 0:
+            def tf(c):
+                return round(mm[c][2] / (mm[c][0] * 1e-3) / 1e12, 1)
+            out['mfma'] = {'note': 'update GEMMs (exact fp32 v_mfma_f32_32x32x2_f32), HIP events around every launch of the same serialised steps as '
+                                   'the roofline; frac = achieved / 157.3 TFLOP/s dense fp32 matrix peak',
+                           'peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                           'gemm': {'achieved_tflops': tf(1), 'frac': round(tf(1) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[1][1],
+                                    'what': 'k_gemm_glds / k_gemm_nn: forward X@W and backward dZ = dQ@W^T'},
+                           'wgrad': {'achieved_tflops': tf(2), 'frac': round(tf(2) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[2][1],
+                                     'what': 'k_wgrad_fast + k_wgrad_reduce: dW = (norm*Z)^T dQ, db'}}
         if extra:
             out['extra'] = {'note': 'flagged exact schedules (same accs/meta-gradient, golden-tested); not the headline value', **extra}
         if not a.no_cpu_baseline and world == 1:           # rank 0 at N=1 only

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libgmeta_hip.so')
+LIB_PATH = os.environ.get('GMETA_HIP_LIB') or os.path.join(HERE, 'libgmeta_hip.so')      # override: kernel experiments with variant builds
 
 GM_MAX_GCN = 4
 (F_SUB_OFF, F_SET_SUB_OFF, F_PARENT, F_GRAPH, F_INDPTR, F_INDICES, F_INDPTR_T, F_INDICES_T, F_CENTRE, F_NORM,
@@ -53,6 +53,7 @@ PROTOTYPES = {
     'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     'gm_profile_enable': (None, [i32]),
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
+    'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),
 }
 
 _lib = None

@@ -79,49 +79,58 @@ extern "C" int64_t gm_model_param_count(const gm_model_t* m) {
     return L.P;
 }
 
-// ---------------------------------------------------------------- aggregate-launch profiling
-struct ProfState {
-    int on = 0;
+// ---------------------------------------------------------------- launch profiling (bench.py roofline / MFMA utilisation)
+// HIP events around every launch of a category, recorded on the stream the kernel is launched on.
+struct ProfCat {
     std::vector<hipEvent_t> ev;   // pairs
     size_t used = 0;
-    int64_t bytes = 0, launches = 0;
+    int64_t work = 0, launches = 0;
+    bool open = false;
 };
-static thread_local ProfState g_prof;
+static thread_local int g_prof_on = 0;
+static thread_local ProfCat g_prof[GM_PROF_CATS];
 
 extern "C" void gm_profile_enable(int32_t on) {
-    g_prof.on = on;
-    g_prof.used = 0; g_prof.bytes = 0; g_prof.launches = 0;
+    g_prof_on = on;
+    gm_prof_reset();
 }
-void gm_prof_reset() { g_prof.used = 0; g_prof.bytes = 0; g_prof.launches = 0; }
+void gm_prof_reset() { for (auto& c : g_prof) { c.used = 0; c.work = 0; c.launches = 0; c.open = false; } }
 
-void gm_prof_agg_begin(hipStream_t s, int64_t bytes) {
-    if (!g_prof.on) return;
-    if (g_prof.used + 2 > g_prof.ev.size()) {
+void gm_prof_begin(int cat, hipStream_t s, int64_t work) {
+    if (!g_prof_on) return;
+    ProfCat& c = g_prof[cat];
+    if (c.used + 2 > c.ev.size()) {
         hipEvent_t a, b;
         if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-        g_prof.ev.push_back(a); g_prof.ev.push_back(b);
+        c.ev.push_back(a); c.ev.push_back(b);
     }
-    (void)hipEventRecord(g_prof.ev[g_prof.used], s);
-    g_prof.bytes += bytes; g_prof.launches += 1;
+    (void)hipEventRecord(c.ev[c.used], s);
+    c.work += work; c.launches += 1; c.open = true;
 }
-void gm_prof_agg_end(hipStream_t s) {
-    if (!g_prof.on || g_prof.used + 2 > g_prof.ev.size()) return;
-    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], s);
-    g_prof.used += 2;
+void gm_prof_end(int cat, hipStream_t s) {
+    ProfCat& c = g_prof[cat];
+    if (!g_prof_on || !c.open) return;
+    (void)hipEventRecord(c.ev[c.used + 1], s);
+    c.used += 2; c.open = false;
 }
 
-extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes) {
+extern "C" int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work) {
+    GM_REQUIRE(category >= 0 && category < GM_PROF_CATS, GM_EINVAL, "profile_read: unknown category %d", category);
+    ProfCat& c = g_prof[category];
     double tot = 0;
-    for (size_t k = 0; k + 1 < g_prof.used + 1 && k + 1 < g_prof.ev.size() + 1 && k < g_prof.used; k += 2) {
-        GM_HIP(hipEventSynchronize(g_prof.ev[k + 1]));
+    for (size_t k = 0; k + 1 < c.used + 1 && k < c.used; k += 2) {
+        GM_HIP(hipEventSynchronize(c.ev[k + 1]));
         float ms = 0;
-        GM_HIP(hipEventElapsedTime(&ms, g_prof.ev[k], g_prof.ev[k + 1]));
+        GM_HIP(hipEventElapsedTime(&ms, c.ev[k], c.ev[k + 1]));
         tot += ms;
     }
     if (total_ms) *total_ms = tot;
-    if (launches) *launches = g_prof.launches;
-    if (algorithmic_bytes) *algorithmic_bytes = g_prof.bytes;
+    if (launches) *launches = c.launches;
+    if (work) *work = c.work;
     return GM_OK;
+}
+extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes) {
+    return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);
 }
 
 int gm_heavy_deg() {

@@ -175,9 +175,7 @@ static int upload(int32_t** d, const std::vector<int32_t>& v, hipStream_t s) {
 // GEMM row tiles and weight-gradient chunks of one level (never straddling two sets: each set has its own weights)
 static int level_tables(gm_cone_level& v, int sets, hipStream_t s) {
     std::vector<int32_t> tiles, chunks, coff(sets + 1, 0);
-    const int64_t target = 256;
-    int64_t cr = ((v.n + target - 1) / target + 31) / 32 * 32;
-    cr = std::max<int64_t>(128, cr);
+    const int64_t cr = gm_wgrad_chunk_rows(v.h_set_off);
     for (int t = 0; t < sets; ++t) {
         const int r0 = v.h_set_off[t], r1 = v.h_set_off[t + 1];
         for (int r = r0; r < r1; r += GM_GEMM_BM) { tiles.push_back(t); tiles.push_back(r); tiles.push_back(std::min(GM_GEMM_BM, r1 - r)); }

@@ -361,16 +361,13 @@ static void batch_free(gm_batch* b) {
 }
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
-// fast weights), weight-gradient chunks are sized so that a batch yields roughly 768 blocks.
+// fast weights); weight-gradient chunks are sized by gm_wgrad_chunk_rows.
 int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     gm_phase_timer tm("finalize");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
     for (int t = 0; t < b->sets; ++t)
         for (int k = b->h_set_sub_off[t]; k < b->h_set_sub_off[t + 1]; ++k) sub_set[k] = t;
-    // weight-gradient blocks run one per CU (128 accumulator VGPRs): aim at 256 (small batches) or 512 chunks
-    const int64_t target = b->rows >= 400000 ? 512 : 256;
-    int64_t cr = ((b->rows + target - 1) / target + 31) / 32 * 32;
-    cr = std::max<int64_t>(128, cr);
+    const int64_t cr = gm_wgrad_chunk_rows(b->h_set_row_off);
     for (int t = 0; t < b->sets; ++t) {
         const int r0 = b->h_set_row_off[t], r1 = b->h_set_row_off[t + 1];
         for (int r = r0; r < r1; r += GM_GEMM_BM) { tiles.push_back(t); tiles.push_back(r); tiles.push_back(std::min(GM_GEMM_BM, r1 - r)); }
@@ -429,13 +426,15 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     GM_TRY(gm_alloc(&b->d_e1_row, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_par, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_norm, b->n_e1, s));
     hipLaunchKernelGGL(k_centre_edges, dim3(b->n_c), dim3(64), 0, s, b->d_crow, d_eoff, b->n_c, b->d_indptr, b->d_indices, b->d_norm,
                        b->d_e1_row, b->d_e1_par, b->d_e1_norm);
-    std::vector<int32_t> ct, cc, ccoff(b->sets + 1, 0), ec, ecoff(b->sets + 1, 0);
+    std::vector<int32_t> ct, cc, ccoff(b->sets + 1, 0), ec, ecoff(b->sets + 1, 0), c_set_off(b->sets + 1), e_set_off(b->sets + 1);
+    for (int t = 0; t <= b->sets; ++t) { c_set_off[t] = b->h_set_sub_off[t] * nc; e_set_off[t] = eoff[b->h_set_sub_off[t] * nc]; }
+    const int ccr = gm_wgrad_chunk_rows(c_set_off), ecr = gm_wgrad_chunk_rows(e_set_off);
     for (int t = 0; t < b->sets; ++t) {
         const int k0 = b->h_set_sub_off[t] * nc, k1 = b->h_set_sub_off[t + 1] * nc;
         for (int k = k0; k < k1; k += GM_GEMM_BM) { ct.push_back(t); ct.push_back(k); ct.push_back(std::min(GM_GEMM_BM, k1 - k)); }
-        for (int k = k0; k < k1; k += 512) { cc.push_back(t); cc.push_back(k); cc.push_back(std::min(512, k1 - k)); }
+        for (int k = k0; k < k1; k += ccr) { cc.push_back(t); cc.push_back(k); cc.push_back(std::min(ccr, k1 - k)); }
         ccoff[t + 1] = (int32_t)(cc.size() / 3);
-        for (int q = eoff[k0]; q < eoff[k1]; q += 512) { ec.push_back(t); ec.push_back(q); ec.push_back(std::min(512, eoff[k1] - q)); }
+        for (int q = eoff[k0]; q < eoff[k1]; q += ecr) { ec.push_back(t); ec.push_back(q); ec.push_back(std::min(ecr, eoff[k1] - q)); }
         ecoff[t + 1] = (int32_t)(ec.size() / 3);
     }
     b->n_c_tiles = (int32_t)(ct.size() / 3); b->n_c_chunks = (int32_t)(cc.size() / 3); b->n_e1_chunks = (int32_t)(ec.size() / 3);

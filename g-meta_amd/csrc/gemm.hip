@@ -341,8 +341,15 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
     }
 }
 
+static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
+    gm_prof_begin(GM_PROF_GEMM, s, 2 * a.rows * a.K * a.N);
+    const int rc = launch_gemm_nn(a, s);
+    gm_prof_end(GM_PROF_GEMM, s);
+    return rc;
+}
+static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
             a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
@@ -527,6 +534,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
 // Specialised weight-gradient kernel: K = 32*TK, N = 32*TN known at compile time (the hidden sizes 64/128/256 of
 // the reference's configs), vectorised operands, no row indirection.  All per-thread staging coordinates are
 // stage-invariant, nothing spills, and the only waits on the prefetch loads sit after the MFMA loop.
+#ifndef GM_WG_SPLIT_NUM
+#define GM_WG_SPLIT_NUM 4      // eighths of a stage computed before the LDS store of the next one
+#endif
 template <int TK, int TN, int ZS>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
     constexpr int ldA = TK * 32, ldG = TN * 32, ld = ldA + ldG, ld4 = ld / 4;
@@ -607,10 +617,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_fast(WgradK w) {
 #pragma unroll
             for (int rr = 0; rr < RK; ++rr) bsum += S[rr * ld + ldA + tid];
         }
+        // the prefetched registers go to LDS after SPLIT of the stage's RK rows: the later, the longer the HBM round trip may take
+        constexpr int SPLIT = RK >= 16 ? (RK * GM_WG_SPLIT_NUM / 8) / 2 * 2 : RK / 2;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll 4
-            for (int kk = half * (RK / 2); kk < (half + 1) * (RK / 2); kk += 2) {
+            for (int kk = half ? SPLIT : 0; kk < (half ? RK : SPLIT); kk += 2) {
 #pragma unroll
                 for (int t = 0; t < NACC; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(S[kk * ld + aoff[t]], S[kk * ld + goff[t]], acc[t], 0, 0, 0);
@@ -637,7 +649,7 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     constexpr int RK = (16384 / ld) >= 32 ? 32 : (16384 / ld) >= 16 ? 16 : 8;
     constexpr int TPW = (TK * TN + WG_WAVES - 1) / WG_WAVES;
     int zs = 1;
-    while (zs < TPW && w.n_chunks * zs < 256) zs <<= 1;       // TPW is 1, 2 or 4
+    while (zs < TPW && w.n_chunks * zs < 192) zs <<= 1;       // TPW is 1, 2 or 4; chunk counts sit just under 256 by construction
     const size_t lds = 2 * RK * ld * sizeof(float);   // double-buffered stages
     static bool attr_done = false;
     if (!attr_done) {
@@ -680,7 +692,14 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
     }
 }
 
+static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
+    gm_prof_begin(GM_PROF_WGRAD, s, 2 * a.rows * a.K * a.N);
+    const int rc = launch_wgrad(a, s);
+    gm_prof_end(GM_PROF_WGRAD, s);
+    return rc;
+}
+static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off};
     if (a.n_chunks <= 0) {      // no rows at all: the gradients are zero
         const int tot0 = (a.K + 1) * a.N;

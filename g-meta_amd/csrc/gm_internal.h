@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
+#include <algorithm>
 #include "../../include/gmeta_hip.h"
 
 #define GM_WAVE 64
@@ -188,6 +189,7 @@ struct gm_gemm_args {
     const float* mask_h;                // optional [rows, ldc]: zero C where mask_h <= 0 (relu')
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
+    int64_t rows;                       // total rows covered by the tiles (profiling: flops = 2*rows*K*N)
 };
 #define GM_GEMM_BM 128
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
@@ -212,10 +214,42 @@ struct gm_wgrad_args {
     // optional fused inner-loop SGD (meta.py:126,151): next_t[off + j] = cur_t[off + j] - lr * grad, written together with the gradient
     const float* sgd_cur; int64_t sgd_cur_stride; float* sgd_next; int64_t sgd_next_stride; float sgd_lr;
     int64_t w_off, b_off;               // offsets of this layer's W and b inside a parameter vector
+    int64_t rows;                       // total rows covered by the chunks (profiling: flops = 2*rows*K*N)
 };
 #define GM_WGRAD_ROWS 1024
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 
-// profiling of aggregate launches (bench.py roofline)
-void gm_prof_agg_begin(hipStream_t s, int64_t bytes);
-void gm_prof_agg_end(hipStream_t s);
+// Rows per weight-gradient chunk for sets of the given sizes.  One workgroup (one CU: 128 accumulator VGPRs x 16 waves)
+// takes one chunk and writes a (K+1)xN partial, so the chunk count should sit just under a multiple of the 256 CUs --
+// 280 chunks cost two rounds for the work of 1.1 -- and be small: every chunk adds a partial to write and re-read.
+// Chunks never straddle two sets (per-task weights).  Returns a multiple of 32.
+static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n_cu = 256) {
+    const int sets = (int)set_off.size() - 1;
+    int64_t total = 0; int mx = 1;
+    for (int t = 0; t < sets; ++t) { const int n = set_off[t + 1] - set_off[t]; total += n; mx = n > mx ? n : mx; }
+    if (total <= 0) return 128;
+    auto chunks_at = [&](int cr) { int64_t c = 0; for (int t = 0; t < sets; ++t) c += (set_off[t + 1] - set_off[t] + cr - 1) / cr; return c; };
+    int best = 128; double best_eff = -1.0;
+    for (int rounds : {1, 2, 3, 4, 6, 8}) {
+        const int64_t cap = (int64_t)n_cu * rounds;
+        int lo = 1, hi = (mx + 31) / 32;                 // in units of 32 rows; chunks_at(32*hi) == #non-empty sets
+        if (chunks_at(32 * hi) > cap) continue;          // more sets than workgroup slots at this round count
+        while (lo < hi) { const int mid = (lo + hi) / 2; if (chunks_at(32 * mid) <= cap) hi = mid; else lo = mid + 1; }
+        const int cr = std::max(128, 32 * lo);
+        const int64_t c = chunks_at(cr);
+        const double eff = (double)total / ((double)((c + n_cu - 1) / n_cu) * n_cu * cr);   // useful rows / rows the rounds have room for
+        if (eff > best_eff + 0.03) { best_eff = eff; best = cr; }
+    }
+    return best;
+}
+
+// launch profiling by category (bench.py): work = algorithmic bytes (aggregate) or flops (GEMM, weight gradient)
+#define GM_PROF_AGG 0
+#define GM_PROF_GEMM 1
+#define GM_PROF_WGRAD 2
+#define GM_PROF_CATS 3
+void gm_prof_begin(int cat, hipStream_t s, int64_t work);
+void gm_prof_end(int cat, hipStream_t s);
+void gm_prof_reset();
+static inline void gm_prof_agg_begin(hipStream_t s, int64_t bytes) { gm_prof_begin(GM_PROF_AGG, s, bytes); }
+static inline void gm_prof_agg_end(hipStream_t s) { gm_prof_end(GM_PROF_AGG, s); }

@@ -7,7 +7,6 @@
 #include <stdlib.h>
 #include "gm_internal.h"
 
-void gm_prof_reset();
 
 // ================================================================================ small kernels
 __device__ __forceinline__ float wave_sumf(float v) {
@@ -348,7 +347,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             const float* A = xin; int64_t lda = fi;
             if (gather) { GM_TRY(gm_gather_features(b, c.X0, st)); A = c.X0; }
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
-            g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+            g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
             gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
@@ -367,7 +366,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 if (l == 0) c.z1_valid = 1;
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
-            g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+            g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
         xin = c.H[l];
@@ -400,7 +399,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         const int fi = L.dims[l], fo = L.dims[l + 1];
         const float* Xprev = l > 0 ? c.H[l - 1] : (c.x0_user ? c.x0_user : c.X0);
         const float* maskprev = l > 0 ? c.H[l - 1] : nullptr;
-        gm_wgrad_args w{}; w.chunks = b->d_chunks; w.n_chunks = b->n_chunks; w.set_chunk_off = b->d_set_chunk_off; w.sets = b->sets;
+        gm_wgrad_args w{}; w.chunks = b->d_chunks; w.n_chunks = b->n_chunks; w.set_chunk_off = b->d_set_chunk_off; w.sets = b->sets; w.rows = b->rows;
         w.partial = c.partial; w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
         w.a_scale = b->d_norm; w.K = fi; w.N = fo;
         wgrad_sgd(w, c, l);
@@ -414,7 +413,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
                 gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
-                g.row_scale = b->d_norm; g.mask_h = maskprev; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+                g.row_scale = b->d_norm; g.mask_h = maskprev; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 GM_TRY(gm_launch_gemm_nn(g, st));
             }
         } else {
@@ -423,7 +422,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
-                g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles;
+                g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
@@ -455,14 +454,14 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
     }
     // dW_L = sum_k norm[c_k] Z_L[c_k]^T G2[k] ; db_L = sum_k G2[k]
     gm_wgrad_args w{}; w.A = c.Z[Lg - 1]; w.lda = fiL; w.K = fiL; w.a_row = b->d_crow; w.a_scale = b->d_cnorm; w.G = c.cG2; w.ldg = foL; w.N = foL;
-    w.chunks = b->d_c_chunks; w.n_chunks = b->n_c_chunks; w.set_chunk_off = b->d_c_set_chunk_off; w.sets = b->sets; w.partial = c.partial_c;
+    w.rows = b->n_c; w.chunks = b->d_c_chunks; w.n_chunks = b->n_c_chunks; w.set_chunk_off = b->d_c_set_chunk_off; w.sets = b->sets; w.partial = c.partial_c;
     w.dW = dparams + L.w_off[Lg - 1]; w.dw_stride = dstride; w.db = dparams + L.b_off[Lg - 1]; w.db_stride = dstride;
     wgrad_sgd(w, c, Lg - 1);
     GM_TRY(gm_launch_wgrad(w, st));
     if (Lg == 1) return GM_OK;
     // T2[k] = norm[c_k] * (G2[k] W_L^T)
     gm_gemm_args g{}; g.A = c.cG2; g.lda = foL; g.B = params + L.w_off[Lg - 1]; g.b_stride = pstride; g.transB = 1; g.C = c.cT2; g.ldc = fiL; g.K = foL; g.N = fiL;
-    g.row_scale = b->d_cnorm; g.tiles = b->d_c_tiles; g.n_tiles = b->n_c_tiles;
+    g.row_scale = b->d_cnorm; g.tiles = b->d_c_tiles; g.n_tiles = b->n_c_tiles; g.rows = b->n_c;
     GM_TRY(gm_launch_gemm_nn(g, st));
     if (b->n_e1 > 0) {
         const int64_t tot = (int64_t)b->n_e1 * fiL;
@@ -473,7 +472,7 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
     // dW_1 = sum_e norm[u_e] Z_1[u_e]^T G1[e] ; db_1 = sum_e G1[e]   (a set without any centre in-edge gets zeros: empty chunk range)
     const int f0 = L.dims[0];
     gm_wgrad_args w1{}; w1.A = c.Z[0]; w1.lda = f0; w1.K = f0; w1.a_row = b->d_e1_row; w1.a_scale = b->d_e1_norm; w1.G = c.cG1; w1.ldg = fiL; w1.N = fiL;
-    w1.chunks = b->d_e1_chunks; w1.n_chunks = b->n_e1_chunks; w1.set_chunk_off = b->d_e1_set_chunk_off; w1.sets = b->sets; w1.partial = c.partial_c;
+    w1.rows = b->n_e1; w1.chunks = b->d_e1_chunks; w1.n_chunks = b->n_e1_chunks; w1.set_chunk_off = b->d_e1_set_chunk_off; w1.sets = b->sets; w1.partial = c.partial_c;
     w1.dW = dparams + L.w_off[0]; w1.dw_stride = dstride; w1.db = dparams + L.b_off[0]; w1.db_stride = dstride;
     wgrad_sgd(w1, c, 0);
     GM_TRY(gm_launch_wgrad(w1, st));
@@ -506,7 +505,7 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
             const float* A = xin;
             if (l == 0) { GM_TRY(gm_gather_rows(b->store, lo.d_feat_row, lo.n, c.X0, st)); A = c.X0; }
             gm_gemm_args g{}; g.A = A; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
-            g.row_scale = lo.d_norm; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles;
+            g.row_scale = lo.d_norm; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles; g.rows = lo.n;
             GM_TRY(gm_launch_gemm_nn(g, st));
             gm_agg_args a = cone_agg(cn, up, 0);
             a.x = c.Z[l]; a.ldx = fo; a.s_out = up.d_norm; a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = up.d_set_off; a.n_sets = b->sets;
@@ -521,7 +520,7 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
                 if (l == 0) c.z1_valid = 1;
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
-            g.row_scale = up.d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles;
+            g.row_scale = up.d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles; g.rows = up.n;
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
         xin = c.H[l];
@@ -555,23 +554,23 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
             a.x = dQ; a.ldx = fo; a.s_in = up.d_norm; a.out = T; a.rows = lo.n; a.width = fo;
             GM_TRY(gm_launch_aggregate(a, st));
             w.A = l > 0 ? c.H[l - 1] : c.X0; w.lda = fi; w.a_scale = lo.d_norm; w.G = T; w.ldg = fo; w.db = nullptr;
-            w.chunks = lo.d_chunks; w.n_chunks = lo.n_chunks; w.set_chunk_off = lo.d_set_chunk_off;
+            w.rows = lo.n; w.chunks = lo.d_chunks; w.n_chunks = lo.n_chunks; w.set_chunk_off = lo.d_set_chunk_off;
             GM_TRY(gm_launch_wgrad(w, st));
             hipLaunchKernelGGL(k_colsum_rows, dim3(b->sets), dim3(256), 0, st, dQ, (int64_t)fo, fo, up.d_set_off, dparams + L.b_off[l], dstride, c.sgd, L.b_off[l]);
             GM_HIP(hipGetLastError());
             if (l > 0) {
                 gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
-                g.row_scale = lo.d_norm; g.mask_h = maskprev; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles;
+                g.row_scale = lo.d_norm; g.mask_h = maskprev; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles; g.rows = lo.n;
                 GM_TRY(gm_launch_gemm_nn(g, st));
             }
         } else {
             // dW = (norm*Z)^T dQ ; db = colsum(dQ) ; dZ = norm * (dQ W^T) ; dQ_prev = relu'(H_prev) * norm * A^T dZ
             w.A = c.Z[l]; w.lda = fi; w.a_scale = up.d_norm; w.G = dQ; w.ldg = fo;
-            w.chunks = up.d_chunks; w.n_chunks = up.n_chunks; w.set_chunk_off = up.d_set_chunk_off;
+            w.rows = up.n; w.chunks = up.d_chunks; w.n_chunks = up.n_chunks; w.set_chunk_off = up.d_set_chunk_off;
             GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
-                g.row_scale = up.d_norm; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles;
+                g.row_scale = up.d_norm; g.tiles = up.d_tiles; g.n_tiles = up.n_tiles; g.rows = up.n;
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 gm_agg_args a = cone_agg(cn, up, 1);
                 a.x = T; a.ldx = fi; a.s_out = lo.d_norm; a.mask_h = maskprev; a.out = dQ; a.rows = lo.n; a.width = fi;

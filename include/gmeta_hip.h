@@ -192,6 +192,9 @@ int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_
  * recorded when gm_profile_enable(1) was called (they add a few microseconds per launch). */
 void gm_profile_enable(int32_t on);
 int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
+/* Same for one launch category: 0 = aggregate (work = algorithmic bytes), 1 = grouped GEMM (forward and dZ; work =
+ * flops 2*rows*K*N), 2 = weight gradient incl. its reduction (work = flops). */
+int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 
 #ifdef __cplusplus
 }
