@@ -371,6 +371,9 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     int bn = a.N > 128 ? 256 : a.N > 64 ? 128 : 64;
     if (bn > bn_cap) bn = bn_cap;
     while (bn > 64 && (int64_t)a.n_tiles * ((a.N + bn - 1) / bn) < 512) bn >>= 1;
+    static int mid_tiles = -1;           // below this many row tiles a 256-wide tile grid is only a few rounds deep: halve the tile (shorter tail)
+    if (mid_tiles < 0) { const char* e = getenv("GM_GEMM_MID_TILES"); mid_tiles = e ? atoi(e) : 1536; }
+    if (bn == 256 && a.n_tiles < mid_tiles) bn = 128;
     g.n_col_tiles = (a.N + bn - 1) / bn;
     static int use_glds = -1;
     if (use_glds < 0) { const char* e = getenv("GM_GEMM_GLDS"); use_glds = e ? atoi(e) : 1; }
