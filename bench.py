@@ -145,10 +145,14 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ov_ms, ov_n, ov_bytes = 0.0, 0, 0
+    ov_mm = {1: [0.0, 0, 0], 2: [0.0, 0, 0]}
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
+        for cat in (1, 2):
+            ms, n, fl = prof_read(cat)
+            ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -162,7 +166,7 @@ def main():
     # the GPU on two streams, which stretches every kernel; the kernel-alone duration is measured on extra steps with
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
-    mm = {1: [0.0, 0, 0], 2: [0.0, 0, 0]}          # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
+    mm = ov_mm if a.serialize else {1: [0.0, 0, 0], 2: [0.0, 0, 0]}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         maml.serialize = 1
         step(0)
