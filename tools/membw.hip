@@ -41,6 +41,40 @@ __global__ __launch_bounds__(256) void k_chunkcopy(const f4v* __restrict__ in, f
 #pragma unroll
     for (int u = 0; u < UNR; ++u) if (r0 + u * RPW < rows) { if (NT_ST) __builtin_nontemporal_store(v[u], out + (r0 + u * RPW) * 64 + col); else out[(r0 + u * RPW) * 64 + col] = v[u]; }
 }
+// LDS-staged per-subgraph copy: one 1024-thread workgroup per block of SUB rows walks the row's 256 floats in CW-float
+// column chunks: chunk c+1 is loaded into registers while chunk c is served from LDS (rows permuted = the gather) and
+// written out.  The shape an LDS-staged per-subgraph aggregate would have.
+template <int CW, int SUB, int NT_ST>
+__global__ __launch_bounds__(1024) void k_subcopy(const f4v* __restrict__ in, f4v* __restrict__ out, const int* __restrict__ perm, size_t rows) {
+    constexpr int LPR = CW / 4, PER = SUB * LPR, PF = (PER + 1023) / 1024, NCH = 256 / CW;
+    extern __shared__ f4v lds[];                       // 2 buffers of SUB * LPR float4
+    const size_t r0 = (size_t)blockIdx.x * SUB;
+    const int tid = threadIdx.x;
+    f4v pf[PF];
+    auto load = [&](int c) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) { const int id = tid + p * 1024; const int r = id / LPR, l = id % LPR; if (id < PER && r0 + r < rows) pf[p] = in[(r0 + r) * 64 + c * LPR + l]; }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) { const int id = tid + p * 1024; if (id < PER) lds[b * PER + id] = pf[p]; }
+    };
+    load(0); stash(0); __syncthreads();
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) load(c + 1);
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int id = tid + p * 1024; const int r = id / LPR, l = id % LPR;
+            if (id < PER && r0 + r < rows) {
+                const int src = perm[r0 + r] - (int)r0;                 // permuted inside the block
+                const f4v v = lds[(c & 1) * PER + src * LPR + l];
+                if (NT_ST) __builtin_nontemporal_store(v, out + (r0 + r) * 64 + c * LPR + l); else out[(r0 + r) * 64 + c * LPR + l] = v;
+            }
+        }
+        if (c + 1 < NCH) stash((c + 1) & 1);
+        __syncthreads();
+    }
+}
 template <int UNR>
 __global__ __launch_bounds__(256) void k_read(const f4v* __restrict__ in, float* sink, size_t n4) {
     size_t i = (size_t)blockIdx.x * 256 * UNR + threadIdx.x;
@@ -93,6 +127,21 @@ int main(int argc, char** argv) {
     TIME("chunk copy 256-B segments  unr4 st", 2 * n4 * 16, hipLaunchKernelGGL((k_chunkcopy<64, 4, 0>), GC(64, 4), dim3(256), 0, 0, a, b, rows));
     TIME("chunk copy 128-B segments  unr4 st-nt", 2 * n4 * 16, hipLaunchKernelGGL((k_chunkcopy<32, 4, 1>), GC(32, 4), dim3(256), 0, 0, a, b, rows));
     TIME("chunk copy 512-B segments  unr2 st-nt", 2 * n4 * 16, hipLaunchKernelGGL((k_chunkcopy<128, 2, 1>), GC(128, 2), dim3(256), 0, 0, a, b, rows));
+    {   // rows permuted inside blocks of 512 rows for the LDS-staged variants
+        std::vector<int> h(rows);
+        for (size_t r = 0; r < rows; ++r) h[r] = (int)r;
+        srand(1); for (size_t w0 = 0; w0 + 512 <= rows; w0 += 512) for (int i = 511; i > 0; --i) { int j = rand() % (i + 1); std::swap(h[w0 + i], h[w0 + j]); }
+        hipMemcpy(perm, h.data(), rows * 4, hipMemcpyHostToDevice);
+        const unsigned nb = (unsigned)((rows + 511) / 512);
+        hipFuncSetAttribute((const void*)k_subcopy<64, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_subcopy<32, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_subcopy<32, 512, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute((const void*)k_subcopy<16, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        TIME("LDS-staged sub copy CW=64 (256-B) 512 rows", 2 * n4 * 16, hipLaunchKernelGGL((k_subcopy<64, 512, 1>), dim3(nb), dim3(1024), 2 * 512 * 16 * 16, 0, a, b, perm, rows));
+        TIME("LDS-staged sub copy CW=32 (128-B) 512 rows", 2 * n4 * 16, hipLaunchKernelGGL((k_subcopy<32, 512, 1>), dim3(nb), dim3(1024), 2 * 512 * 8 * 16, 0, a, b, perm, rows));
+        TIME("LDS-staged sub copy CW=32 st (no nt)      ", 2 * n4 * 16, hipLaunchKernelGGL((k_subcopy<32, 512, 0>), dim3(nb), dim3(1024), 2 * 512 * 8 * 16, 0, a, b, perm, rows));
+        TIME("LDS-staged sub copy CW=16 (64-B)  512 rows", 2 * n4 * 16, hipLaunchKernelGGL((k_subcopy<16, 512, 1>), dim3(nb), dim3(1024), 2 * 512 * 4 * 16, 0, a, b, perm, rows));
+    }
     for (int W : {1, 512, 4096}) {          // W = 1: identity; else rows shuffled inside windows of W rows (subgraph-local gather)
         std::vector<int> h(rows);
         for (size_t r = 0; r < rows; ++r) h[r] = (int)r;
