@@ -26,14 +26,20 @@ __device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) 
     return k.compact ? (int64_t)s * k.nc + which : (int64_t)k.sub_off[s] + k.centre[s * k.nc + which];
 }
 
+// Row of the last GCN activation at centre `which` of subgraph s: from the LDS copy hs (rows of the set starting at
+// subgraph s0, centre order) when the fused kernel staged one, else from H.
+__device__ __forceinline__ const float* centre_feat(const HeadK& k, int s, int which, const float* hs, int s0) {
+    return hs ? hs + ((int64_t)(s - s0) * k.nc + which) * k.Hd : k.H + centre_row(k, s, which) * k.ldh;
+}
+
 // Optional fused inner-loop SGD (meta.py:126,151): next_t[j] = cur_t[j] - lr * grad_t[j], written with the gradient.
 struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; };
 
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
-__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits) {
+__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits, const float* hs = nullptr, int s0 = 0) {
     const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
-    const float* h0 = k.H + centre_row(k, s, 0) * k.ldh;
-    const float* h1 = k.nc == 2 ? k.H + centre_row(k, s, 1) * k.ldh : nullptr;
+    const float* h0 = centre_feat(k, s, 0, hs, s0);
+    const float* h1 = k.nc == 2 ? centre_feat(k, s, 1, hs, s0) : nullptr;
     for (int c = 0; c < k.C; ++c) {
         const float* w = P + k.wl_off + (int64_t)c * k.hc;
         float acc = 0.f;
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
 template <int NT>
 __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
-                                             float* Gc, const SgdK& u) {
+                                             float* Gc, const SgdK& u, const float* hs = nullptr) {
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
     float* D = dparams + (int64_t)set * dstride;
@@ -59,7 +65,7 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         const int c = id / k.hc, h = id - c * k.hc;
         float acc = 0.f;
         for (int s = s0; s < s1; ++s) {
-            const float hv = h < k.Hd ? k.H[centre_row(k, s, 0) * k.ldh + h] : k.H[centre_row(k, s, 1) * k.ldh + h - k.Hd];
+            const float hv = h < k.Hd ? centre_feat(k, s, 0, hs, s0)[h] : centre_feat(k, s, 1, hs, s0)[h - k.Hd];
             acc += dlogits[(int64_t)s * k.C + c] * hv;
         }
         D[k.wl_off + id] = acc;
@@ -77,9 +83,9 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         for (int which = 0; which < k.nc; ++which) {
             float v = 0.f;
             for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
-            const int64_t at = centre_row(k, s, which) * k.ldh + col;
-            if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = k.H[at] > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
-            else if (k.H[at] > 0.f) dQ[at] += v;
+            const float hval = centre_feat(k, s, which, hs, s0)[col];
+            if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
+            else if (hval > 0.f) dQ[centre_row(k, s, which) * k.ldh + col] += v;
         }
     }
 }
@@ -186,17 +192,28 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
 // five launches between the last GCN layer of a forward and the first weight gradient of its backward, in one.
 #define HL_THREADS 1024
 __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
-                                                          float* Gc, SgdK u) {
+                                                          float* Gc, SgdK u, int stage_h, int proto_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int set = blockIdx.x, tid = threadIdx.x;
     const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1];
-    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, logits);
+    // the set's centre rows of H_L (a few KB) are read three times below (logits, dWl, relu' mask): keep them in LDS
+    float* hs = nullptr;
+    if (stage_h) {
+        hs = sm + proto_floats;
+        const int tot = (s1 - s0) * hk.nc * hk.Hd;
+        for (int id = tid; id < tot; id += HL_THREADS) {
+            const int q = id / hk.Hd, col = id - q * hk.Hd;
+            hs[id] = hk.H[centre_row(hk, s0 + q / hk.nc, q % hk.nc) * hk.ldh + col];
+        }
+        __syncthreads();
+    }
+    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, logits, hs, s0);
     if (pk.dlogits) for (int id = tid; id < (s1 - s0) * pk.D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * pk.D + id] = 0.f;   // rows outside the class tables
     __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
     proto_set<HL_THREADS>(pk, set, tid, sm);
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<HL_THREADS>(hk, set, tid, pk.dlogits, dparams, dstride, dQ, Gc, u);
+    head_bwd_set<HL_THREADS>(hk, set, tid, pk.dlogits, dparams, dstride, dQ, Gc, u, hs);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -694,8 +711,16 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
         }
     }
     HeadK hk = make_head(c, params, pstride);
-    hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), proto_lds(pk.Ct, pk.n, pk.D, HL_THREADS), st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
-                       bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f});
+    const size_t proto_bytes = (proto_lds(pk.Ct, pk.n, pk.D, HL_THREADS) + 15) / 16 * 16;
+    int max_subs = 0;
+    for (int t = 0; t < b->sets; ++t) max_subs = std::max(max_subs, b->h_set_sub_off[t + 1] - b->h_set_sub_off[t]);
+    const size_t hs_bytes = sizeof(float) * (size_t)max_subs * b->centres * L.dims[L.n_gcn];
+    const int stage_h = proto_bytes + hs_bytes <= 150 * 1024;
+    const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
+    static bool attr = false;
+    if (!attr) { GM_HIP(hipFuncSetAttribute((const void*)k_head_loss, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
+                       bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f}, stage_h, (int)(proto_bytes / sizeof(float)));
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
