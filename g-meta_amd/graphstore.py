@@ -55,6 +55,7 @@ class GraphStore:
         self.handle = h
         self.n_graphs, self.n_nodes, self.feat_dim = G, ns, F0
         self.n_edges = [int(p[-1]) for p in ptrs]
+        self.host_csr = list(zip(ptrs, idxs))      # host copy of the in-edge CSR (Subgraphs(sample_mode='reference') walks it like sdp.py:301)
 
     def close(self):
         if getattr(self, 'handle', None):

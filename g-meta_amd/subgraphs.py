@@ -4,6 +4,7 @@ h-hop extraction, sampling, induced-subgraph build and batching done by HIP kern
 import collections
 import csv
 import ctypes as C
+import itertools
 import os
 import random
 
@@ -203,8 +204,17 @@ class Subgraphs(Dataset):
     (create_batch_*) follows sdp.py:150-292; `tables=` can replace the CSV files by in-memory
     {'train': (names, labels)} style dictionaries (names 'g_i' or 'g_i_j', labels as in the CSV)."""
 
-    def __init__(self, root, mode, subgraph2label, n_way, k_shot, k_query, batchsz, args, adjs, h, tables=None, verbose=True):
+    def __init__(self, root, mode, subgraph2label, n_way, k_shot, k_query, batchsz, args, adjs, h, tables=None, verbose=True, sample_mode=None):
         self.batchsz, self.n_way, self.k_shot, self.k_query = batchsz, n_way, k_shot, k_query
+        # 'device' (default): neighbourhoods above sample_nodes are thinned by the keyed permutation in gm_extract.
+        # 'reference': the node sets the REFERENCE would draw for the same global-RNG history (sdp.py:312-314,337-339):
+        # the oversize neighbourhood is rebuilt on the host in the reference's list order, passed through a CPython set
+        # and np.random.choice exactly like sdp.py:300-313, memoised per name like sdp.py:296-297,319; the GPU then builds
+        # the induced subgraphs from those sets (gm_batch_from_nodes).  For reproducing reference runs, not for speed.
+        self.sample_mode = sample_mode or getattr(args, 'sample_mode', 'device')
+        if self.sample_mode not in ('device', 'reference'):
+            raise ValueError("sample_mode must be 'device' or 'reference'")
+        self._ref_memo = {}
         self.setsz, self.querysz = n_way * k_shot, n_way * k_query            # sdp.py:20-21
         self.h = h
         self.sample_nodes = args.sample_nodes
@@ -365,22 +375,90 @@ class Subgraphs(Dataset):
         return (bs, ys, bq, yq, torch.from_numpy(bs.centres_local().astype(np.int64)), torch.from_numpy(bq.centres_local().astype(np.int64)),
                 bs.node_lists(), bq.node_lists(), bs.graph_ids().tolist(), bq.graph_ids().tolist())
 
+    # ---- reference-order sampling replay (sample_mode='reference')
+    def _in(self, g, v):
+        ip, ix = self.G.host_csr[g]
+        return ix[ip[v]:ip[v + 1]].tolist()                                   # [n.item() for n in G.in_edges(v)[0]] (sdp.py:301)
+
+    def _reference_nodes(self, name, g, i, j):
+        """The sorted node array the reference keeps for an OVERSIZE neighbourhood; consumes np.random like sdp.py:313."""
+        if name in self._ref_memo:
+            return self._ref_memo[name]
+        chain = itertools.chain
+        if self.link_pred_mode:                                               # sdp.py:327-335 (j side: 1 hop, the sdp.py:332 quirk)
+            f_hop = self._in(g, i)
+            n_l = [self._in(g, u) for u in f_hop]
+            a1 = np.array(list(set([x for sub in n_l for x in sub] + f_hop + [i])), np.int64)
+            f_hop = self._in(g, j)
+            n_l = [self._in(g, j) for _ in f_hop]
+            a2 = np.array(list(set([x for sub in n_l for x in sub] + f_hop + [j])), np.int64)
+            arr, keep = np.union1d(a1, a2), [i, j]
+        else:
+            f_hop = self._in(g, i)
+            if self.h == 1:                                                   # sdp.py:304-306
+                arr = np.array(list(set(f_hop + [i])), np.int64)
+            elif self.h == 2:                                                 # sdp.py:300-303
+                n_l = [self._in(g, u) for u in f_hop]
+                arr = np.array(list(set(list(chain(*n_l)) + f_hop + [i])), np.int64)
+            elif self.h == 3:                                                 # sdp.py:307-311
+                n_2 = [self._in(g, u) for u in f_hop]
+                n_3 = [self._in(g, u) for u in list(chain(*n_2))]
+                arr = np.array(list(set(list(chain(*n_2)) + list(chain(*n_3)) + f_hop + [i])), np.int64)
+            else:
+                raise ValueError('the reference defines h in {1, 2, 3} (sdp.py:300-311)')
+            keep = [i]
+        if arr.shape[0] <= self.sample_nodes:
+            raise RuntimeError('reference replay: %s is not oversize on the host (%d nodes) but was on the device' % (name, arr.shape[0]))
+        arr = np.random.choice(arr, self.sample_nodes, replace=False)         # sdp.py:313 / 338 -- the global numpy RNG
+        arr = np.unique(np.append(arr, keep)).astype(np.int32)                # sdp.py:314 / 339
+        self._ref_memo[name] = arr
+        return arr
+
+    def _extract_reference(self, tasks):
+        """tasks: [(spt_seeds, spt_names, qry_seeds, qry_names)] in visiting order.  Returns (S, Q) batches holding the
+        reference's node sets; the RNG is consumed task by task, support items before query items, like __getitem__
+        (sdp.py:363-386), once per name."""
+        seeds = np.concatenate([np.concatenate([t[0], t[2]]) for t in tasks])
+        names = [n for t in tasks for n in (list(t[1]) + list(t[3]))]
+        full = SubgraphBatch.extract(self.G, seeds, [0, len(seeds)], self.h, 2 ** 30, self.rng_seed, self.link_pred_mode)     # no sampling
+        off, par = full.sub_off, full.parent()
+        lists = []
+        for k, (name, (g, i, j)) in enumerate(zip(names, seeds.tolist())):
+            if off[k + 1] - off[k] > self.sample_nodes:
+                lists.append(self._reference_nodes(name, g, i, j))
+            else:
+                lists.append(par[off[k]:off[k + 1]])
+        pos, ls, lq = 0, [], []
+        for t in tasks:
+            ls += lists[pos:pos + len(t[0])]; pos += len(t[0])
+            lq += lists[pos:pos + len(t[2])]; pos += len(t[2])
+        off_s = np.cumsum([0] + [len(t[0]) for t in tasks]); off_q = np.cumsum([0] + [len(t[2]) for t in tasks])
+        S = SubgraphBatch.from_nodes(self.G, np.concatenate([t[0] for t in tasks]), off_s, ls, self.link_pred_mode)
+        Q = SubgraphBatch.from_nodes(self.G, np.concatenate([t[2] for t in tasks]), off_q, lq, self.link_pred_mode)
+        return S, Q
+
+    def _extract_tasks(self, indices):
+        arrs = [self._task_arrays(i) for i in indices]
+        if self.sample_mode == 'reference':
+            names = [self._task_names(i) for i in indices]
+            S, Q = self._extract_reference([(a[0], n[0], a[1], n[1]) for a, n in zip(arrs, names)])
+            return arrs, S, Q
+        off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
+        S = SubgraphBatch.extract(self.G, np.concatenate([a[0] for a in arrs]), off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        Q = SubgraphBatch.extract(self.G, np.concatenate([a[1] for a in arrs]), off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        return arrs, S, Q
+
     def __getitem__(self, index):
         """One task (sdp.py:348-408): the 10-tuple with SubgraphBatch handles in slots 0 and 2."""
-        seeds_s, seeds_q, lab_s, lab_q = self._task_arrays(index)
-        ys, yq = self._labels(lab_s, lab_q)
-        bs = SubgraphBatch.extract(self.G, seeds_s, [0, len(seeds_s)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
-        bq = SubgraphBatch.extract(self.G, seeds_q, [0, len(seeds_q)], self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        arrs, bs, bq = self._extract_tasks([index])
+        ys, yq = self._labels(arrs[0][2], arrs[0][3])
         return self._tuple(bs, bq, ys, yq)
 
     def get_batch(self, indices):
         """MI355X-first counterpart of DataLoader(..., collate_fn=collate): the subgraphs of ALL tasks of a
         meta-batch are extracted by two launches (support / query); returns the collated 10-tuple of lists."""
-        arrs = [self._task_arrays(i) for i in indices]
+        arrs, S, Q = self._extract_tasks(indices)
         ys_yq = [self._labels(a[2], a[3]) for a in arrs]
-        off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
-        S = SubgraphBatch.extract(self.G, np.concatenate([a[0] for a in arrs]), off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
-        Q = SubgraphBatch.extract(self.G, np.concatenate([a[1] for a in arrs]), off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
         return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])
 
     def batches(self, index_lists, prefetch=1, cone_layers=0):

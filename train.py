@@ -51,6 +51,8 @@ def parse(argv=None):
     ap.add_argument('--link_pred_mode', default='False', type=str)
     ap.add_argument('--h', default=2, type=int)
     ap.add_argument('--sample_nodes', type=int, default=1000)
+    ap.add_argument('--sample_mode', default='device', choices=['device', 'reference'],
+                    help="'reference': draw oversize neighbourhoods exactly like the reference (global numpy RNG, CPython set order); slow, for reproducing its runs")
     ap.add_argument('--eval_tasks', type=int, default=100, help='validation / test tasks (the reference hard-codes 100, train.py:90-91)')
     # schedules of the MI355X build that return the same results faster (include/gmeta_hip.h, gm_hparams_t); 0 = as the reference computes
     ap.add_argument('--hoist_z1', type=int, default=0, help='1: aggregate the layer-1 input once per meta-step instead of in every forward')
