@@ -15,6 +15,7 @@ struct AggK {
     const int32_t* indptr; const int32_t* indices; const float* x; const int32_t* x_row; int64_t ldx;
     const float* s_in; const float* s_out; const float* mask_h; const float* bias; int64_t bias_stride;
     const int32_t* set_row_off; int n_sets; int relu; float* out; int64_t rows; int width; int nblocks;
+    const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* heavy; int n_heavy, heavy_deg;
     int nt;                    // 1: non-temporal output stores (Z is not re-read by this kernel; keep L2 for the X gathers)
     int win;                   // rows per wave window (64 for big batches; smaller when the batch would underfill the chip)
@@ -80,8 +81,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
             float v = (vget(acc0, k) + vget(acc1, k)) * so;
             if (a.bias) v += a.bias[(int64_t)set * a.bias_stride + c0 + k];
             if (a.relu) v = v < 0.f ? 0.f : v;      // NaN propagates like torch relu (meta.py:163 guard)
-            if (a.mask_h) v = a.mask_h[row * a.width + c0 + k] > 0.f ? v : 0.f;
+            if (a.mask_b) v = ((a.mask_b[(row * a.width + c0) >> 2] >> k) & 1u) ? v : 0.f;      // VEC == 4 only (launcher)
+            else if (a.mask_h) v = a.mask_h[row * a.width + c0 + k] > 0.f ? v : 0.f;
             vset(res, k, v);
+        }
+        if (a.relu_bits) {                          // VEC == 4 only (launcher)
+            unsigned bits = 0;
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) bits |= (vget(res, k) > 0.f ? 1u : 0u) << k;
+            a.relu_bits[(row * a.width + c0) >> 2] = (uint8_t)bits;
         }
         *reinterpret_cast<V*>(a.out + row * a.width + c0) = res;
     }
@@ -146,10 +154,14 @@ __global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
         float4 v = make_float4(s4.x * so, s4.y * so, s4.z * so, s4.w * so);
         if (bp) { const float4 bb = *reinterpret_cast<const float4*>(bp + c * LPR * 4); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
         if (a.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
-        if (a.mask_h) {
+        if (a.mask_b) {
+            const unsigned m = a.mask_b[((int64_t)row * a.width + l * 4 + c * LPR * 4) >> 2];
+            v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+        } else if (a.mask_h) {
             const float4 m = *reinterpret_cast<const float4*>(a.mask_h + (int64_t)row * a.width + l * 4 + c * LPR * 4);
             v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         }
+        if (a.relu_bits) a.relu_bits[((int64_t)row * a.width + l * 4 + c * LPR * 4) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
         *reinterpret_cast<float4*>(a.out + (int64_t)row * a.width + l * 4 + c * LPR * 4) = v;
     }
 }
@@ -248,10 +260,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
                 float4 v = make_float4(acc[k][c].x * s_, acc[k][c].y * s_, acc[k][c].z * s_, acc[k][c].w * s_);
                 if (bp) { const float4 bb = *reinterpret_cast<const float4*>(bp + c * LPR * 4); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
                 if (a.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
-                if (a.mask_h) {
+                if (a.mask_b) {
+                    const unsigned m = a.mask_b[(row * a.width + l * 4 + c * LPR * 4) >> 2];
+                    v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+                } else if (a.mask_h) {
                     const float4 m = *reinterpret_cast<const float4*>(a.mask_h + row * a.width + l * 4 + c * LPR * 4);
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                 }
+                if (a.relu_bits) a.relu_bits[(row * a.width + l * 4 + c * LPR * 4) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
                 float4* dst = reinterpret_cast<float4*>(a.out + row * a.width + l * 4 + c * LPR * 4);
                 if (a.nt) {
                     typedef float f4v __attribute__((ext_vector_type(4)));
@@ -309,10 +325,11 @@ static int agg_variant() {
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
-           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.heavy, g.n_heavy, g.heavy_deg, agg_nt(), 64};
+           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg, agg_nt(), 64};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
+    GM_REQUIRE(!(g.mask_b || g.relu_bits) || vec4, GM_EINVAL, "aggregate: packed relu masks need width %% 4 == 0 and 16-byte aligned operands");
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
     if (!win) { a.heavy = nullptr; a.n_heavy = 0; }      // the generic kernel walks every row itself
     if (win) {

@@ -15,6 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 struct GemmK {
     const float* A; int64_t lda; const float* B; int64_t b_stride; int transB; float* C; int64_t ldc; int K, N;
     const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
+    const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec, c_vec; int nt_store;
 };
 
@@ -183,10 +184,14 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
             if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }   // NaN propagates like torch relu
             float* dst = g.C + row * g.ldc + col;
             if (g.c_vec) {
-                if (g.mask_h) {
+                if (g.mask_b) {
+                    const unsigned m = g.mask_b[(row * g.ldc + col) >> 2];
+                    v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+                } else if (g.mask_h) {
                     const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
                     v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
                 }
+                if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
                 *reinterpret_cast<float4*>(dst) = v;
             } else {
                 const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -332,6 +337,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
                 const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
                 v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
             }
+            if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
             if (g.nt_store) {     // C is re-read by the NEXT kernel only (>> L2): keep L2 for the A rows and the weights
                 typedef float f4v __attribute__((ext_vector_type(4)));
                 f4v vv = {v.x, v.y, v.z, v.w};
@@ -351,11 +357,12 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
 }
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
-            a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
+            a.mask_b, a.relu_bits, a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
     g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
     g.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.mask_h || (((uintptr_t)a.mask_h & 15) == 0));
     const bool vec = g.a_vec && g.b_vec && a.K >= 4 && a.N >= 4;
+    GM_REQUIRE(!(a.mask_b || a.relu_bits) || g.c_vec, GM_EINVAL, "gemm: packed relu masks need 16-byte aligned C with N %% 4 == 0");
 #define GM_LAUNCH_GEMM(WC_, THREADS_)                                                                                         \
     do {                                                                                                                      \
         const dim3 grid(g.n_tiles * g.n_col_tiles), blk(THREADS_);                                                            \
@@ -381,7 +388,7 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     static int nts = -1;
     if (nts < 0) { const char* e = getenv("GM_GEMM_NT"); nts = e ? atoi(e) : 1; }
     g.nt_store = nts;
-    if (use_glds && vec && !a.transB && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
+    if (use_glds && vec && !a.transB && !a.mask_b && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
         const dim3 grid(g.n_tiles * g.n_col_tiles);
         if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);
         else if (bn == 128) hipLaunchKernelGGL((k_gemm_glds<2>), grid, dim3(256), 0, s, g);

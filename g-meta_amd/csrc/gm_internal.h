@@ -161,6 +161,8 @@ struct gm_agg_args {
     const float* s_in;         // optional per-source scale
     const float* s_out;        // optional per-destination scale
     const float* mask_h;       // optional [rows, width]: zero the output where mask_h <= 0 (relu')
+    const uint8_t* mask_b;     // same mask, packed: byte (row*width + col)/4 holds the relu' bits of 4 consecutive columns
+    uint8_t* relu_bits;        // optional output: packed relu' bits of `out` (written with relu; width % 4 == 0)
     const float* bias;         // optional per-set bias (bias + set*bias_stride) -- matmul-first layers
     int64_t bias_stride;
     const int32_t* set_row_off;// required when bias != NULL and bias_stride != 0: row range of every set
@@ -187,6 +189,8 @@ struct gm_gemm_args {
     const float* bias; int64_t bias_stride;   // optional per-set bias [N]
     int relu;
     const float* mask_h;                // optional [rows, ldc]: zero C where mask_h <= 0 (relu')
+    const uint8_t* mask_b;              // same mask packed, byte (row*ldc + col)/4 = bits of 4 consecutive columns (needs vector stores)
+    uint8_t* relu_bits;                 // optional output: packed relu' bits of C (with relu; N % 4 == 0, ldc == N)
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
     int64_t rows;                       // total rows covered by the tiles (profiling: flops = 2*rows*K*N)

@@ -278,6 +278,7 @@ struct Carver {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    uint8_t* M[GM_MAX_GCN];      // packed relu' bits of H[l] (one byte per 4 columns): what the backward reads instead of H[l] (dense schedule)
     float* cG2; float* cT2; float* cG1; float* partial_c;      // compact matrices of the row-sparse backward
     const float* x0_user; const int32_t* centre; int z1_valid;
     int zw[GM_MAX_GCN];
@@ -317,6 +318,7 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
         c.zw[l] = fi > fo ? fo : fi;
         c.Z[l] = cv.take<float>(rows * c.zw[l]);
         c.H[l] = cv.take<float>(rows * fo);
+        c.M[l] = (fo % 4 == 0 && l + 1 < L.n_gcn) ? cv.take<uint8_t>(rows * fo / 4) : nullptr;
         maxd = std::max(maxd, std::max(fi, fo));
         maxkn = std::max<int64_t>(maxkn, (int64_t)(fi + 1) * fo);
     }
@@ -368,7 +370,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             GM_TRY(gm_launch_gemm_nn(g, st));
             gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
-            a.out = c.H[l]; a.rows = b->rows; a.width = fo;
+            a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -384,6 +386,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
+            g.relu_bits = c.M[l];
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
         xin = c.H[l];
@@ -416,6 +419,8 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         const int fi = L.dims[l], fo = L.dims[l + 1];
         const float* Xprev = l > 0 ? c.H[l - 1] : (c.x0_user ? c.x0_user : c.X0);
         const float* maskprev = l > 0 ? c.H[l - 1] : nullptr;
+        const uint8_t* maskbits = l > 0 ? c.M[l - 1] : nullptr;           // packed relu'(H_{l-1}): 1/16 of the bytes of H_{l-1}
+        if (maskbits) maskprev = nullptr;
         gm_wgrad_args w{}; w.chunks = b->d_chunks; w.n_chunks = b->n_chunks; w.set_chunk_off = b->d_set_chunk_off; w.sets = b->sets; w.rows = b->rows;
         w.partial = c.partial; w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
         w.a_scale = b->d_norm; w.K = fi; w.N = fo;
@@ -430,7 +435,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
                 gm_gemm_args g{}; g.A = T; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = dQ; g.ldc = fi; g.K = fo; g.N = fi;
-                g.row_scale = b->d_norm; g.mask_h = maskprev; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
+                g.row_scale = b->d_norm; g.mask_h = maskprev; g.mask_b = maskbits; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 GM_TRY(gm_launch_gemm_nn(g, st));
             }
         } else {
@@ -441,7 +446,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 GM_TRY(gm_launch_gemm_nn(g, st));
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
