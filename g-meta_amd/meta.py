@@ -94,8 +94,11 @@ class Meta(nn.Module):
 
     def _workspace(self, nbytes, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
+            had = self._ws is not None
             self._ws = None
-            self._ws = torch.empty(int(nbytes * 1.05) + 4096, dtype=torch.uint8, device=dev)
+            if had:                       # rare (a larger meta-batch than any before): hand the old block back instead of
+                torch.cuda.empty_cache()  # leaving it parked in torch's caching allocator next to the new, larger one
+            self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         return self._ws
 
     def _run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
