@@ -80,6 +80,7 @@ def main():
     ap.add_argument('--cone', type=int, default=0, help='1: time the flagged receptive-field schedule (layer l only on the rows that reach a centre)')
     ap.add_argument('--serialize', type=int, default=0, help='1: run the timed region on one stream (what the rocprofv3 per-kernel summaries use)')
     ap.add_argument('--extra_steps', type=int, default=3, help='steps per flagged exact schedule reported under "extra" (N=1 only; 0 = skip)')
+    ap.add_argument('--e2e_steps', type=int, default=10, help='N=1 only: extra steps with a FRESH extraction per step (prefetched on a second thread), reported under "end_to_end"; 0 = skip')
     ap.add_argument('--roofline_steps', type=int, default=2, help='extra serialised steps after the timed region for the per-kernel roofline')
     a = ap.parse_args()
 
@@ -113,7 +114,7 @@ def main():
     maml = gmeta_amd.Meta(args, config).to('cuda')
     maml.force_allreduce = os.environ.get('GMETA_FORCE_DIST') == '1' and os.environ.get('GMETA_SKIP_ALLREDUCE') != '1'
     db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'],
-                             batchsz=T * a.n_batches, args=args, adjs=store, h=cfg['h'],
+                             batchsz=T * (a.n_batches + (a.e2e_steps + 2 if world == 1 else 0)), args=args, adjs=store, h=cfg['h'],
                              tables={'train': (data['names'], data['labels'])}, verbose=False)
     per = T // world
     batches, ext_ms = [], []
@@ -204,6 +205,21 @@ def main():
             lv[side] = {'batch_rows': int(x.rows), 'batch_edges': int(x.edges), 'level_rows': list(nr), 'level_edges': list(ne)}
         extra['cone']['receptive_field'] = lv
 
+    # ---- end to end ("report also with extraction included"): every step extracts its own meta-batch
+    e2e = None
+    if world == 1 and a.e2e_steps > 0:
+        lists = [list(range((a.n_batches + k) * T, (a.n_batches + k + 1) * T)) for k in range(a.e2e_steps + 2)]
+        it = iter(db.batches(lists, prefetch=1))
+        for _ in range(2):
+            maml(*next(it), data['feats'])
+        torch.cuda.synchronize(); te = time.perf_counter()
+        for _ in range(a.e2e_steps):
+            maml(*next(it), data['feats'])
+        torch.cuda.synchronize()
+        ms_e = (time.perf_counter() - te) / a.e2e_steps * 1e3
+        e2e = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1), 'steps': a.e2e_steps,
+               'what': 'Subgraphs.get_batch (h-hop extraction + sampling + induced batch on the GPU, prefetched one step ahead on a second '
+                       'thread/stream) + Meta.forward per step; same schedule as `value`'}
     if rank == 0:
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), see profiles/
@@ -247,6 +263,8 @@ def main():
                                     'what': 'k_gemm_glds / k_gemm_nn: forward X@W and backward dZ = dQ@W^T'},
                            'wgrad': {'achieved_tflops': tf(2), 'frac': round(tf(2) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[2][1],
                                      'what': 'k_wgrad_fast + k_wgrad_reduce: dW = (norm*Z)^T dQ, db'}}
+        if e2e:
+            out['end_to_end'] = e2e
         if extra:
             out['extra'] = {'note': 'flagged exact schedules (same accs/meta-gradient, golden-tested); not the headline value', **extra}
         if not a.no_cpu_baseline and world == 1:           # rank 0 at N=1 only
