@@ -215,7 +215,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_nn(GemmK g) {
 // b128 fragment reads are 4-way bank conflicted -- irrelevant next to 64-cycle f32 MFMAs), B tile [16][64*WC].
 template <int WC>
 __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
-    constexpr int NT = 128 * WC, NW = 2 * WC, BN = 64 * WC;
+    constexpr int NW = 2 * WC, BN = 64 * WC;
     constexpr int A_FLOATS = GM_GEMM_BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;
     constexpr int EP_LD = 68, EPI_FLOATS = NW * 32 * EP_LD;
     constexpr int MAIN_FLOATS = 3 * STAGE > EPI_FLOATS ? 3 * STAGE : EPI_FLOATS;
