@@ -224,7 +224,7 @@ def main():
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), see profiles/
         tp = os.path.join(ROOT, 'profiles', 'agg_traffic.json')
-        if os.path.exists(tp):
+        if os.path.exists(tp) and a.config == 'arxiv' and not a.task_num:      # the PMC passes were taken on the default workload
             try:
                 traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
             except Exception:
@@ -233,7 +233,8 @@ def main():
             'metric': 'meta-tasks/sec (inner-loop fwd+bwd) at task_num=%d' % T, 'value': round(T / (ms_per_step * 1e-3), 3),
             'unit': 'meta-tasks/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'BASELINE configs[1]: arxiv-ogbn shape (synthetic PA graph N=%d m=%d, F0=%d), Disjoint, h=%d, hidden=%d, '
+            'config': {'workload': ('BASELINE configs[1]: arxiv-ogbn shape' if a.config == 'arxiv' else 'BASELINE configs[0]: synthetic plumbing case') +
+                                   ' (synthetic PA graph N=%d m=%d, F0=%d), Disjoint, h=%d, hidden=%d, '
                                    '%d-way %d-shot %d-qry, task_num=%d, update_step=%d, sample_nodes=%d; subgraphs pre-extracted in HBM'
                                    % (cfg['n'], cfg['m'], cfg['F0'], cfg['h'], cfg['hidden'], cfg['n_way'], cfg['k_spt'], cfg['k_qry'], T,
                                       cfg['update_step'], cfg['sample_nodes']),
