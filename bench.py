@@ -224,7 +224,7 @@ def main():
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), see profiles/
         tp = os.path.join(ROOT, 'profiles', 'agg_traffic.json')
-        if os.path.exists(tp) and a.config == 'arxiv' and not a.task_num:      # the PMC passes were taken on the default workload
+        if os.path.exists(tp) and a.config == 'arxiv' and not a.task_num and world == 1:      # the PMC passes were taken on the default workload
             try:
                 traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
             except Exception:
