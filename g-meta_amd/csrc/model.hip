@@ -237,6 +237,19 @@ __global__ void k_expand_edges(const float* T2, const float* H1, int F, const in
     }
 }
 
+// WT[t][k][n] = W_t[n][k]: the dZ GEMM (dQ @ W^T) then runs as a plain row-major product on the DMA-fed kernel.
+// W_t = params + t*pstride + w_off, [fi, fo] row-major; WT_t [fo, fi].  32x32 tiles through LDS, grid (fo/32, fi/32, sets).
+__global__ __launch_bounds__(256) void k_transpose_w(const float* params, int64_t pstride, int64_t w_off, int fi, int fo, float* WT) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const float* W = params + (int64_t)t * pstride + w_off;
+    float* O = WT + (int64_t)t * fi * fo;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const int n = n0 + r, k = k0 + tx; tile[r][tx] = (n < fi && k < fo) ? W[(int64_t)n * fo + k] : 0.f; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int k = k0 + r, n = n0 + tx; if (k < fo && n < fi) O[(int64_t)k * fi + n] = tile[tx][r]; }
+}
+
 // db[set, n] = sum over the set's rows [set_off[set], set_off[set+1]) of G[row, n]   (cone schedule, multiply-first layers)
 __global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t* set_off, float* db, int64_t db_stride, SgdK u, int64_t b_off) {
     const int set = blockIdx.x, r0 = set_off[set], r1 = set_off[set + 1];
@@ -278,6 +291,7 @@ struct Carver {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    float* WT;                   // per-task transposed weights of the layer whose dZ GEMM is running (dense backward)
     uint8_t* M[GM_MAX_GCN];      // packed relu' bits of H[l] (one byte per 4 columns): what the backward reads instead of H[l] (dense schedule)
     float* cG2; float* cT2; float* cG1; float* partial_c;      // compact matrices of the row-sparse backward
     const float* x0_user; const int32_t* centre; int z1_valid;
@@ -326,6 +340,7 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
     c.bufA = cv.take<float>(rows * maxd);
     c.bufB = cv.take<float>(rows * maxd);
     c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
+    c.WT = cv.take<float>((int64_t)c.b->sets * maxkn);
     c.cG2 = cv.take<float>((int64_t)c.b->n_c * maxd); c.cT2 = cv.take<float>((int64_t)c.b->n_c * maxd);
     c.cG1 = cv.take<float>((int64_t)c.b->n_e1 * maxd);
     c.partial_c = cv.take<float>((int64_t)std::max(c.b->n_c_chunks, c.b->n_e1_chunks) * maxkn);
@@ -443,8 +458,17 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             w.A = c.Z[l]; w.lda = fi; w.G = dQ; w.ldg = fo;
             GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
-                gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
+                gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
+                static int dz_glds = -1;
+                if (dz_glds < 0) { const char* e = getenv("GM_DZ_GLDS"); dz_glds = e ? atoi(e) : 1; }
+                if (dz_glds && c.WT && fi % 64 == 0 && fo % 16 == 0) {
+                    // dZ = dQ @ W^T through the direct-to-LDS kernel: transpose the (T x 256 KB) weights once, then a plain product
+                    const int nt = pstride ? b->sets : 1;             // shared theta (step 0): one transpose serves every task
+                    hipLaunchKernelGGL(k_transpose_w, dim3((fo + 31) / 32, (fi + 31) / 32, nt), dim3(256), 0, st, params, pstride, L.w_off[l], fi, fo, c.WT);
+                    GM_HIP(hipGetLastError());
+                    g.B = c.WT; g.b_stride = pstride ? (int64_t)fi * fo : 0; g.transB = 0;
+                } else { g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; }
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
