@@ -6,7 +6,7 @@ set -u
 tag=${1:-final}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python bench.py --warmup 1 --no_cpu_baseline --extra_steps 0"
+B="python bench.py --warmup 1 --no_cpu_baseline --extra_steps 0 --e2e_steps 0"
 db() { find "$1" -name '*.db' | head -1; }
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/p_ser -o x -- $B --serialize 1 --steps 3 > $out/${tag}_serialized_bench.log 2>&1
 python tools/prof_summary.py "$(db $out/p_ser)" > $out/${tag}_serialized_kernel_stats.txt
@@ -23,3 +23,4 @@ python tools/pmc_summary.py "$(db $out/p_sq)" > $out/${tag}_pmc_sq.txt
 grep -h '^{' $out/${tag}_serialized_bench.log $out/${tag}_two_stream_bench.log | cut -c1-400
 head -6 $out/${tag}_serialized_kernel_stats.txt | cut -c1-150
 cat $out/${tag}_agg_traffic.json
+rm -rf $out/p_ser $out/p_two $out/p_f $out/p_w $out/p_sq      # only the summaries travel back (gpurun merges <= 64 MiB)
