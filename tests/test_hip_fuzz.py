@@ -115,3 +115,50 @@ def test_random_multigraph_matches_oracle(seed):
         np.testing.assert_allclose(g, og_flat, atol=TOL * scale, rtol=1e-3, err_msg=name)
         # accuracies are argmax decisions: equal unless two distances tie within noise
         assert np.abs(np.asarray(accs) - np.asarray(oaccs)).max() <= 1.0 / (C * k_qry) + 1e-9, name
+
+
+@pytest.mark.parametrize('dims', [[512, 128, 128], [64, 512, 512], [100, 300, 60], [2048, 64]])
+def test_wide_and_odd_layer_shapes_match_oracle(dims):
+    """Shapes outside the specialised kernels' sweet spot (Fold-PPI's 512 -> 128 multiply-first layer, 512-wide hidden
+    layers, widths that are not multiples of 32, the 2048 limit): generic kernels, same results."""
+    import gmeta_amd
+    from gmeta_amd.subgraphs import SubgraphBatch
+    rng = np.random.default_rng(77)
+    n_gcn = len(dims) - 1
+    graphs = [_graph(rng, 90)]
+    feats = [(0.3 * rng.standard_normal((90, dims[0]))).astype(np.float32)]
+    T, C, k_spt, k_qry, h = 2, 2, 2, 3, 2
+    store = gmeta_amd.GraphStore(graphs, feats)
+    og = [orc.Graph(*g) for g in graphs]
+    mk = lambda cnt: np.array([(0, int(rng.integers(0, 90)), -1) for _ in range(cnt)], np.int32)      # noqa: E731
+    spt_seeds = [mk(C * k_spt) for _ in range(T)]; qry_seeds = [mk(C * k_qry) for _ in range(T)]
+    ys = [np.repeat(np.arange(C), k_spt).astype(np.int32) for _ in range(T)]
+    yq = [np.repeat(np.arange(C), k_qry).astype(np.int32) for _ in range(T)]
+    S = SubgraphBatch.extract(store, np.concatenate(spt_seeds), np.arange(T + 1) * C * k_spt, h, 1000, 222, False)
+    Q = SubgraphBatch.extract(store, np.concatenate(qry_seeds), np.arange(T + 1) * C * k_qry, h, 1000, 222, False)
+    ospt = [orc.extract_batch(og, s, h, 1000, 222, False) for s in spt_seeds]
+    oqry = [orc.extract_batch(og, s, h, 1000, 222, False) for s in qry_seeds]
+    config = [('GraphConv', [dims[l], dims[l + 1]]) for l in range(n_gcn)] + [('Linear', [dims[-1], C])]
+    args = argparse.Namespace(update_lr=0.02, meta_lr=1e-3, n_way=C, k_spt=k_spt, k_qry=k_qry, task_num=T, update_step=2, update_step_test=2,
+                              method='G-Meta', sample_nodes=1000, link_pred_mode='False', task_setup='Shared', h=h)
+    theta0 = None
+    for kw in ({}, dict(cone=1)):
+        torch.manual_seed(3)
+        m = gmeta_amd.Meta(args, config).to('cuda')
+        for k, v in kw.items():
+            setattr(m, k, v)
+        if theta0 is None:
+            theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+            theta0 = [t if t.ndim > 1 else (rng.uniform(0.15, 0.4, size=t.shape) * rng.choice([-1.0, 1.0], size=t.shape)).astype(np.float32) for t in theta0]
+        with torch.no_grad():
+            for p_, v_ in zip(m.net.parameters(), theta0):
+                p_.copy_(torch.from_numpy(v_))
+        grads = {}
+        orig = m.meta_optim.step
+        m.meta_optim.step = lambda *a, _g=grads, _m=m, _o=orig, **k: (_g.setdefault('g', torch.cat([p.grad.reshape(-1) for p in _m.net.parameters()]).cpu().numpy().copy()), _o(*a, **k))[1]
+        m(S.views(), [torch.from_numpy(y.astype(np.int64)) for y in ys], Q.views(), [torch.from_numpy(y.astype(np.int64)) for y in yq],
+          None, None, None, None, None, None, feats)
+        oaccs, ograd, _, lq = orc.meta_step(og, feats, ospt, oqry, ys, yq, theta0, config, k_spt, 0.02, 1e-3, 2, adam_state={})
+        og_flat = np.concatenate([g.reshape(-1) for g in ograd])
+        np.testing.assert_allclose(m.last_stats['losses_q'], lq, atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(grads['g'], og_flat, atol=TOL * max(1.0, float(np.abs(og_flat).max())), rtol=1e-3)
