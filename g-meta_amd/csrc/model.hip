@@ -36,16 +36,17 @@ __device__ __forceinline__ const float* centre_feat(const HeadK& k, int s, int w
 struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; };
 
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
-__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits, const float* hs = nullptr, int s0 = 0) {
+__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits, const float* hs = nullptr, int s0 = 0,
+                                             const float* wl_s = nullptr) {          // wl_s: LDS copy of [Wl (C x hc) | bl (C)] of the set
     const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
     const float* h0 = centre_feat(k, s, 0, hs, s0);
     const float* h1 = k.nc == 2 ? centre_feat(k, s, 1, hs, s0) : nullptr;
     for (int c = 0; c < k.C; ++c) {
-        const float* w = P + k.wl_off + (int64_t)c * k.hc;
+        const float* w = wl_s ? wl_s + c * k.hc : P + k.wl_off + (int64_t)c * k.hc;
         float acc = 0.f;
         for (int h = lane; h < k.hc; h += 64) acc += (h < k.Hd ? h0[h] : h1[h - k.Hd]) * w[h];
         acc = wave_sumf(acc);
-        if (lane == 0) logits[(int64_t)s * k.C + c] = acc + P[k.bl_off + c];
+        if (lane == 0) logits[(int64_t)s * k.C + c] = acc + (wl_s ? wl_s[k.C * k.hc + c] : P[k.bl_off + c]);
     }
 }
 __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
@@ -57,9 +58,10 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
 template <int NT>
 __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
-                                             float* Gc, const SgdK& u, const float* hs = nullptr) {
+                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr) {
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
+    const float* WL = wl_s ? wl_s : P + k.wl_off;                     // [C, hc]
     float* D = dparams + (int64_t)set * dstride;
     for (int id = tid; id < k.C * k.hc; id += NT) {
         const int c = id / k.hc, h = id - c * k.hc;
@@ -82,7 +84,7 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         const int s = s0 + id / k.Hd, col = id % k.Hd;
         for (int which = 0; which < k.nc; ++which) {
             float v = 0.f;
-            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * P[k.wl_off + (int64_t)c * k.hc + which * k.Hd + col];
+            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * WL[(int64_t)c * k.hc + which * k.Hd + col];
             const float hval = centre_feat(k, s, which, hs, s0)[col];
             if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
             else if (hval > 0.f) dQ[centre_row(k, s, which) * k.ldh + col] += v;
@@ -192,28 +194,47 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
 // five launches between the last GCN layer of a forward and the first weight gradient of its backward, in one.
 #define HL_THREADS 1024
 __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
-                                                          float* Gc, SgdK u, int stage_h, int proto_floats) {
+                                                          float* Gc, SgdK u, int stage, int proto_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int set = blockIdx.x, tid = threadIdx.x;
-    const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1];
-    // the set's centre rows of H_L (a few KB) are read three times below (logits, dWl, relu' mask): keep them in LDS
-    float* hs = nullptr;
-    if (stage_h) {
+    const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1], S = s1 - s0, D = pk.D;
+    // stage != 0: everything the three phases share stays in LDS -- the set's centre rows of H_L, its head weights, its
+    // logits and dlogits -- so that a phase costs LDS latency instead of an L2 round trip (the kernel is pure latency)
+    float *hs = nullptr, *wl_s = nullptr;
+    float* lg = logits; float* dl = pk.dlogits;
+    if (stage) {
         hs = sm + proto_floats;
-        const int tot = (s1 - s0) * hk.nc * hk.Hd;
-        for (int id = tid; id < tot; id += HL_THREADS) {
+        wl_s = hs + (int64_t)S * hk.nc * hk.Hd;
+        float* lg_s = wl_s + hk.C * hk.hc + hk.C;
+        float* dl_s = lg_s + S * D;
+        const float* P = hk.params + (int64_t)set * hk.pstride;
+        for (int id = tid; id < S * hk.nc * hk.Hd; id += HL_THREADS) {
             const int q = id / hk.Hd, col = id - q * hk.Hd;
             hs[id] = hk.H[centre_row(hk, s0 + q / hk.nc, q % hk.nc) * hk.ldh + col];
         }
+        for (int id = tid; id < hk.C * hk.hc; id += HL_THREADS) wl_s[id] = P[hk.wl_off + id];
+        for (int id = tid; id < hk.C; id += HL_THREADS) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
+        lg = lg_s - (int64_t)s0 * D;            // indexed by the global subgraph id like the global arrays
+        if (pk.dlogits) { dl = dl_s - (int64_t)s0 * D; for (int id = tid; id < S * D; id += HL_THREADS) dl_s[id] = 0.f; }
         __syncthreads();
+    } else if (pk.dlogits) {
+        for (int id = tid; id < S * D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
     }
-    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, logits, hs, s0);
-    if (pk.dlogits) for (int id = tid; id < (s1 - s0) * pk.D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * pk.D + id] = 0.f;   // rows outside the class tables
+    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s);
     __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
-    proto_set<HL_THREADS>(pk, set, tid, sm);
+    ProtoK pl = pk;
+    pl.logits = lg; pl.dlogits = dl;
+    proto_set<HL_THREADS>(pl, set, tid, sm);
+    if (stage) {              // the global copies (API / debugging): logits always, dlogits when requested
+        __syncthreads();
+        for (int id = tid; id < S * D; id += HL_THREADS) {
+            logits[(int64_t)s0 * D + id] = lg[(int64_t)s0 * D + id];
+            if (pk.dlogits) pk.dlogits[(int64_t)s0 * D + id] = dl[(int64_t)s0 * D + id];
+        }
+    }
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<HL_THREADS>(hk, set, tid, pk.dlogits, dparams, dstride, dQ, Gc, u, hs);
+    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -743,8 +764,10 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     const size_t proto_bytes = (proto_lds(pk.Ct, pk.n, pk.D, HL_THREADS) + 15) / 16 * 16;
     int max_subs = 0;
     for (int t = 0; t < b->sets; ++t) max_subs = std::max(max_subs, b->h_set_sub_off[t + 1] - b->h_set_sub_off[t]);
-    const size_t hs_bytes = sizeof(float) * (size_t)max_subs * b->centres * L.dims[L.n_gcn];
-    const int stage_h = proto_bytes + hs_bytes <= 150 * 1024;
+    const size_t hs_bytes = sizeof(float) * ((size_t)max_subs * b->centres * L.dims[L.n_gcn] + (size_t)L.n_out * (L.hc + 1) + 2 * (size_t)max_subs * L.n_out);
+    static int stage_on = -1;
+    if (stage_on < 0) { const char* e = getenv("GM_HEAD_STAGE"); stage_on = e ? atoi(e) : 1; }
+    const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
     const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
     static bool attr = false;
     if (!attr) { GM_HIP(hipFuncSetAttribute((const void*)k_head_loss, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
