@@ -209,7 +209,7 @@ def main():
     e2e = None
     if world == 1 and a.e2e_steps > 0:
         lists = [list(range((a.n_batches + k) * T, (a.n_batches + k + 1) * T)) for k in range(a.e2e_steps + 2)]
-        it = iter(db.batches(lists, prefetch=1))
+        it = iter(db.batches(lists, prefetch=1, cone_layers=cfg['h'] if a.cone else 0))
         for _ in range(2):
             maml(*next(it), data['feats'])
         torch.cuda.synchronize(); te = time.perf_counter()
