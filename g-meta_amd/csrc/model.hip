@@ -37,7 +37,7 @@ struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_st
 
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
 __device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits, const float* hs = nullptr, int s0 = 0,
-                                             const float* wl_s = nullptr) {          // wl_s: LDS copy of [Wl (C x hc) | bl (C)] of the set
+                                             const float* wl_s = nullptr, int lbase = 0) {   // wl_s: LDS copy of [Wl | bl]; logits holds subgraphs [lbase, ..)
     const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
     const float* h0 = centre_feat(k, s, 0, hs, s0);
     const float* h1 = k.nc == 2 ? centre_feat(k, s, 1, hs, s0) : nullptr;
@@ -46,7 +46,7 @@ __device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, fl
         float acc = 0.f;
         for (int h = lane; h < k.hc; h += 64) acc += (h < k.Hd ? h0[h] : h1[h - k.Hd]) * w[h];
         acc = wave_sumf(acc);
-        if (lane == 0) logits[(int64_t)s * k.C + c] = acc + (wl_s ? wl_s[k.C * k.hc + c] : P[k.bl_off + c]);
+        if (lane == 0) logits[(int64_t)(s - lbase) * k.C + c] = acc + (wl_s ? wl_s[k.C * k.hc + c] : P[k.bl_off + c]);
     }
 }
 __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
 template <int NT>
 __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
-                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr) {
+                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr, int dbase = 0) {     // dlogits holds subgraphs [dbase, ..)
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
     const float* WL = wl_s ? wl_s : P + k.wl_off;                     // [C, hc]
@@ -68,14 +68,14 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         float acc = 0.f;
         for (int s = s0; s < s1; ++s) {
             const float hv = h < k.Hd ? centre_feat(k, s, 0, hs, s0)[h] : centre_feat(k, s, 1, hs, s0)[h - k.Hd];
-            acc += dlogits[(int64_t)s * k.C + c] * hv;
+            acc += dlogits[(int64_t)(s - dbase) * k.C + c] * hv;
         }
         D[k.wl_off + id] = acc;
         if (u.next) u.next[(int64_t)set * u.next_stride + k.wl_off + id] = u.cur[(int64_t)set * u.cur_stride + k.wl_off + id] - u.lr * acc;
     }
     for (int c = tid; c < k.C; c += NT) {
         float acc = 0.f;
-        for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)s * k.C + c];
+        for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)(s - dbase) * k.C + c];
         D[k.bl_off + c] = acc;
         if (u.next) u.next[(int64_t)set * u.next_stride + k.bl_off + c] = u.cur[(int64_t)set * u.cur_stride + k.bl_off + c] - u.lr * acc;
     }
@@ -84,7 +84,7 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         const int s = s0 + id / k.Hd, col = id % k.Hd;
         for (int which = 0; which < k.nc; ++which) {
             float v = 0.f;
-            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)s * k.C + c] * WL[(int64_t)c * k.hc + which * k.Hd + col];
+            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)(s - dbase) * k.C + c] * WL[(int64_t)c * k.hc + which * k.Hd + col];
             const float hval = centre_feat(k, s, which, hs, s0)[col];
             if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
             else if (hval > 0.f) dQ[centre_row(k, s, which) * k.ldh + col] += v;
@@ -101,7 +101,8 @@ struct ProtoK {
     const float* logits; int D; const int32_t* rows; int Ct, n; int mode;
     const float* protos_in; float* protos_out; float* loss; float* acc; int64_t ld_out; int col_out;
     float* dlogits; float* dprotos;
-};
+    int row_base;                         // logits / dlogits hold subgraphs [row_base, ...): 0 for the global arrays, the set's first
+};                                        // subgraph when the fused kernel keeps them in LDS
 
 __device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
     float d = 0.f;
@@ -121,7 +122,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
         float p;
         if (k.mode == 0) {
             p = 0.f;
-            for (int r = 0; r < k.n; ++r) p += k.logits[(int64_t)rows[c * k.n + r] * D + d];
+            for (int r = 0; r < k.n; ++r) p += k.logits[(int64_t)(rows[c * k.n + r] - k.row_base) * D + d];
             p /= (float)k.n;                                                        // .mean(0) (meta.py:41)
             if (k.protos_out) k.protos_out[(int64_t)set * k.Ct * D + id] = p;
         } else {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
     __syncthreads();
     float lpart = 0.f, apart = 0.f;
     for (int q = tid; q < Q; q += NT) {
-        const float* x = k.logits + (int64_t)rows[q] * D;
+        const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
         const int tgt = q / k.n;
         float m = -INFINITY, at = 0.f; int best = 0;
         for (int c = 0; c < k.Ct; ++c) {
@@ -159,26 +160,26 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
     const float invQ = 1.f / (float)Q;
     for (int id = tid; id < Q * D; id += NT) {
         const int q = id / D, d = id - q * D;
-        const float* x = k.logits + (int64_t)rows[q] * D;
+        const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
         const int tgt = q / k.n;
         float s = 0.f;
         for (int c = 0; c < k.Ct; ++c) {
             const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == tgt ? 1.f : 0.f)) * invQ;
             s += g * -2.f * (x[d] - protos[c * D + d]);
         }
-        k.dlogits[(int64_t)rows[q] * D + d] = s;
+        k.dlogits[(int64_t)(rows[q] - k.row_base) * D + d] = s;
     }
     __syncthreads();
     for (int id = tid; id < k.Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float s = 0.f;
         for (int q = 0; q < Q; ++q) {
-            const float* x = k.logits + (int64_t)rows[q] * D;
+            const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
             const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / k.n ? 1.f : 0.f)) * invQ;
             s += g * 2.f * (x[d] - protos[id]);
         }
         if (k.mode == 0) {
-            for (int r = 0; r < k.n; ++r) k.dlogits[(int64_t)rows[c * k.n + r] * D + d] += s / (float)k.n;
+            for (int r = 0; r < k.n; ++r) k.dlogits[(int64_t)(rows[c * k.n + r] - k.row_base) * D + d] += s / (float)k.n;
         } else if (k.dprotos) {
             k.dprotos[(int64_t)set * k.Ct * D + id] = s;
         }
@@ -214,27 +215,28 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
         }
         for (int id = tid; id < hk.C * hk.hc; id += HL_THREADS) wl_s[id] = P[hk.wl_off + id];
         for (int id = tid; id < hk.C; id += HL_THREADS) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
-        lg = lg_s - (int64_t)s0 * D;            // indexed by the global subgraph id like the global arrays
-        if (pk.dlogits) { dl = dl_s - (int64_t)s0 * D; for (int id = tid; id < S * D; id += HL_THREADS) dl_s[id] = 0.f; }
+        lg = lg_s;                              // LDS copies hold the set's subgraphs only: indexed relative to s0 (base below)
+        if (pk.dlogits) { dl = dl_s; for (int id = tid; id < S * D; id += HL_THREADS) dl_s[id] = 0.f; }
         __syncthreads();
     } else if (pk.dlogits) {
         for (int id = tid; id < S * D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
     }
-    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s);
+    const int base = stage ? s0 : 0;
+    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s, base);
     __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
     ProtoK pl = pk;
-    pl.logits = lg; pl.dlogits = dl;
+    pl.logits = lg; pl.dlogits = dl; pl.row_base = base;
     proto_set<HL_THREADS>(pl, set, tid, sm);
     if (stage) {              // the global copies (API / debugging): logits always, dlogits when requested
         __syncthreads();
         for (int id = tid; id < S * D; id += HL_THREADS) {
-            logits[(int64_t)s0 * D + id] = lg[(int64_t)s0 * D + id];
-            if (pk.dlogits) pk.dlogits[(int64_t)s0 * D + id] = dl[(int64_t)s0 * D + id];
+            logits[(int64_t)s0 * D + id] = lg[id];
+            if (pk.dlogits) pk.dlogits[(int64_t)s0 * D + id] = dl[id];
         }
     }
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s);
+    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
