@@ -420,7 +420,9 @@ class Subgraphs(Dataset):
         (sdp.py:363-386), once per name."""
         seeds = np.concatenate([np.concatenate([t[0], t[2]]) for t in tasks])
         names = [n for t in tasks for n in (list(t[1]) + list(t[3]))]
-        full = SubgraphBatch.extract(self.G, seeds, [0, len(seeds)], self.h, 2 ** 30, self.rng_seed, self.link_pred_mode)     # no sampling
+        # sizing pass: with a threshold of sample_nodes + 1 every neighbourhood the reference would sample comes back with more than
+        # sample_nodes nodes (thinned or not) and every other one comes back exact -- without per-subgraph buffers of graph size
+        full = SubgraphBatch.extract(self.G, seeds, [0, len(seeds)], self.h, self.sample_nodes + 1, self.rng_seed, self.link_pred_mode)
         off, par = full.sub_off, full.parent()
         lists = []
         for k, (name, (g, i, j)) in enumerate(zip(names, seeds.tolist())):
