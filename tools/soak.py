@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmeta_amd
 from gmeta_amd import synth
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+if os.environ.get('SOAK_SWITCH'):
+    sys.setswitchinterval(float(os.environ['SOAK_SWITCH']))      # GIL hand-over period (default 5 ms)
 T = 32
 args, cfg = synth.make_args('arxiv')
 np.random.seed(222); random.seed(222); torch.manual_seed(222)
