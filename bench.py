@@ -2,11 +2,13 @@
 """bench.py -- meta-tasks/sec of the G-Meta inner-loop hot path on MI355X.
 
 One "step" = one Meta.forward (ProtoMAML meta-step: K inner SGD steps on the support subgraphs, K+1 query
-evaluations, first-order meta-gradient, Adam) over a meta-batch of task_num=32 tasks whose h-hop subgraphs
-are already extracted and resident in HBM.  Workload = BASELINE.json configs[1]: arxiv-ogbn shape
-(synthetic graph of 169,343 nodes, F0=128, h=2, hidden 256, 3-way 3-shot 24-query, K=10, sample_nodes=1000).
-With --gpus N the 32 tasks are sharded over N ranks (strong scaling) and the meta-gradient is summed by one
-RCCL all-reduce per step.  Prints ONE JSON line on rank 0.
+evaluations, first-order meta-gradient, Adam) over a meta-batch of task_num tasks whose h-hop subgraphs are
+already extracted and resident in HBM.  Default workload = BASELINE.json configs[1]: arxiv-ogbn shape
+(synthetic graph of 169,343 nodes, F0=128, h=2, hidden 256, 3-way 3-shot 24-query, task_num=32, K=10,
+sample_nodes=1000); --config selects the other BASELINE configs (syn0 = configs[0], tissue = configs[3],
+firstmm = configs[4]).  With --gpus N the tasks of a meta-batch are sharded over N ranks (strong scaling;
+uneven shards when N does not divide task_num) and the meta-gradient is summed by one RCCL all-reduce per
+step.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
@@ -25,45 +27,92 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3        # dense fp32 matrix peak (MI355X_MICROARCH.md)
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 matrix peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0               # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def cpu_baseline(data, cfg, config, seconds_hint=20.0):
-    """The oracle (oracle/gmeta_oracle.py: numpy + OpenMP C aggregate, kind "port") timed on the host cores
-    on a bounded sample of the SAME workload: whole tasks of the same config, one at a time, until ~20 s."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def shard_bounds(T, world):
+    """Contiguous task ranges of a meta-batch per rank (sizes differ by at most one)."""
+    return np.linspace(0, T, world + 1).round().astype(int)
+
+
+def cpu_baseline(db, data, cfg, config, batch, budget_s=40.0):
+    """The CPU restatement of the same workload, timed on the host cores (kind "port"; the reference's own Python
+    needs DGL 0.4.3, which cannot be installed here).  Two variants of the SAME per-task inner loop
+    (K support steps fwd+bwd, K+1 query evaluations, the first-order meta-gradient):
+      numpy-omp  oracle/gmeta_oracle.py: numpy/BLAS matmuls + the OpenMP C aggregate (forward and transposed)
+      torch-cpu  oracle/torch_cpu_baseline.py: torch CPU ops + autograd, index_add_ for update_all -- the closest
+                 analogue of the reference's DGL-CPU path (learner.py:38-47)
+    on whole tasks of the first GPU meta-batch (same subgraphs: node sets replayed from the GPU extraction, which is
+    bit-exact vs the oracle's; extraction is excluded on both sides).  2 warm-up + >= 5 timed tasks per variant, median."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import torch
     import gmeta_oracle as orc
+    import torch_cpu_baseline as tcb
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    graphs = [orc.Graph(*g) for g in data['graphs']]
+    S, Q = batch[0][0].view_of or batch[0][0], batch[2][0].view_of or batch[2][0]
+    link = bool(cfg.get('link'))
     rng = np.random.default_rng(222)
-    n, src, dst = data['graphs'][0]
-    G = [orc.Graph(n, src, dst)]
-    labels = np.array([int(l) for l in data['labels']])
-    n_way, k_spt, k_qry, K = cfg['n_way'], cfg['k_spt'], cfg['k_qry'], cfg['update_step']
     theta = []
-    dims = [cfg['F0']] + [cfg['hidden']] * cfg['h']
-    for a, b in zip(dims[:-1], dims[1:]):
-        theta += [(rng.standard_normal((a, b)) * np.sqrt(2.0 / (a + b))).astype(np.float32), np.zeros(b, np.float32)]
-    theta += [(rng.standard_normal((n_way, cfg['hidden'])) * 0.1).astype(np.float32), np.zeros(n_way, np.float32)]
-    done, t_total = 0, 0.0
-    while t_total < seconds_hint and done < 4:
-        cls = rng.choice(cfg['classes'], n_way, replace=False)
-        spt_seeds, qry_seeds, ys, yq = [], [], [], []
-        for ci, c in enumerate(cls):
-            pool = np.nonzero(labels == c)[0]
-            pick = rng.choice(pool, k_spt + k_qry, replace=False)
-            spt_seeds += [(0, int(v), -1) for v in pick[:k_spt]]; ys += [ci] * k_spt
-            qry_seeds += [(0, int(v), -1) for v in pick[k_spt:]]; yq += [ci] * k_qry
-        t0 = time.perf_counter()
-        bs = orc.extract_batch(G, spt_seeds, cfg['h'], cfg['sample_nodes'], 222, False)
-        bq = orc.extract_batch(G, qry_seeds, cfg['h'], cfg['sample_nodes'], 222, False)
-        t1 = time.perf_counter()
-        orc.task_inner_loop(bs, bq, bs.features(data['feats']), bq.features(data['feats']), np.array(ys), np.array(yq), theta, config,
-                            k_spt, cfg['update_lr'], K, True)
-        t2 = time.perf_counter()
-        done += 1; t_total += t2 - t1
-        extract_s = t1 - t0
-    return {'value': round(done / t_total, 4), 'unit': 'meta-tasks/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': '%d task(s) of the same config (K=%d inner steps incl. meta-gradient), subgraphs pre-extracted '
-                      '(oracle extraction took %.1f s/task, excluded like the GPU side); numpy/BLAS + OpenMP C aggregate' % (done, K, extract_s)}
+    for name, p in config:
+        if name == 'GraphConv':
+            theta += [(rng.standard_normal(p) * np.sqrt(2.0 / sum(p))).astype(np.float32), np.zeros(p[1], np.float32)]
+        elif name == 'Linear':
+            theta += [(rng.standard_normal((p[1], p[0] * (2 if link else 1))) * 0.1).astype(np.float32), np.zeros(p[1], np.float32)]
+    n_gcn = cfg['h']
+    K, k_spt, lr = cfg['update_step'], cfg['k_spt'], cfg['update_lr']
+    T = len(batch[0])
+
+    def task(t):
+        out = []
+        for B, seeds in ((S, db._task_arrays(t)[0]), (Q, db._task_arrays(t)[1])):
+            so, par, off = B.set_sub_off, B.parent(), B.sub_off
+            lists = [par[off[k]:off[k + 1]] for k in range(so[t], so[t + 1])]
+            out.append(orc.Batch(graphs, [tuple(int(v) for v in s) for s in seeds], lists))
+        return out[0], out[1], np.asarray(batch[1][t]), np.asarray(batch[3][t])
+
+    variants = {}
+    for name in ('numpy-omp', 'torch-cpu'):
+        times, t_used, t = [], 0.0, 0
+        n_warm = 2
+        while t < T and (len(times) < 5 or (t_used < budget_s * 0.5 and len(times) < 9)):
+            bs, bq, ys, yq = task(t % T)
+            xs, xq = bs.features(data['feats']), bq.features(data['feats'])
+            t0 = time.perf_counter()
+            if name == 'numpy-omp':
+                orc.task_inner_loop(bs, bq, xs, xq, ys, yq, theta, config, k_spt, lr, K, True)
+            else:
+                tcb.task_inner_loop(bs, bq, xs, xq, ys, yq, theta, n_gcn, k_spt, lr, K, True)
+            dt = time.perf_counter() - t0
+            t += 1; t_used += dt
+            if n_warm > 0 and dt * 7 < budget_s:      # warm-ups only when 2 + 5 tasks fit the budget
+                n_warm -= 1
+                continue
+            n_warm = 0
+            times.append(dt)
+            if t_used > budget_s and len(times) >= 3:
+                break
+        med = float(np.median(times))
+        variants[name] = {'value': round(1.0 / med, 4), 'median_s_per_task': round(med, 3), 'tasks_timed': len(times),
+                          'min_s': round(min(times), 3), 'max_s': round(max(times), 3)}
+    best = max(variants, key=lambda k: variants[k]['value'])
+    return {'value': variants[best]['value'], 'unit': 'meta-tasks/s', 'cores': cores, 'kind': 'port', 'variant': best,
+            'cpu_model': cpu_model(), 'variants': variants,
+            'sample': 'whole tasks of the first meta-batch of the same config (K=%d inner steps incl. the meta-gradient), one task at a '
+                      'time like the reference loop (meta.py:118), subgraphs pre-extracted on both sides; up to 2 warm-up tasks then the '
+                      'median of >= 5 timed tasks per variant (fewer when one task exceeds the time budget); torch/BLAS/OpenMP threads = %d' % (K, cores)}
 
 
 def main():
@@ -71,7 +120,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--config', default='arxiv', choices=['arxiv', 'syn0'])
+    ap.add_argument('--config', default='arxiv', choices=['arxiv', 'syn0', 'tissue', 'firstmm'])
     ap.add_argument('--task_num', type=int, default=None)
     ap.add_argument('--hoist_z1', type=int, default=0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
@@ -103,24 +152,27 @@ def main():
         over['task_num'] = a.task_num
     args, cfg = synth.make_args(a.config, **over)
     T = cfg['task_num']
-    if T % world:
-        raise SystemExit('task_num=%d is not divisible by %d ranks' % (T, world))
+    if world > T:
+        raise SystemExit('task_num=%d cannot be sharded over %d ranks (every rank needs at least one task)' % (T, world))
+    bounds = shard_bounds(T, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     # ---- identical synthetic data + task lists on every rank (seed 222), each rank keeps its task shard
     np.random.seed(222); import random; random.seed(222); torch.manual_seed(222)
     t0 = time.perf_counter()
-    data = synth.node_dataset(cfg['n'], cfg['m'], cfg['F0'], cfg['classes'])
+    data = synth.make_dataset(cfg)
+    link = bool(cfg.get('link'))
     store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
-    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
+    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], synth.n_out(cfg), link=link)
     maml = gmeta_amd.Meta(args, config).to('cuda')
     maml.force_allreduce = os.environ.get('GMETA_FORCE_DIST') == '1' and os.environ.get('GMETA_SKIP_ALLREDUCE') != '1'
+    n_eval = int(cfg.get('eval_tasks', 0)) if world == 1 else 0
     db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'],
-                             batchsz=T * (a.n_batches + (a.e2e_steps + 2 if world == 1 else 0)), args=args, adjs=store, h=cfg['h'],
-                             tables={'train': (data['names'], data['labels'])}, verbose=False)
-    per = T // world
+                             batchsz=T * (a.n_batches + (a.e2e_steps + 2 if world == 1 else 0)) + n_eval, args=args, adjs=store, h=cfg['h'],
+                             tables=data['tables'], verbose=False)
     batches, ext_ms = [], []
-    db.get_batch(list(range(rank * per, (rank + 1) * per)))      # warm-up extraction (first call pays one-off setup)
+    db.get_batch(list(range(lo, hi)))      # warm-up extraction (first call pays one-off setup)
     for b in range(a.n_batches):
-        idx = list(range(b * T + rank * per, b * T + (rank + 1) * per))
+        idx = list(range(b * T + lo, b * T + hi))
         torch.cuda.synchronize(); te = time.perf_counter()
         batches.append(db.get_batch(idx))
         torch.cuda.synchronize(); ext_ms.append((time.perf_counter() - te) * 1e3)
@@ -133,7 +185,7 @@ def main():
 
     lib = _lib.lib()
 
-    def prof_read(cat=0):       # 0 aggregate (bytes), 1 grouped GEMM (flops), 2 weight gradient (flops)
+    def prof_read(cat=0):       # 0 aggregate (bytes), 1 grouped GEMM (flops), 2 weight gradient (flops), 3 aggregate, compulsory HBM bytes
         ms, n, by = C.c_double(), C.c_int64(), C.c_int64()
         lib.gm_profile_read(cat, C.byref(ms), C.byref(n), C.byref(by))
         return ms.value, n.value, by.value
@@ -147,10 +199,12 @@ def main():
     t0 = time.perf_counter()
     ov_ms, ov_n, ov_bytes = 0.0, 0, 0
     ov_mm = {1: [0.0, 0, 0], 2: [0.0, 0, 0]}
+    strict_bytes = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
+        strict_bytes += prof_read(3)[2]
         for cat in (1, 2):
             ms, n, fl = prof_read(cat)
             ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
@@ -168,18 +222,21 @@ def main():
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
     mm = ov_mm if a.serialize else {1: [0.0, 0, 0], 2: [0.0, 0, 0]}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
+    ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         maml.serialize = 1
         step(0)
-        agg_ms, agg_n, agg_bytes = 0.0, 0, 0
+        agg_ms, agg_n, agg_bytes, strict_bytes = 0.0, 0, 0, 0
         for k in range(a.roofline_steps):
             step(k)
             ms, n, by = prof_read()
             agg_ms += ms; agg_n += n; agg_bytes += by
+            strict_bytes += prof_read(3)[2]
             for cat in (1, 2):
                 ms, n, fl = prof_read(cat)
                 mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
         maml.serialize = 0
+        ser_steps = a.roofline_steps
     lib.gm_profile_enable(0)
     # ---- secondary numbers: the flagged schedules that produce identical results without the structural zeros /
     # loop-invariant recomputation (never the headline `value`)
@@ -197,13 +254,26 @@ def main():
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
-        import ctypes as C_
         lv = {}
         for side, x in (('spt', batches[0][0][0].view_of), ('qry', batches[0][2][0].view_of)):      # what the cone schedule touches
-            ok = C_.c_int32(); nr = (C_.c_int64 * (cfg['h'] + 1))(); ne = (C_.c_int64 * (cfg['h'] + 1))()
-            _lib.check(lib.gm_batch_cone_dims(x.handle, cfg['h'], C_.byref(ok), nr, ne), 'cone_dims')
+            ok = C.c_int32(); nr = (C.c_int64 * (cfg['h'] + 1))(); ne = (C.c_int64 * (cfg['h'] + 1))()
+            _lib.check(lib.gm_batch_cone_dims(x.handle, cfg['h'], C.byref(ok), nr, ne), 'cone_dims')
             lv[side] = {'batch_rows': int(x.rows), 'batch_edges': int(x.edges), 'level_rows': list(nr), 'level_edges': list(ne)}
         extra['cone']['receptive_field'] = lv
+    # ---- evaluation leg (BASELINE configs[3]: "x10 eval tasks"): Meta.finetunning over eval_tasks tasks in one batched call
+    if n_eval > 0 and not (a.sparse_bwd or a.hoist_z1 or a.serialize or a.cone):
+        base = T * (a.n_batches + a.e2e_steps + 2)
+        ev = db.get_batch(list(range(base, base + n_eval)))
+        maml.finetunning_batch(ev[0], ev[1], ev[2], ev[3])
+        torch.cuda.synchronize(); te = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            acc_e = maml.finetunning_batch(ev[0], ev[1], ev[2], ev[3])
+        torch.cuda.synchronize()
+        ms_e = (time.perf_counter() - te) / reps * 1e3
+        extra['finetunning'] = {'tasks': n_eval, 'update_step_test': cfg['update_step_test'], 'ms_per_call': round(ms_e, 3),
+                                'tasks_per_s': round(n_eval / (ms_e * 1e-3), 1), 'mean_final_acc': round(float(acc_e[:, -1].mean()), 4),
+                                'what': 'Meta.finetunning (meta.py:175-234) for all eval tasks in one batched call (the reference loops them, train.py:118-121)'}
 
     # ---- end to end ("report also with extraction included"): every step extracts its own meta-batch
     e2e = None
@@ -222,32 +292,44 @@ def main():
                        'thread/stream) + Meta.forward per step; same schedule as `value`'}
     if rank == 0:
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
-        traffic = None          # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE), see profiles/
+        strict = strict_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
+        # HBM bytes per launch from the PMC passes (FETCH_SIZE x2 correction + WRITE_SIZE): NOT measured in this run; read from the
+        # committed summary of a separate rocprofv3 --pmc pass over this command (see profiles/), and only quoted for the workload it was taken on
+        traffic, traffic_source = None, None
         tp = os.path.join(ROOT, 'profiles', 'agg_traffic.json')
-        if os.path.exists(tp) and a.config == 'arxiv' and not a.task_num and world == 1:      # the PMC passes were taken on the default workload
+        if os.path.exists(tp) and a.config == 'arxiv' and not a.task_num and world == 1:
             try:
-                traffic = json.load(open(tp)).get('hbm_bytes_per_launch')
+                tj = json.load(open(tp))
+                traffic = tj.get('hbm_bytes_per_launch')
+                traffic_source = 'profiles/agg_traffic.json (%s; separate rocprofv3 --pmc pass, not this run)' % tj.get('taken', 'date unknown')
             except Exception:
                 traffic = None
+        gemm_mode = os.environ.get('GM_GEMM_MODE', 'default')
         out = {
             'metric': 'meta-tasks/sec (inner-loop fwd+bwd) at task_num=%d' % T, 'value': round(T / (ms_per_step * 1e-3), 3),
             'unit': 'meta-tasks/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': ('BASELINE configs[1]: arxiv-ogbn shape' if a.config == 'arxiv' else 'BASELINE configs[0]: synthetic plumbing case') +
-                                   ' (synthetic PA graph N=%d m=%d, F0=%d), Disjoint, h=%d, hidden=%d, '
-                                   '%d-way %d-shot %d-qry, task_num=%d, update_step=%d, sample_nodes=%d; subgraphs pre-extracted in HBM'
-                                   % (cfg['n'], cfg['m'], cfg['F0'], cfg['h'], cfg['hidden'], cfg['n_way'], cfg['k_spt'], cfg['k_qry'], T,
-                                      cfg['update_step'], cfg['sample_nodes']),
+            'config': {'workload': synth.WORKLOADS[a.config] +
+                                   ' (synthetic %s, F0=%d), %s%s, h=%d, hidden=%d, %d-way %d-shot %d-qry, task_num=%d, update_step=%d, '
+                                   'sample_nodes=%d; subgraphs pre-extracted in HBM'
+                                   % ('PA graph N=%d m=%d' % (cfg['n'], cfg['m']) if cfg.get('kind', 'single') == 'single' else
+                                      '%d graphs x %d nodes (PA m=%d)' % (cfg['n_graphs'], cfg['n'], cfg['m']), cfg['F0'],
+                                      cfg.get('task_setup', 'Disjoint'), ' link prediction' if link else '', cfg['h'], cfg['hidden'], cfg['n_way'],
+                                      cfg['k_spt'], cfg['k_qry'], T, cfg['update_step'], cfg['sample_nodes']),
                        'schedule': ('hoist_z1 ' if a.hoist_z1 else '') + ('cone (receptive-field rows only, forward and backward)' if a.cone else
                                     'sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
                                     'full (reference-equivalent: every forward/backward dense over all subgraph rows)'),
                        'streams': 1 if a.serialize else 2,
-                       'parallelism': 'tasks sharded over %d rank(s), one all-reduce of the meta-gradient per step' % world,
+                       'parallelism': 'tasks sharded over %d rank(s) (rank 0: %d of %d), one all-reduce of the meta-gradient per step' % (world, hi - lo, T),
                        'rows_per_rank': int(rows), 'edges_per_rank': int(edges),
                        'extract_ms_per_meta_batch_rank0': round(float(np.min(ext_ms)), 2), 'last_accs': [round(float(x), 4) for x in accs]},
             'roofline': {'bound': 'hbm', 'kernel': 'k_agg (batched subgraph message passing, all widths)',
                          'achieved': round(ach, 1) if ach else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None, 'traffic': traffic,
+                         'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None, 'traffic': traffic, 'traffic_source': traffic_source,
+                         'strict_hbm_achieved': round(strict, 1) if strict else None,
+                         'strict_hbm_frac': round(strict / HBM_PEAK_GBS, 4) if strict else None,
+                         'strict_hbm_note': 'same launches and durations, layer-1 launches (which gather rows of the L2/MALL-resident feature table) '
+                                            'priced at the table size instead of rows x width',
                          'launches_measured': agg_n, 'avg_launch_ms': round(agg_ms / max(agg_n, 1), 4),
                          'algorithmic_bytes_per_launch': agg_bytes // max(agg_n, 1),
                          'measured': 'HIP events on the launch stream over %s' % ('the timed region (serialize=1)' if a.serialize else
@@ -257,20 +339,29 @@ def main():
         if mm[1][0] > 0:
             def tf(c):
                 return round(mm[c][2] / (mm[c][0] * 1e-3) / 1e12, 1)
-            out['mfma'] = {'note': 'update GEMMs (exact fp32 v_mfma_f32_32x32x2_f32), HIP events around every launch of the same serialised steps as '
-                                   'the roofline; frac = achieved / 157.3 TFLOP/s dense fp32 matrix peak',
-                           'peak_tflops': MFMA_F32_PEAK_TFLOPS,
+            out['mfma'] = {'note': 'update GEMMs, HIP events around every launch of the same serialised steps as the roofline; flops counted as '
+                                   '2*rows*K*N of the fp32 product (whatever MFMA passes implement it); frac = achieved / 157.3 TFLOP/s dense fp32 matrix peak',
+                           'peak_tflops': MFMA_F32_PEAK_TFLOPS, 'gemm_mode': gemm_mode,
                            'gemm': {'achieved_tflops': tf(1), 'frac': round(tf(1) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[1][1],
-                                    'what': 'k_gemm_glds / k_gemm_nn: forward X@W and backward dZ = dQ@W^T'},
+                                    'what': 'forward X@W and backward dZ = dQ@W^T'},
                            'wgrad': {'achieved_tflops': tf(2), 'frac': round(tf(2) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[2][1],
-                                     'what': 'k_wgrad_fast + k_wgrad_reduce: dW = (norm*Z)^T dQ, db'}}
+                                     'what': 'dW = (norm*Z)^T dQ, db, incl. the partial reduction'}}
+            if ser_steps > 0:
+                # composite bound of the whole step: all update flops at the fp32 matrix peak + all aggregate bytes at the HBM peak
+                fl = (mm[1][2] + mm[2][2]) / ser_steps; by = agg_bytes / ser_steps
+                t_mfma, t_hbm = fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3, by / (HBM_PEAK_GBS * 1e9) * 1e3
+                out['step_bound'] = {'update_gflop_per_step': round(fl / 1e9, 1), 'aggregate_gb_per_step': round(by / 1e9, 2),
+                                     'ms_at_fp32_mfma_peak': round(t_mfma, 2), 'ms_at_hbm_peak': round(t_hbm, 2),
+                                     'frac_of_serial_bound': round((t_mfma + t_hbm) / ms_per_step, 3),
+                                     'frac_of_overlapped_bound': round(max(t_mfma, t_hbm) / ms_per_step, 3),
+                                     'note': 'bounds priced with the exact-fp32 MFMA peak (157.3 TF); a split-bf16 GEMM mode can beat the fp32 bound'}
         if e2e:
             out['end_to_end'] = e2e
         if extra:
-            out['extra'] = {'note': 'flagged exact schedules (same accs/meta-gradient, golden-tested); not the headline value', **extra}
+            out['extra'] = {'note': 'flagged exact schedules (same accs/meta-gradient, golden-tested) and the evaluation leg; not the headline value', **extra}
         if not a.no_cpu_baseline and world == 1:           # rank 0 at N=1 only
             try:
-                out['cpu_baseline'] = cpu_baseline(data, cfg, config)
+                out['cpu_baseline'] = cpu_baseline(db, data, cfg, config, batches[0])
             except Exception as e:   # the baseline is a reported number, never the product path
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out), flush=True)

@@ -51,6 +51,7 @@ PROTOTYPES = {
     'gm_meta_ws_bytes': (i64, [vp, vp, vp, vp]),
     'gm_meta_out_floats': (i64, [vp, vp, vp]),
     'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    'gm_meta_finish': (C.c_int, [vp, i64, i32, vp, vp, vp]),
     'gm_profile_enable': (None, [i32]),
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
     'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),

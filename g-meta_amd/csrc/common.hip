@@ -1,6 +1,10 @@
 // Error handling, allocation helpers, model layout, aggregate-launch profiling.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <map>
+#include <mutex>
+#include <set>
+#include <utility>
 #include "gm_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -107,6 +111,7 @@ void gm_prof_begin(int cat, hipStream_t s, int64_t work) {
     (void)hipEventRecord(c.ev[c.used], s);
     c.work += work; c.launches += 1; c.open = true;
 }
+void gm_prof_note(int cat, int64_t work) { if (g_prof_on) g_prof[cat].work += work; }
 void gm_prof_end(int cat, hipStream_t s) {
     ProfCat& c = g_prof[cat];
     if (!g_prof_on || !c.open) return;
@@ -137,4 +142,32 @@ int gm_heavy_deg() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("GM_HEAVY_DEG"); v = e ? atoi(e) : 64; if (v < 2) v = 2; }
     return v;
+}
+
+// ---------------------------------------------------------------- per-device facts (one process may drive several GPUs)
+static std::mutex g_dev_mu;
+
+int gm_num_cus() {
+    static std::map<int, int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    auto it = cus.find(dev);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n;
+    return n;
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KiB) once per (device, kernel)
+int gm_func_full_lds(const void* fn) {
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    GM_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (done.count({dev, fn})) return GM_OK;
+    GM_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert({dev, fn});
+    return GM_OK;
 }

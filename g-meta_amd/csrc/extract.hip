@@ -347,8 +347,18 @@ __global__ void k_gather_rows(const float* feat, const int32_t* feat_row, float*
 }
 
 // ------------------------------------------------------------------------------------------ host
+void gm_batch_mark_use(const gm_batch* b, hipStream_t st) {
+    if (!b || st == b->stream) return;              // same stream: the frees are already ordered behind the consumer
+    if (!b->used_ev && hipEventCreateWithFlags(&b->used_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); b->used_ev = nullptr; return; }
+    if (hipEventRecord(b->used_ev, st) != hipSuccess) (void)hipGetLastError();
+}
+
 static void batch_free(gm_batch* b) {
     hipStream_t s = b->stream;
+    if (b->used_ev) {
+        if (hipStreamWaitEvent(s, b->used_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b->used_ev); }
+        (void)hipEventDestroy(b->used_ev); b->used_ev = nullptr;
+    }
     gm_dev_free(b->d_sub_off, s); gm_dev_free(b->d_set_sub_off, s); gm_dev_free(b->d_set_row_off, s); gm_dev_free(b->d_graph, s);
     gm_dev_free(b->d_parent, s); gm_dev_free(b->d_feat_row, s); gm_dev_free(b->d_indptr, s); gm_dev_free(b->d_indices, s);
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
@@ -516,12 +526,8 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     const bool gpath = force_global || lds_a > 160 * 1024;
     if (gpath) lds_a = sizeof(uint32_t) * (EX_BLOCK + 256 + 16);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GM_HIP(hipFuncSetAttribute((const void*)k_nodes<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GM_HIP(hipFuncSetAttribute((const void*)k_fill<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    GM_TRY(gm_func_full_lds((const void*)k_nodes<false>));
+    GM_TRY(gm_func_full_lds((const void*)k_fill<false>));
     ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx};
 
     gm_seed_t* d_seeds = nullptr; int32_t *d_nodes = nullptr, *d_degi = nullptr, *d_dego = nullptr, *d_nsub = nullptr, *d_esub = nullptr;

@@ -661,13 +661,9 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     int zs = 1;
     while (zs < TPW && w.n_chunks * zs < 192) zs <<= 1;       // TPW is 1, 2 or 4; chunk counts sit just under 256 by construction
     const size_t lds = 2 * RK * ld * sizeof(float);   // double-buffered stages
-    static bool attr_done = false;
-    if (!attr_done) {
-        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        GM_HIP(hipFuncSetAttribute((const void*)k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad_fast<TK, TN, 1>));
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>));
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>));
     if (zs == 4 && TPW >= 4) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 4 ? 4 : 1)>), dim3(w.n_chunks, 4), dim3(WG_THREADS), lds, s, w);
     else if (zs >= 2 && TPW >= 2) hipLaunchKernelGGL((k_wgrad_fast<TK, TN, (TPW >= 2 ? 2 : 1)>), dim3(w.n_chunks, 2), dim3(WG_THREADS), lds, s, w);
     else hipLaunchKernelGGL((k_wgrad_fast<TK, TN, 1>), dim3(w.n_chunks, 1), dim3(WG_THREADS), lds, s, w);
@@ -725,7 +721,7 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const bool fast_ok = (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
                          (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
     if (fast_ok && !launched) {
-#define GM_WG_CASE(TK_, TN_) if (!launched && w.TK == TK_ && w.TN == TN_) { launch_wgrad_fast<TK_, TN_>(w, s); launched = true; }
+#define GM_WG_CASE(TK_, TN_) if (!launched && w.TK == TK_ && w.TN == TN_) { GM_TRY((launch_wgrad_fast<TK_, TN_>(w, s))); launched = true; }
         GM_WG_CASE(8, 8) GM_WG_CASE(4, 8) GM_WG_CASE(8, 4) GM_WG_CASE(4, 4) GM_WG_CASE(2, 4) GM_WG_CASE(4, 2) GM_WG_CASE(2, 2)
         GM_WG_CASE(1, 2) GM_WG_CASE(2, 1) GM_WG_CASE(1, 4) GM_WG_CASE(1, 8) GM_WG_CASE(1, 1)
 #undef GM_WG_CASE
@@ -745,8 +741,7 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.vec = (a.K % 4 == 0) && (a.N % 4 == 0) && (a.lda % 4 == 0) && (a.ldg % 4 == 0) && (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
     const size_t lds = (size_t)w.RK * ld * sizeof(float);
     GM_REQUIRE(lds <= 160 * 1024, GM_ERANGE, "wgrad: K=%d N=%d needs %zu B of LDS", a.K, a.N, lds);
-    static bool attr = false;
-    if (!attr) { GM_HIP(hipFuncSetAttribute((const void*)k_wgrad, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad));
     const int zgroups = (w.TK * w.TN + WG_WAVES * WG_MAXT - 1) / (WG_WAVES * WG_MAXT);
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_chunks, zgroups), dim3(WG_THREADS), lds, s, w);
     GM_HIP(hipGetLastError());

@@ -111,9 +111,13 @@ struct gm_batch {
     int32_t* d_c_chunks = nullptr; int32_t* d_c_set_chunk_off = nullptr; int32_t n_c_chunks = 0;
     int32_t* d_e1_chunks = nullptr; int32_t* d_e1_set_chunk_off = nullptr; int32_t n_e1_chunks = 0;
     mutable gm_cone* cone[GM_MAX_GCN + 1] = {};     // receptive-field tables per number of GCN layers (gm_hparams_t.cone)
-    hipStream_t stream = nullptr;      // stream the arrays were produced on
+    hipStream_t stream = nullptr;      // stream the arrays were produced on (and are freed on, stream-ordered)
+    mutable hipEvent_t used_ev = nullptr;   // last consumer on ANOTHER stream: the frees wait for it (gm_batch_mark_use)
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);
+// A consumer that ran kernels over the batch on `st` calls this afterwards: gm_batch_destroy then orders its frees behind
+// that work instead of relying on the host having synchronised (deferred read-back, prefetch threads).
+void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
 
 // ---- host phase timing for the setup paths (env GM_TIMING=1 prints to stderr)
 #include <chrono>
@@ -224,10 +228,12 @@ struct gm_wgrad_args {
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 
 // Rows per weight-gradient chunk for sets of the given sizes.  One workgroup (one CU: 128 accumulator VGPRs x 16 waves)
-// takes one chunk and writes a (K+1)xN partial, so the chunk count should sit just under a multiple of the 256 CUs --
+// takes one chunk and writes a (K+1)xN partial, so the chunk count should sit just under a multiple of the CU count (256) --
 // 280 chunks cost two rounds for the work of 1.1 -- and be small: every chunk adds a partial to write and re-read.
 // Chunks never straddle two sets (per-task weights).  Returns a multiple of 32.
-static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n_cu = 256) {
+int gm_num_cus();                         // compute units of the current device (cached per device)
+int gm_func_full_lds(const void* fn);     // allow 160 KiB of dynamic LDS for a kernel, once per (device, kernel)
+static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n_cu = gm_num_cus()) {
     const int sets = (int)set_off.size() - 1;
     int64_t total = 0; int mx = 1;
     for (int t = 0; t < sets; ++t) { const int n = set_off[t + 1] - set_off[t]; total += n; mx = n > mx ? n : mx; }
@@ -251,9 +257,11 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_AGG 0
 #define GM_PROF_GEMM 1
 #define GM_PROF_WGRAD 2
-#define GM_PROF_CATS 3
+#define GM_PROF_AGG_STRICT 3   // work-only shadow of GM_PROF_AGG: compulsory HBM bytes (a layer-1 gather reads at most the feature table)
+#define GM_PROF_CATS 4
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
 void gm_prof_reset();
+void gm_prof_note(int cat, int64_t work);      // adds work to a category without timing events
 static inline void gm_prof_agg_begin(hipStream_t s, int64_t bytes) { gm_prof_begin(GM_PROF_AGG, s, bytes); }
 static inline void gm_prof_agg_end(hipStream_t s) { gm_prof_end(GM_PROF_AGG, s); }

@@ -98,11 +98,13 @@ __global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits,
 // Prototypical loss for one set per block (meta.py:28-79).  rows: [sets, Ct, n] global subgraph ids grouped by
 // sorted class.  mode 0 = support (prototypes = class means of the same rows), 1 = query (prototypes given).
 struct ProtoK {
-    const float* logits; int D; const int32_t* rows; int Ct, n; int mode;
+    const float* logits; int D; const int32_t* rows; int Ct, n; int mode;      // Ct, n: the LARGEST class count / rows per class over the sets
     const float* protos_in; float* protos_out; float* loss; float* acc; int64_t ld_out; int col_out;
     float* dlogits; float* dprotos;
     int row_base;                         // logits / dlogits hold subgraphs [row_base, ...): 0 for the global arrays, the set's first
-};                                        // subgraph when the fused kernel keeps them in LDS
+                                          // subgraph when the fused kernel keeps them in LDS
+    const int32_t* tab;                   // [sets*3] per set: offset into rows, classes, rows per class (every task keeps its own class
+};                                        // layout, like the per-task proto_loss calls of meta.py:118-157); prototypes are strided by Ct
 
 __device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
     float d = 0.f;
@@ -112,18 +114,19 @@ __device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
 
 template <int NT>
 __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, float* sm) {
-    const int Q = k.Ct * k.n, D = k.D;
-    float* protos = sm;                 // [Ct*D]
+    const int Ct = k.tab[set * 3 + 1], n = k.tab[set * 3 + 2];
+    const int Q = Ct * n, D = k.D;
+    float* protos = sm;                 // [Ct*D]   (LDS sized for the largest set)
     float* lse = sm + k.Ct * D;         // [Q]
-    float* red = lse + Q;               // [2 * NT]
-    const int32_t* rows = k.rows + (int64_t)set * Q;
-    for (int id = tid; id < k.Ct * D; id += NT) {
+    float* red = lse + k.Ct * k.n;      // [2 * NT]
+    const int32_t* rows = k.rows + k.tab[set * 3];
+    for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float p;
         if (k.mode == 0) {
             p = 0.f;
-            for (int r = 0; r < k.n; ++r) p += k.logits[(int64_t)(rows[c * k.n + r] - k.row_base) * D + d];
-            p /= (float)k.n;                                                        // .mean(0) (meta.py:41)
+            for (int r = 0; r < n; ++r) p += k.logits[(int64_t)(rows[c * n + r] - k.row_base) * D + d];
+            p /= (float)n;                                                          // .mean(0) (meta.py:41)
             if (k.protos_out) k.protos_out[(int64_t)set * k.Ct * D + id] = p;
         } else {
             p = k.protos_in[(int64_t)set * k.Ct * D + id];
@@ -134,15 +137,15 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
     float lpart = 0.f, apart = 0.f;
     for (int q = tid; q < Q; q += NT) {
         const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
-        const int tgt = q / k.n;
+        const int tgt = q / n;
         float m = -INFINITY, at = 0.f; int best = 0;
-        for (int c = 0; c < k.Ct; ++c) {
+        for (int c = 0; c < Ct; ++c) {
             const float a = -sqdist(x, protos + c * D, D);                           // -dists (meta.py:44-45)
             if (a > m) { m = a; best = c; }
             if (c == tgt) at = a;
         }
         float se = 0.f;
-        for (int c = 0; c < k.Ct; ++c) se += expf(-sqdist(x, protos + c * D, D) - m);
+        for (int c = 0; c < Ct; ++c) se += expf(-sqdist(x, protos + c * D, D) - m);
         const float l = m + logf(se);
         lse[q] = l;
         lpart += -(at - l);                                                          // -log_p[q, class(q)]
@@ -161,25 +164,25 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
     for (int id = tid; id < Q * D; id += NT) {
         const int q = id / D, d = id - q * D;
         const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
-        const int tgt = q / k.n;
+        const int tgt = q / n;
         float s = 0.f;
-        for (int c = 0; c < k.Ct; ++c) {
+        for (int c = 0; c < Ct; ++c) {
             const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == tgt ? 1.f : 0.f)) * invQ;
             s += g * -2.f * (x[d] - protos[c * D + d]);
         }
         k.dlogits[(int64_t)(rows[q] - k.row_base) * D + d] = s;
     }
     __syncthreads();
-    for (int id = tid; id < k.Ct * D; id += NT) {
+    for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float s = 0.f;
         for (int q = 0; q < Q; ++q) {
             const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
-            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / k.n ? 1.f : 0.f)) * invQ;
+            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / n ? 1.f : 0.f)) * invQ;
             s += g * 2.f * (x[d] - protos[id]);
         }
         if (k.mode == 0) {
-            for (int r = 0; r < k.n; ++r) k.dlogits[(int64_t)(rows[c * k.n + r] - k.row_base) * D + d] += s / (float)k.n;
+            for (int r = 0; r < n; ++r) k.dlogits[(int64_t)(rows[c * n + r] - k.row_base) * D + d] += s / (float)n;
         } else if (k.dprotos) {
             k.dprotos[(int64_t)set * k.Ct * D + id] = s;
         }
@@ -240,11 +243,12 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
-__global__ void k_protos_to_dlogits(const float* dprotos, const int32_t* rows, int Ct, int n, int D, float* dlogits) {
-    const int set = blockIdx.x;
+__global__ void k_protos_to_dlogits(const float* dprotos, const int32_t* rows, const int32_t* tab, int CtMax, int D, float* dlogits) {
+    const int set = blockIdx.x, Ct = tab[set * 3 + 1], n = tab[set * 3 + 2];
+    rows += tab[set * 3];
     for (int id = threadIdx.x; id < Ct * n * D; id += blockDim.x) {
         const int q = id / D, d = id - q * D, c = q / n;
-        dlogits[(int64_t)rows[(int64_t)set * Ct * n + q] * D + d] = dprotos[((int64_t)set * Ct + c) * D + d] / (float)n;
+        dlogits[(int64_t)rows[q] * D + d] = dprotos[((int64_t)set * CtMax + c) * D + d] / (float)n;
     }
 }
 
@@ -409,7 +413,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
-            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo));
+            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
@@ -418,6 +422,11 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = fi; }
                 else { a.x = xin; a.ldx = fi; }
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
+                {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
+                    int64_t strict = gm_aggregate_bytes(b, fi);
+                    if (gather) strict += 4 * b->rows - 4 * b->rows * (int64_t)fi + std::min<int64_t>(4 * b->rows * (int64_t)fi, 4 * b->store->total_nodes * (int64_t)fi);
+                    gm_prof_note(GM_PROF_AGG_STRICT, strict);
+                }
                 GM_TRY(gm_launch_aggregate(a, st));
                 gm_prof_agg_end(st);
                 if (l == 0) c.z1_valid = 1;
@@ -466,7 +475,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
             gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
-            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo));
+            gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
             w.A = Xprev; w.lda = fi; w.G = T; w.ldg = fo; w.Gb = dQ; w.ldgb = fo;
@@ -495,7 +504,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
-                gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
+                gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
                 gm_prof_agg_end(st);
             }
@@ -659,7 +668,9 @@ extern "C" int gm_gcn_forward(const gm_batch_t* b, const gm_model_t* m, const fl
     gcn_carve(c, cv);
     GM_REQUIRE(cv.ok(), GM_ENOMEM, "gcn_forward: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
     c.x0_user = x0; c.centre = centre_local;
-    return gcn_forward(c, params, param_stride, logits, (hipStream_t)stream, 0);
+    const int rc = gcn_forward(c, params, param_stride, logits, (hipStream_t)stream, 0);
+    gm_batch_mark_use(b, (hipStream_t)stream);
+    return rc;
 }
 
 extern "C" int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* params, int64_t param_stride, const float* x0,
@@ -673,15 +684,23 @@ extern "C" int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const f
     gcn_carve(c, cv);
     GM_REQUIRE(cv.ok(), GM_ENOMEM, "gcn_backward: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
     c.x0_user = x0; c.centre = centre_local;
-    return gcn_backward(c, params, param_stride, dlogits, dparams, dparam_stride, (hipStream_t)stream);
+    const int rc = gcn_backward(c, params, param_stride, dlogits, dparams, dparam_stride, (hipStream_t)stream);
+    gm_batch_mark_use(b, (hipStream_t)stream);
+    return rc;
 }
 
 // ================================================================================ prototypical losses
 // Host side of meta.py:32-42,60-65: sorted unique classes, rows of each class (first n_support for the
-// support loss; all rows, equal counts required, for the query loss), as global subgraph ids.
-static int class_tables(const gm_batch* b, const int32_t* y, int limit, std::vector<int32_t>& rows, int* Ct, int* n) {
-    *Ct = -1; *n = -1;
-    rows.clear();
+// support loss; all rows, equal counts required, for the query loss), as global subgraph ids.  Every set (task) keeps its
+// own class layout -- the reference calls proto_loss_* once per task (meta.py:118-157), so a Shared dataset whose graphs
+// carry different label sets, or evaluation tasks of different shapes, are fine.
+struct ClassTables {
+    std::vector<int32_t> rows;          // concatenated per set: [Ct_t][n_t] subgraph ids
+    std::vector<int32_t> tab;           // [sets*3]: offset into rows, Ct_t, n_t
+    int Ct = 0, n = 0;                  // maxima over the sets (LDS sizing, prototype stride)
+};
+static int class_tables(const gm_batch* b, const int32_t* y, int limit, ClassTables& ct) {
+    ct.rows.clear(); ct.tab.assign((size_t)b->sets * 3, 0); ct.Ct = 0; ct.n = 0;
     for (int t = 0; t < b->sets; ++t) {
         std::map<int32_t, std::vector<int32_t>> by;
         for (int s = b->h_set_sub_off[t]; s < b->h_set_sub_off[t + 1]; ++s) by[y[s]].push_back(s);
@@ -696,11 +715,11 @@ static int class_tables(const gm_batch* b, const int32_t* y, int limit, std::vec
             GM_REQUIRE(cnt < 0 || cnt == c, GM_EINVAL, "proto loss: classes of set %d have unequal row counts (torch.stack at meta.py:65 fails)", t);
             cnt = c;
         }
-        GM_REQUIRE(*Ct < 0 || (*Ct == (int)by.size() && *n == cnt), GM_EINVAL, "proto loss: set %d has a different class layout than set 0", t);
-        *Ct = (int)by.size(); *n = cnt;
-        for (auto& kv : by) rows.insert(rows.end(), kv.second.begin(), kv.second.begin() + cnt);
+        ct.tab[t * 3] = (int32_t)ct.rows.size(); ct.tab[t * 3 + 1] = (int32_t)by.size(); ct.tab[t * 3 + 2] = cnt;
+        ct.Ct = std::max(ct.Ct, (int)by.size()); ct.n = std::max(ct.n, cnt);
+        for (auto& kv : by) ct.rows.insert(ct.rows.end(), kv.second.begin(), kv.second.begin() + cnt);
     }
-    GM_REQUIRE((int64_t)*Ct * *n <= 8192 && *Ct <= 256, GM_ERANGE, "proto loss: %d classes x %d rows per set is outside the kernel's range", *Ct, *n);
+    GM_REQUIRE((int64_t)ct.Ct * ct.n <= 8192 && ct.Ct <= 256, GM_ERANGE, "proto loss: %d classes x %d rows per set is outside the kernel's range", ct.Ct, ct.n);
     return GM_OK;
 }
 
@@ -712,19 +731,35 @@ static int launch_proto(const gm_batch* b, ProtoK k, hipStream_t st) {
     return GM_OK;
 }
 
+// rows + tab of a ClassTables on the device (one allocation: [rows | tab]); freed by the caller with gm_dev_free
+static int upload_tables(const ClassTables& ct, int32_t** d_out, hipStream_t st) {
+    *d_out = nullptr;
+    int32_t* d = nullptr;
+    GM_TRY(gm_alloc(&d, ct.rows.size() + ct.tab.size(), st));
+    if (hipMemcpyAsync(d, ct.rows.data(), 4 * ct.rows.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d + ct.rows.size(), ct.tab.data(), 4 * ct.tab.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {             // pageable sources: complete before `ct` can go away
+        gm_set_error("proto loss: class-table upload failed"); gm_dev_free(d, st); return GM_EHIP;
+    }
+    *d_out = d;
+    return GM_OK;
+}
+
 extern "C" int gm_proto_loss_spt(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, int32_t n_support, float* loss,
                                  float* acc, float* protos, float* dlogits, void* stream) {
     GM_REQUIRE(b && logits && y && loss && acc && n_support >= 1, GM_EINVAL, "proto_loss_spt: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    std::vector<int32_t> rows; int Ct, n;
-    GM_TRY(class_tables(b, y, n_support, rows, &Ct, &n));
+    ClassTables ct;
+    GM_TRY(class_tables(b, y, n_support, ct));
     int32_t* d_rows = nullptr;
-    GM_TRY(gm_alloc(&d_rows, rows.size(), st));
-    GM_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, st));
-    if (dlogits) GM_HIP(hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st));
-    ProtoK k{logits, n_out, d_rows, Ct, n, 0, nullptr, protos, loss, acc, 1, 0, dlogits, nullptr};
-    int rc = launch_proto(b, k, st);
-    GM_HIP(hipStreamSynchronize(st));
+    GM_TRY(upload_tables(ct, &d_rows, st));
+    int rc = GM_OK;
+    if (dlogits && hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st) != hipSuccess) { gm_set_error("proto_loss_spt: memset failed"); rc = GM_EHIP; }
+    if (rc == GM_OK) {
+        ProtoK k{logits, n_out, d_rows, ct.Ct, ct.n, 0, nullptr, protos, loss, acc, 1, 0, dlogits, nullptr, 0, d_rows + ct.rows.size()};
+        rc = launch_proto(b, k, st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) { gm_set_error("proto_loss_spt: kernel failed"); rc = GM_EHIP; }
     gm_dev_free(d_rows, st);
     return rc;
 }
@@ -733,16 +768,18 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
                                  float* loss, float* acc, float* dlogits, float* dprotos, void* stream) {
     GM_REQUIRE(b && logits && y && protos && loss && acc, GM_EINVAL, "proto_loss_qry: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    std::vector<int32_t> rows; int Ct, n;
-    GM_TRY(class_tables(b, y, 0, rows, &Ct, &n));
-    GM_REQUIRE(Ct == c_task, GM_EINVAL, "proto_loss_qry: %d query classes but %d prototypes", Ct, c_task);
+    ClassTables ct;
+    GM_TRY(class_tables(b, y, 0, ct));
+    GM_REQUIRE(ct.Ct == c_task, GM_EINVAL, "proto_loss_qry: %d query classes but %d prototypes", ct.Ct, c_task);
     int32_t* d_rows = nullptr;
-    GM_TRY(gm_alloc(&d_rows, rows.size(), st));
-    GM_HIP(hipMemcpyAsync(d_rows, rows.data(), 4 * rows.size(), hipMemcpyHostToDevice, st));
-    if (dlogits) GM_HIP(hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st));
-    ProtoK k{logits, n_out, d_rows, Ct, n, 1, protos, nullptr, loss, acc, 1, 0, dlogits, dprotos};
-    int rc = launch_proto(b, k, st);
-    GM_HIP(hipStreamSynchronize(st));
+    GM_TRY(upload_tables(ct, &d_rows, st));
+    int rc = GM_OK;
+    if (dlogits && hipMemsetAsync(dlogits, 0, sizeof(float) * b->subs * n_out, st) != hipSuccess) { gm_set_error("proto_loss_qry: memset failed"); rc = GM_EHIP; }
+    if (rc == GM_OK) {
+        ProtoK k{logits, n_out, d_rows, ct.Ct, ct.n, 1, protos, nullptr, loss, acc, 1, 0, dlogits, dprotos, 0, d_rows + ct.rows.size()};
+        rc = launch_proto(b, k, st);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == GM_OK) { gm_set_error("proto_loss_qry: kernel failed"); rc = GM_EHIP; }
     gm_dev_free(d_rows, st);
     return rc;
 }
@@ -771,8 +808,7 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     if (stage_on < 0) { const char* e = getenv("GM_HEAD_STAGE"); stage_on = e ? atoi(e) : 1; }
     const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
     const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
-    static bool attr = false;
-    if (!attr) { GM_HIP(hipFuncSetAttribute((const void*)k_head_loss, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    GM_TRY(gm_func_full_lds((const void*)k_head_loss));
     hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
                        bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f}, stage_h, (int)(proto_bytes / sizeof(float)));
     GM_HIP(hipGetLastError());
@@ -804,13 +840,48 @@ struct MetaStreams {
         return GM_OK;
     }
 };
-static MetaStreams& meta_streams() { static thread_local MetaStreams m; return m; }
+// One side stream / event pool / staging ring per (thread, device): a process may drive several GPUs.
+static MetaStreams& meta_streams() {
+    static thread_local std::map<int, MetaStreams> m;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    return m[dev];
+}
+
+// Pinned host staging for the per-step class tables: the H2D copy is truly asynchronous (no stream synchronisation in
+// gm_meta_step); a slot is reused only after the copy that read it has completed (4 slots: never waits in practice).
+struct StageRing {
+    static const int N = 4;
+    void* buf[N] = {}; size_t cap[N] = {}; hipEvent_t ev[N] = {}; bool busy[N] = {}; int next = 0;
+    int acquire(size_t bytes, void** out, int* slot) {
+        const int k = next; next = (next + 1) % N;
+        if (busy[k]) { GM_HIP(hipEventSynchronize(ev[k])); busy[k] = false; }
+        if (!ev[k]) GM_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        if (cap[k] < bytes) {
+            if (buf[k]) (void)hipHostFree(buf[k]);
+            buf[k] = nullptr; cap[k] = 0;
+            const size_t want = std::max<size_t>(bytes * 2, 64 * 1024);
+            GM_HIP(hipHostMalloc(&buf[k], want, hipHostMallocDefault));
+            cap[k] = want;
+        }
+        *out = buf[k]; *slot = k;
+        return GM_OK;
+    }
+    int release_after(int slot, hipStream_t st) { GM_HIP(hipEventRecord(ev[slot], st)); busy[slot] = true; return GM_OK; }
+};
+static StageRing& stage_ring() {
+    static thread_local std::map<int, StageRing> m;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    return m[dev];
+}
+
 struct MetaPlan {
     gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
     GcnCtx S, Q;
     float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq;
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
-    int32_t *rows_s, *rows_q;
+    int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q]
     int Ct, ns, nq;
 };
 
@@ -834,7 +905,11 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     p.protos = cv.take<float>(p.proto_sz * p.K); p.dprotos = cv.take<float>(p.proto_sz);
     p.ls = cv.take<float>((int64_t)p.T * K1); p.as_ = cv.take<float>((int64_t)p.T * K1);
     p.lq = cv.take<float>((int64_t)p.T * K1); p.aq = cv.take<float>((int64_t)p.T * K1);
-    p.rows_s = cv.take<int32_t>(spt->subs); p.rows_q = cv.take<int32_t>(qry->subs);
+    {   // rows of a set never exceed its subgraphs: [rows_s (spt->subs) | rows_q (qry->subs) | tab_s (3T) | tab_q (3T)]
+        int32_t* blk = cv.take<int32_t>((int64_t)spt->subs + qry->subs + 6 * (int64_t)p.T);
+        p.rows_s = blk; p.rows_q = blk ? blk + spt->subs : nullptr;
+        p.tab_s = blk ? p.rows_q + qry->subs : nullptr; p.tab_q = blk ? p.tab_s + 3 * p.T : nullptr;
+    }
     gcn_carve(p.S, cv); gcn_carve(p.Q, cv);
     p.Ct = Ct; p.ns = ns; p.nq = nq;
     if (need) *need = cv.used + 256;
@@ -867,16 +942,29 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_REQUIRE(((uintptr_t)theta & 15) == 0, GM_EINVAL, "meta_step: theta must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     gm_phase_timer tm("meta_step");
-    std::vector<int32_t> rows_s, rows_q; int Ct, ns, Ctq, nq;
-    GM_TRY(class_tables(spt, y_spt, hp->k_spt, rows_s, &Ct, &ns));
-    GM_TRY(class_tables(qry, y_qry, 0, rows_q, &Ctq, &nq));
-    GM_REQUIRE(Ct == Ctq, GM_EINVAL, "meta_step: %d support classes but %d query classes per task", Ct, Ctq);
+    ClassTables cs, cq;
+    GM_TRY(class_tables(spt, y_spt, hp->k_spt, cs));
+    GM_TRY(class_tables(qry, y_qry, 0, cq));
+    for (int t = 0; t < spt->sets; ++t)
+        GM_REQUIRE(cs.tab[t * 3 + 1] == cq.tab[t * 3 + 1], GM_EINVAL, "meta_step: task %d has %d support classes but %d query classes", t, cs.tab[t * 3 + 1], cq.tab[t * 3 + 1]);
+    const int Ct = cs.Ct, ns = cs.n, nq = cq.n;
     MetaPlan p;
     GM_TRY(meta_plan(p, spt, qry, m, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
     const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
-    GM_HIP(hipMemcpyAsync(p.rows_s, rows_s.data(), 4 * rows_s.size(), hipMemcpyHostToDevice, st));
-    GM_HIP(hipMemcpyAsync(p.rows_q, rows_q.data(), 4 * rows_q.size(), hipMemcpyHostToDevice, st));
-    GM_HIP(hipStreamSynchronize(st));       // pageable host vectors: make the copies complete before they go out of scope
+    {   // class tables -> pinned staging -> ONE asynchronous copy (no host synchronisation in the meta-step)
+        const size_t n_tab = (size_t)spt->subs + qry->subs + 6 * (size_t)T;
+        void* h = nullptr; int slot = 0;
+        StageRing& ring = stage_ring();
+        GM_TRY(ring.acquire(4 * n_tab, &h, &slot));
+        int32_t* hp32 = (int32_t*)h;
+        memset(hp32, 0, 4 * n_tab);
+        memcpy(hp32, cs.rows.data(), 4 * cs.rows.size());
+        memcpy(hp32 + spt->subs, cq.rows.data(), 4 * cq.rows.size());
+        memcpy(hp32 + spt->subs + qry->subs, cs.tab.data(), 4 * cs.tab.size());
+        memcpy(hp32 + spt->subs + qry->subs + 3 * (size_t)T, cq.tab.data(), 4 * cq.tab.size());
+        GM_HIP(hipMemcpyAsync(p.rows_s, h, 4 * n_tab, hipMemcpyHostToDevice, st));
+        GM_TRY(ring.release_after(slot, st));
+    }
     gm_prof_reset();
     tm.lap("plan");
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
@@ -899,7 +987,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     auto spt_step = [&](int k, const float* w, int64_t wstride, float* w_next) -> int {
         GM_TRY(gcn_forward(p.S, w, wstride, p.logit_s, st, hoist, 1));
         p.S.sgd = SgdK{w, wstride, w_next, Pp, hp->update_lr};
-        ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr};
+        ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr, 0, p.tab_s};
         GM_TRY(head_loss(p.S, w, wstride, p.logit_s, pk, 1, p.g, Pp, sparse, st));
         return GM_OK;
     };
@@ -912,7 +1000,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     // meta-gradient is wanted) once the prototypes / weights it needs are ready.
     auto qry_fwd = [&](const float* w, int64_t wstride) -> int { return gcn_forward(p.Q, w, wstride, p.logit_q, sq, hoist, 1); };
     auto qry_loss = [&](const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
-        ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr};
+        ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
         return head_loss(p.Q, w, wstride, p.logit_q, pk, grad ? 1 : 0, p.gq, Pp, sparse, sq);
     };
     // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq
@@ -942,7 +1030,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
             GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq, sparse, 1));
             wait(st, e_dp);
             GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
-            hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, Ct, ns, C, p.dlog_s);
+            hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, p.tab_s, Ct, C, p.dlog_s);
             GM_TRY(gcn_backward(p.S, fw(k), Pp, p.dlog_s, p.gp, Pp, st, sparse));
             have_grad = true;
         }
@@ -951,6 +1039,23 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     const int64_t tot = L.P + 2 * K1 + 1 + (int64_t)T * K1;
     hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
                        have_grad ? p.gq : nullptr, p.gp, Pp, L.P, T, p.lq, p.aq, K1, out);
+    GM_HIP(hipGetLastError());
+    gm_batch_mark_use(spt, st); gm_batch_mark_use(qry, st);
+    return GM_OK;
+}
+
+// ================================================================================ after the all-reduce
+// grad[i] = head[i] / task count ;  found_inf = isnan(losses_q[K] / task count)  (meta.py:161-163).  `head` is the
+// (all-reduced) [grad(P) | losses_q(K1) | corrects(K1) | count] block of gm_meta_step's output.
+__global__ void k_meta_finish(const float* head, int64_t P, int K1, float* grad, float* found_inf) {
+    const float cnt = head[P + 2 * K1];
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < P; id += (int64_t)gridDim.x * blockDim.x) grad[id] = head[id] / cnt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const float l = head[P + K1 - 1] / cnt; *found_inf = (l != l) ? 1.f : 0.f; }
+}
+
+extern "C" int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream) {
+    GM_REQUIRE(head && grad && found_inf && P >= 1 && K1 >= 1, GM_EINVAL, "meta_finish: bad arguments");
+    hipLaunchKernelGGL(k_meta_finish, dim3((int)std::min<int64_t>(512, (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head, P, K1, grad, found_inf);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

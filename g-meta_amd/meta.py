@@ -39,8 +39,10 @@ class Meta(nn.Module):
         self._ws = None
         self._keep = None
         self._flat_grad = None
+        self._flat_theta_buf = None
+        self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -54,9 +56,12 @@ class Meta(nn.Module):
     # ---- helpers
     def _make_adam(self):
         params = self.net.parameters()
+        self._adam_fused = False
         if all(p.is_cuda for p in params):
             try:                                   # one fused kernel instead of ~7 foreach launches (same update rule)
-                return optim.Adam(params, lr=self.meta_lr, fused=True)
+                opt = optim.Adam(params, lr=self.meta_lr, fused=True)
+                self._adam_fused = True
+                return opt
             except (TypeError, RuntimeError):
                 pass
         return optim.Adam(params, lr=self.meta_lr)
@@ -67,30 +72,45 @@ class Meta(nn.Module):
             self.meta_optim = self._make_adam()
         return r
 
-    def _bind_grads(self, dev):
-        """p.grad of every parameter is a view into one flat buffer, so the reduced meta-gradient is installed by a
-        single kernel.  (Re-bound if a deepcopy or an external zero_grad(set_to_none) broke the aliasing.)"""
+    def _bind_flat(self, attr, dev, grads):
+        """Every parameter (grads=False) or its .grad (grads=True) is a view into ONE flat fp32 buffer: the kernels read
+        theta / write the meta-gradient without a gather or scatter launch.  Re-bound whenever something (deepcopy, .to(),
+        zero_grad(set_to_none), load_state_dict on fresh tensors) broke the aliasing; values are preserved."""
         params = list(self.net.parameters())
         P = sum(p.numel() for p in params)
-        fg = getattr(self, '_flat_grad', None)
-        ok = fg is not None and fg.numel() == P and fg.device == dev
+        buf = getattr(self, attr, None)
+        ok = buf is not None and buf.numel() == P and buf.device == dev
         if ok:
             off = 0
             for p in params:
-                if p.grad is None or p.grad.data_ptr() != fg.data_ptr() + 4 * off:
+                t = p.grad if grads else p
+                if t is None or t.data_ptr() != buf.data_ptr() + 4 * off or not t.is_contiguous():
                     ok = False
                     break
                 off += p.numel()
         if not ok:
-            self._flat_grad = fg = torch.zeros(P, dtype=torch.float32, device=dev)
+            buf = torch.zeros(P, dtype=torch.float32, device=dev)
             off = 0
-            for p in params:
-                p.grad = fg[off:off + p.numel()].view_as(p)
-                off += p.numel()
-        return fg
+            with torch.no_grad():
+                for p in params:
+                    view = buf[off:off + p.numel()].view_as(p)
+                    if grads:
+                        p.grad = view
+                    else:
+                        view.copy_(p.detach())
+                        p.data = view
+                    off += p.numel()
+            setattr(self, attr, buf)
+        return buf
+
+    def _bind_grads(self, dev):
+        return self._bind_flat('_flat_grad', dev, True)
 
     def _flat_theta(self):
-        return torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).contiguous()
+        p0 = self.net.parameters()[0]
+        if not p0.is_cuda:
+            return torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).contiguous()
+        return self._bind_flat('_flat_theta_buf', p0.device, False)
 
     def _workspace(self, nbytes, dev):
         if self._ws is None or self._ws.numel() < nbytes or self._ws.device != dev:
@@ -109,6 +129,10 @@ class Meta(nn.Module):
         dev = theta.device
         if dev.type != 'cuda':
             raise RuntimeError('Meta parameters must live on the GPU (call .to("cuda")); there is no CPU fallback')
+        model = self.net.model
+        P = int(lib.gm_model_param_count(C.byref(model)))
+        if len(x_spt) == 0:               # an empty task shard (more ranks than tasks in a trailing meta-batch): contributes zeros
+            return torch.zeros(P + 2 * (K + 1) + 1, dtype=torch.float32, device=dev), P, 0
         if any(not isinstance(b, SubgraphBatch) for b in list(x_spt) + list(x_qry)):
             raise TypeError('x_spt / x_qry must be lists of gmeta_amd.SubgraphBatch (from gmeta_amd.Subgraphs)')
         S, Q = SubgraphBatch.concat(list(x_spt)), SubgraphBatch.concat(list(x_qry))
@@ -117,10 +141,8 @@ class Meta(nn.Module):
         yq = np.ascontiguousarray(np.concatenate([np.asarray(y).reshape(-1) for y in y_qry]), np.int32)
         if len(ys) != S.subs or len(yq) != Q.subs:
             raise ValueError('label count does not match the number of subgraphs')
-        model = self.net.model
         hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd),
                           int(self.cone))
-        P = int(lib.gm_model_param_count(C.byref(model)))
         n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
         ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
         if ws_bytes < 0 or n_out < 0:
@@ -132,8 +154,17 @@ class Meta(nn.Module):
         self._keep = (S, Q)             # keep concatenated batches alive until the stream has consumed them
         return out, P, T
 
+    @staticmethod
+    def _dist_on():
+        return torch.distributed.is_available() and torch.distributed.is_initialized()
+
     # ---- meta.py:101-173
-    def forward_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+    def forward_deferred(self, x_spt, y_spt, x_qry, y_qry, *unused):
+        """Meta.forward without the device->host read: everything of meta.py:101-173 is queued on the stream -- the K-step
+        inner loop over the local task shard, the all-reduce, the mean, the NaN guard and the Adam step all stay on the
+        device -- and a handle is returned whose .accs() performs the one read.  `maml(...)` == forward_deferred(...).accs();
+        a training loop that only looks at the accuracies every few steps (train.py:110) can keep the GPU busy while the host
+        prepares the next meta-batch."""
         K = self.update_step
         if K < 2:
             raise ValueError('update_step must be >= 2: losses_q[0] and [1] are computed under no_grad (meta.py:129-141), '
@@ -141,23 +172,27 @@ class Meta(nn.Module):
         out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, True)
         K1 = K + 1
         head = out[:P + 2 * K1 + 1]                           # [grad | losses_q | corrects | task count], contiguous view
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and (
-                torch.distributed.get_world_size() > 1 or getattr(self, 'force_allreduce', False)):
+        if self._dist_on() and (torch.distributed.get_world_size() > 1 or getattr(self, 'force_allreduce', False)):
             # Drain the compute stream first: queued behind pending work on another stream, torch's synchronous NCCL
             # all_reduce takes a slow wait path on this stack (measured: a constant +7 ms per call; 32 us otherwise).
-            # The host has to synchronise for the loss/accs readback two lines below anyway, so this costs nothing.
             if head.is_cuda:
                 torch.cuda.current_stream().synchronize()
             torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
-        tail = head[P:].cpu().numpy().astype(np.float64)     # the only device->host sync of the meta-step
-        task_num = float(tail[-1])
-        loss_q = tail[K1 - 1] / task_num                      # losses_q[-1] / task_num (meta.py:161)
-        self.last_stats = {'loss_q': loss_q, 'losses_q': tail[:K1] / task_num, 'task_num': task_num}
-        if not np.isnan(loss_q):                              # meta.py:163-169
+        if head.is_cuda and self._adam_fused:
+            # mean + NaN guard on the device (gm_meta_finish), then the fused Adam with `found_inf`: the kernel skips the
+            # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)
             fg = self._bind_grads(head.device)               # (stands for meta_optim.zero_grad(); loss_q.backward())
-            torch.div(head[:P], task_num, out=fg)
+            if getattr(self, '_found_inf', None) is None or self._found_inf.device != head.device:
+                self._found_inf = torch.zeros(1, dtype=torch.float32, device=head.device)
+            _lib.check(_lib.lib().gm_meta_finish(_lib.ptr(head), P, K1, _lib.ptr(fg), _lib.ptr(self._found_inf), _lib.stream_ptr()), 'gm_meta_finish')
+            self.meta_optim.found_inf = self._found_inf
+            self.meta_optim.grad_scale = None
             self.meta_optim.step()
-        return tail[K1:2 * K1] / task_num                     # np.array(corrects) / task_num (meta.py:171)
+            return _Deferred(self, head[P:], K1, applied=True)
+        return _Deferred(self, head, K1, applied=False, P=P)
+
+    def forward_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
+        return self.forward_deferred(x_spt, y_spt, x_qry, y_qry).accs()
 
     # ---- meta.py:175-234
     def finetunning_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
@@ -166,13 +201,24 @@ class Meta(nn.Module):
         K1 = K + 1
         return out[P + 2 * K1 + 1:P + 3 * K1 + 1].cpu().numpy().astype(np.float64)
 
-    def finetunning_batch(self, x_spt, y_spt, x_qry, y_qry):
+    def finetunning_batch(self, x_spt, y_spt, x_qry, y_qry, shard=False):
         """All given evaluation tasks in ONE call (the reference loops 100 val/test tasks one at a time,
-        train.py:118-121); returns accs [T, K_test+1]."""
+        train.py:118-121); returns accs [T, K_test+1].  shard=True under torch.distributed: every rank fine-tunes a
+        contiguous slice of the tasks (they are independent and nothing is updated, meta.py:181) and the per-task
+        accuracies are all-gathered, so every rank returns the full [T, K_test+1] array."""
         K = self.update_step_test
-        out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
         K1 = K + 1
-        return out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
+        n = len(x_spt)
+        world = torch.distributed.get_world_size() if (shard and self._dist_on()) else 1
+        if world == 1 and not (shard and self._dist_on() and getattr(self, 'force_allreduce', False)):
+            out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
+            return out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
+        rank = torch.distributed.get_rank()
+        bounds = np.linspace(0, n, world + 1).round().astype(int)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        out, P, T = self._run(x_spt[lo:hi], y_spt[lo:hi], x_qry[lo:hi], y_qry[lo:hi], K, False)
+        mine = out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1)
+        return gather_rows(mine, bounds, K1).cpu().numpy().astype(np.float64)
 
     def forward(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
         if self.method == 'G-Meta':
@@ -183,3 +229,43 @@ class Meta(nn.Module):
         if self.method == 'G-Meta':
             accs = self.finetunning_ProtoMAML(x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat)
         return accs
+
+
+def gather_rows(mine, bounds, width):
+    """all_gather of per-rank row blocks of unequal height: rank r owns rows [bounds[r], bounds[r+1]) of the result."""
+    world = len(bounds) - 1
+    cap = int(max(bounds[r + 1] - bounds[r] for r in range(world)))
+    pad = torch.zeros(cap, width, dtype=mine.dtype, device=mine.device)
+    pad[:mine.shape[0]] = mine
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    torch.distributed.all_gather(parts, pad)
+    return torch.cat([parts[r][:int(bounds[r + 1] - bounds[r])] for r in range(world)])
+
+
+class _Deferred:
+    """Result handle of Meta.forward_deferred: .accs() reads losses/accuracies back (the only device->host sync of a
+    meta-step) and returns np.array(corrects) / task_num (meta.py:171)."""
+
+    def __init__(self, meta, buf, K1, applied, P=0):
+        self._meta, self._buf, self._K1, self._applied, self._P = meta, buf, K1, applied, P
+        self._accs = None
+
+    def accs(self):
+        if self._accs is not None:
+            return self._accs
+        m, K1 = self._meta, self._K1
+        if self._applied:                                     # device path: Adam already queued, buf = [losses_q | corrects | count]
+            tail = self._buf.cpu().numpy().astype(np.float64)
+        else:                                                 # host path (non-fused Adam / CPU tensors): guard + step here
+            head, P = self._buf, self._P
+            tail = head[P:].cpu().numpy().astype(np.float64)
+        task_num = float(tail[-1])
+        loss_q = tail[K1 - 1] / task_num                      # losses_q[-1] / task_num (meta.py:161)
+        m.last_stats = {'loss_q': loss_q, 'losses_q': tail[:K1] / task_num, 'task_num': task_num}
+        if not self._applied and not np.isnan(loss_q):        # meta.py:163-169
+            fg = m._bind_grads(head.device)
+            torch.div(head[:P], task_num, out=fg)
+            m.meta_optim.step()
+        self._accs = tail[K1:2 * K1] / task_num               # np.array(corrects) / task_num (meta.py:171)
+        self._buf = None
+        return self._accs

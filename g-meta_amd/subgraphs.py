@@ -459,6 +459,8 @@ class Subgraphs(Dataset):
     def get_batch(self, indices):
         """MI355X-first counterpart of DataLoader(..., collate_fn=collate): the subgraphs of ALL tasks of a
         meta-batch are extracted by two launches (support / query); returns the collated 10-tuple of lists."""
+        if len(indices) == 0:           # an empty task shard (more ranks than tasks in a short trailing meta-batch)
+            return tuple([] for _ in range(10))
         arrs, S, Q = self._extract_tasks(indices)
         ys_yq = [self._labels(a[2], a[3]) for a in arrs]
         return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])

@@ -161,8 +161,9 @@ int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* param
 
 /* ---- Prototypical losses (meta.py:28-54 proto_loss_spt, 56-79 proto_loss_qry), per set.
  * y: HOST int32 [subs] labels.  Outputs (device): loss[sets], acc[sets], protos[sets, c_task, n_out]
- * (c_task = classes per set, must be equal across sets), dlogits[subs, n_out] (may be NULL),
- * dprotos[sets, c_task, n_out] (qry only, may be NULL). */
+ * (c_task = the LARGEST number of classes of any set; every set keeps its own class layout -- classes, rows per class --
+ * like the per-task calls of meta.py:118-157; set t uses the first classes_t rows of its [c_task, n_out] block),
+ * dlogits[subs, n_out] (may be NULL), dprotos[sets, c_task, n_out] (qry only, may be NULL). */
 int gm_proto_loss_spt(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, int32_t n_support,
                       float* loss, float* acc, float* protos, float* dlogits, void* stream);
 int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32_t n_out, const int32_t* y, const float* protos,
@@ -187,13 +188,21 @@ int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_
                  const gm_model_t* m, const gm_hparams_t* hp, const float* theta, float* out, void* ws,
                  int64_t ws_bytes, void* stream);
 
+/* After the (optional) all-reduce of out[0 .. P + 2*(K+1)] over the ranks: the mean meta-gradient and the NaN guard of
+ * meta.py:161-163, on the device.  head: device, the reduced block; grad: device fp32 [P] <- head[0..P) / task count;
+ * found_inf: device fp32 [1] <- 1.0 if losses_q[K] / task count is NaN else 0.0 (a fused Adam skips its step on 1.0, which
+ * is the reference's `if torch.isnan(loss_q): pass`).  K1 = update_step + 1. */
+int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream);
+
 /* Profiling aid for bench.py: HIP-event time (ms) of the aggregate launches of the last
  * gm_meta_step on this thread, their count and their summed algorithmic bytes.  Events are only
  * recorded when gm_profile_enable(1) was called (they add a few microseconds per launch). */
 void gm_profile_enable(int32_t on);
 int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes);
 /* Same for one launch category: 0 = aggregate (work = algorithmic bytes), 1 = grouped GEMM (forward and dZ; work =
- * flops 2*rows*K*N), 2 = weight gradient incl. its reduction (work = flops). */
+ * flops 2*rows*K*N), 2 = weight gradient incl. its reduction (work = flops), 3 = the aggregate launches of category 0
+ * priced at their COMPULSORY HBM bytes (a layer-1 launch that gathers from the store's feature table reads at most the
+ * whole table, not rows*width; total_ms is 0 for this category -- use category 0's). */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 
 #ifdef __cplusplus

@@ -38,3 +38,11 @@ int64_t oracle_khop_mark(int64_t n, const int64_t* indptr, const int32_t* indice
     }
     return count;
 }
+
+/* autograd backward of update_all(copy_src, sum): grad_x[u] = sum over out-edges (u->v) of g[v].
+ * indptr_t/indices_t = the same edges grouped by SOURCE (destinations in edge order), so every
+ * output row is owned by one thread and the summation order is fixed. */
+void oracle_agg_t_f32(int64_t n, int64_t F, const int64_t* indptr_t, const int64_t* indices_t,
+                      const float* g, float* out) {
+    oracle_agg_f32(n, F, indptr_t, indices_t, g, out);
+}

@@ -209,8 +209,27 @@ def agg(indptr, indices, x):
     return out
 
 
+def _by_source(batch):
+    """The batch's edges grouped by source (stable: destinations keep their edge order); built once per batch."""
+    c = getattr(batch, '_csr_t', None)
+    if c is None:
+        order = np.argsort(batch.indices, kind='stable')
+        ptr = np.zeros(batch.n + 1, np.int64)
+        np.add.at(ptr, np.asarray(batch.indices, np.int64) + 1, 1)
+        c = batch._csr_t = (np.cumsum(ptr), np.ascontiguousarray(batch.dst[order], np.int64))
+    return c
+
+
 def agg_t(batch, g):
     """autograd backward of update_all: grad_x[u] = sum_{(u->v)} g[v] (transposed pass)."""
+    lib = _load_c()
+    if lib and hasattr(lib, 'oracle_agg_t_f32'):
+        ptr, idx = _by_source(batch)
+        g = np.ascontiguousarray(g, f32)
+        out = np.zeros_like(g)
+        lib.oracle_agg_t_f32(ctypes.c_int64(batch.n), ctypes.c_int64(g.shape[1]), ptr.ctypes.data_as(ctypes.c_void_p),
+                             idx.ctypes.data_as(ctypes.c_void_p), g.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+        return out
     out = np.zeros_like(g)
     np.add.at(out, batch.indices, g[batch.dst])
     return out

@@ -20,6 +20,7 @@ import gmeta_amd                     # noqa: E402
 
 def main():
     rank, world, port, case, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    mode = sys.argv[6] if len(sys.argv) > 6 else 'train'      # 'train' | 'short' (one task only: rank 1 gets an EMPTY shard) | 'eval' (sharded finetunning)
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = port
     dist.init_process_group('gloo', rank=rank, world_size=world)
     fx = Fixture(case)
@@ -30,13 +31,14 @@ def main():
         for p, v in zip(m.net.parameters(), fx.vars0):
             p.copy_(torch.from_numpy(v))
     # contiguous task shard of this rank (uneven on purpose when T % world != 0)
-    bounds = np.linspace(0, fx.T, world + 1).round().astype(int)
+    n_tasks = 1 if mode == 'short' else fx.T
+    bounds = np.linspace(0, n_tasks, world + 1).round().astype(int)
     mine = list(range(bounds[rank], bounds[rank + 1]))
 
     def oracle_run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
         theta = [p.detach().numpy().copy() for p in self.net.parameters()]
         P = sum(t.size for t in theta); K1 = K + 1; T = len(x_spt)
-        out = np.zeros(P + 2 * K1 + 1 + T * K1, np.float32)
+        out = np.zeros(P + 2 * K1 + 1 + T * K1, np.float32)             # T == 0 (empty shard): all zeros, like Meta._run
         for t in range(T):
             with np.errstate(all='ignore'):
                 lq, aq, mg = orc.task_inner_loop(x_spt[t], x_qry[t], x_spt[t].features(fx.feats), x_qry[t].features(fx.feats), np.asarray(y_spt[t]),
@@ -50,6 +52,13 @@ def main():
     gmeta_amd.Meta._run = oracle_run
     spt = [orc.extract_batch(graphs, fx.z['spt_seeds'][t], fx.args['h'], fx.args['sample_nodes'], 222, fx.link, replay_nodes=fx.replay_lists('spt', t)) for t in mine]
     qry = [orc.extract_batch(graphs, fx.z['qry_seeds'][t], fx.args['h'], fx.args['sample_nodes'], 222, fx.link, replay_nodes=fx.replay_lists('qry', t)) for t in mine]
+    if mode == 'eval':
+        # train.py:evaluate under torch.distributed: every rank holds only ITS slice (None elsewhere), results all-gathered
+        pad = lambda part: [None] * int(bounds[rank]) + list(part) + [None] * (fx.T - int(bounds[rank + 1]))      # noqa: E731
+        accs = m.finetunning_batch(pad(spt), pad([fx.z['y_spt'][t] for t in mine]), pad(qry), pad([fx.z['y_qry'][t] for t in mine]), shard=True)
+        np.savez(os.path.join(outdir, 'rank%d.npz' % rank), accs=accs)
+        dist.barrier(); dist.destroy_process_group()
+        return
     accs = m(spt, [fx.z['y_spt'][t] for t in mine], qry, [fx.z['y_qry'][t] for t in mine], None, None, None, None, None, None, fx.feats)
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), accs=accs, loss_q=m.last_stats['loss_q'], task_num=m.last_stats['task_num'],
              **{'v%d' % k: p.detach().numpy() for k, p in enumerate(m.net.parameters())})

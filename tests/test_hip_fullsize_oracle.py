@@ -1,0 +1,176 @@
+"""GPU (-m gpu): HIP vs the oracle's FLOATS at the headline shapes, so that the kernel instantiations the bench runs are the
+ones compared -- BASELINE configs[1] (arxiv shape, T=8: the 286k-row query batch selects the 256-wide DMA GEMM, the
+8x8 / 4x8 weight-gradient tiles, the 64-row window aggregate + the hub-row kernel on sampled ~1000-node hub subgraphs)
+and the nominal sizes of configs[3] (Tissue shape: 24 x 2,100 nodes, in-degree ~50, F0=50, H=128, every subgraph sampled,
+in-degree ~24 inside a subgraph) and configs[4] (FirstMM shape: 41 directed graphs x 1,400 nodes, F0=5, pair centres, head
+[2, 2H]).  learner.py:25-56,134-175 / meta.py:101-173 against oracle/gmeta_oracle.py, tolerance 1e-4 (north star).
+
+The oracle walks the SAME node sets (replayed from the HIP extraction, which the other tests pin bit-exactly; a sample of
+subgraphs is re-derived here with the oracle's own k-hop + keyed sampler) because its Python extraction of 600+ sampled
+subgraphs would take minutes; everything after the node sets -- induced CSR, degrees, features, every float -- is its own."""
+import argparse
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import gmeta_oracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+K = 3
+
+
+def _world(name, T):
+    import gmeta_amd
+    from gmeta_amd import synth
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args(name, task_num=T, update_step=K, update_step_test=K)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=T, args=args,
+                             adjs=store, h=cfg['h'], tables=data['tables'], verbose=False)
+    batch = db.get_batch(list(range(T)))
+    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], synth.n_out(cfg), link=bool(cfg.get('link')))
+    og = [orc.Graph(*g) for g in data['graphs']]
+    S, Q = batch[0][0].view_of, batch[2][0].view_of
+    ob = {}
+    for tag, B, col in (('spt', S, 0), ('qry', Q, 1)):
+        par, off, so = B.parent(), B.sub_off, B.set_sub_off
+        ob[tag] = []
+        for t in range(T):
+            seeds = [tuple(int(v) for v in s) for s in db._task_arrays(t)[col]]
+            ob[tag].append(orc.Batch(og, seeds, [par[off[k]:off[k + 1]] for k in range(so[t], so[t + 1])]))
+    return dict(args=args, cfg=cfg, data=data, store=store, db=db, batch=batch, config=config, og=og, S=S, Q=Q, ob=ob, T=T, link=bool(cfg.get('link')))
+
+
+@pytest.fixture(scope='module')
+def arxiv():
+    return _world('arxiv', 8)
+
+
+def _check_extraction_sample(w, stride):
+    """The replayed node sets are the oracle's own for a sample of subgraphs (k-hop / link-pred expansion + keyed sampler)."""
+    cfg, n_sampled = w['cfg'], 0
+    for tag, B, col in (('spt', w['S'], 0), ('qry', w['Q'], 1)):
+        par, off = B.parent(), B.sub_off
+        seeds = np.concatenate([w['db']._task_arrays(t)[col] for t in range(w['T'])])
+        for k in range(0, B.subs, stride):
+            g, i, j = (int(v) for v in seeds[k])
+            full = orc.linkpred_nodes(w['og'][g], i, j) if w['link'] else orc.khop_nodes(w['og'][g], i, cfg['h'])
+            want = orc.sample_nodes(full, cfg['sample_nodes'], 222, g, i, j if w['link'] else -1)
+            n_sampled += int(len(full) > cfg['sample_nodes'])
+            assert np.array_equal(par[off[k]:off[k + 1]], want), (tag, k)
+    return n_sampled
+
+
+def _meta_vs_oracle(w, tol_grad=TOL):
+    import gmeta_amd
+    torch.manual_seed(11)
+    m = gmeta_amd.Meta(w['args'], w['config']).to('cuda')
+    theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+    grads = {}
+    orig = m.meta_optim.step
+    m.meta_optim.step = lambda *a, **k: (grads.setdefault('g', torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy().copy()), orig(*a, **k))[1]
+    b = w['batch']
+    accs = m(*b, w['data']['feats'])
+    ys = [np.asarray(y) for y in b[1]]; yq = [np.asarray(y) for y in b[3]]
+    T = w['T']
+    lq_sum, g_sum, acc_t = np.zeros(K + 1), None, []
+    for t in range(T):
+        bs, bq = w['ob']['spt'][t], w['ob']['qry'][t]
+        lq, aq, mg = orc.task_inner_loop(bs, bq, bs.features(w['data']['feats']), bq.features(w['data']['feats']), ys[t], yq[t], theta0, w['config'],
+                                         w['args'].k_spt, w['args'].update_lr, K, True)
+        lq_sum += lq; acc_t.append(aq)
+        flat = np.concatenate([g.reshape(-1) for g in mg]).astype(np.float64)
+        g_sum = flat if g_sum is None else g_sum + flat
+    np.testing.assert_allclose(accs, np.mean(acc_t, axis=0), atol=1e-6)                       # corrects / task_num (meta.py:171)
+    np.testing.assert_allclose(m.last_stats['losses_q'], lq_sum / T, atol=TOL, rtol=1e-4)     # losses_q[k] / task_num
+    np.testing.assert_allclose(grads['g'], g_sum / T, atol=tol_grad, rtol=1e-3)               # theta.grad before Adam
+    # per-task accuracies of every step (the [sets, K+1] block of gm_meta_step's output) through finetunning on the same theta
+    return m, theta0
+
+
+def test_arxiv_extraction_sample_is_the_oracles(arxiv):
+    assert _check_extraction_sample(arxiv, 23) > 0          # sampled hub subgraphs are among the checked ones
+
+
+def test_arxiv_meta_step_floats_match_oracle(arxiv):
+    """gm_meta_step at the arxiv shape, T=8 (production kernel selection), against the oracle on ALL 8 tasks: accuracies,
+    losses_q of every step, and the first-order meta-gradient."""
+    assert arxiv['Q'].rows >= 196608, 'query batch too small to select the 256-wide GEMM tiles'
+    sizes = np.diff(arxiv['Q'].sub_off)
+    assert (sizes >= 1000).any(), 'no sampled hub subgraph in this batch'
+    _meta_vs_oracle(arxiv)
+
+
+def test_arxiv_forward_backward_per_task_weights_match_oracle(arxiv):
+    """gm_gcn_forward / gm_gcn_backward with param_stride = P (every task its own fast weights, as inside the K-loop) on the
+    286k-row query batch: per-set logits and per-set parameter gradients of two tasks -- one of them holding the largest
+    (sampled, hub-centred) subgraph -- against the oracle's forward/backward (learner.py:25-56,134-175)."""
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    w = arxiv
+    Q, T = w['Q'], w['T']
+    model = _lib.make_model(w['config'])
+    P = int(lib.gm_model_param_count(C.byref(model)))
+    Pp = (P + 63) // 64 * 64
+    rng = np.random.default_rng(3)
+    thetas = []
+    params = np.zeros((T, Pp), np.float32)
+    for t in range(T):                                       # distinct weights per task
+        th = []
+        for name, p in w['config']:
+            if name == 'GraphConv':
+                th += [(rng.standard_normal(p) * np.sqrt(2.0 / sum(p))).astype(np.float32), (rng.standard_normal(p[1]) * 0.1).astype(np.float32)]
+            elif name == 'Linear':
+                th += [(rng.standard_normal((p[1], p[0])) * 0.2).astype(np.float32), (rng.standard_normal(p[1]) * 0.1).astype(np.float32)]
+        thetas.append(th)
+        params[t, :P] = np.concatenate([v.reshape(-1) for v in th])
+    d_params = torch.from_numpy(params).cuda()
+    ws_bytes = int(lib.gm_gcn_ws_bytes(Q.handle, C.byref(model)))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device='cuda')
+    logits = torch.empty(Q.subs, model.n_out, dtype=torch.float32, device='cuda')
+    _lib.check(lib.gm_gcn_forward(Q.handle, C.byref(model), _lib.ptr(d_params), Pp, None, None, _lib.ptr(logits), _lib.ptr(ws), ws_bytes, _lib.stream_ptr()))
+    dlog = rng.standard_normal((Q.subs, model.n_out)).astype(np.float32)
+    d_dlog = torch.from_numpy(dlog).cuda()
+    dparams = torch.zeros(T, Pp, dtype=torch.float32, device='cuda')
+    _lib.check(lib.gm_gcn_backward(Q.handle, C.byref(model), _lib.ptr(d_params), Pp, None, None, _lib.ptr(d_dlog), _lib.ptr(dparams), Pp, _lib.ptr(ws),
+                                   ws_bytes, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    logits, dparams = logits.cpu().numpy(), dparams.cpu().numpy()
+    so = Q.set_sub_off
+    sizes = np.diff(Q.sub_off)
+    t_hub = int(np.searchsorted(so, int(np.argmax(sizes)), side='right') - 1)
+    for t in sorted({t_hub, (t_hub + 3) % T}):
+        ob = w['ob']['qry'][t]
+        lo, cache = orc.classifier_forward(ob, ob.features(w['data']['feats']), thetas[t], w['config'])
+        np.testing.assert_allclose(logits[so[t]:so[t + 1]], lo, atol=TOL, rtol=1e-4)
+        og = orc.classifier_backward(ob, thetas[t], w['config'], cache, dlog[so[t]:so[t + 1]])
+        want = np.concatenate([g.reshape(-1) for g in og])
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(dparams[t, :P], want, atol=TOL * scale, rtol=1e-3)
+
+
+@pytest.mark.parametrize('name', ['tissue', 'firstmm'])
+def test_nominal_size_configs_match_oracle(name):
+    """BASELINE configs[3] / configs[4] at SURVEY 8(d)'s nominal sizes and their own task_num (4 / 8), K=3: extraction sample
+    bit-exact, then accuracies / losses / meta-gradient of the whole meta-step against the oracle on every task, and the
+    batched finetunning against the oracle's per-task loop (meta.py:175-234)."""
+    from gmeta_amd import synth
+    w = _world(name, synth.CONFIGS[name]['task_num'])
+    n_sampled = _check_extraction_sample(w, 11)
+    if name == 'tissue':
+        assert n_sampled > 0                                  # a 2-hop neighbourhood covers the 2,100-node graph: every subgraph sampled
+        deg = np.diff(w['Q'].csr()[0])
+        assert deg.mean() > 10                                # dense induced subgraphs: the degree profile the arxiv shape does not have
+    m, theta0 = _meta_vs_oracle(w)
+    theta1 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+    b = w['batch']
+    ft = m.finetunning_batch(b[0], b[1], b[2], b[3])
+    for t in (0, w['T'] - 1):
+        o = orc.finetune(w['og'], w['data']['feats'], w['ob']['spt'][t], w['ob']['qry'][t], np.asarray(b[1][t]), np.asarray(b[3][t]), theta1, w['config'],
+                         w['args'].k_spt, w['args'].update_lr, K)
+        np.testing.assert_allclose(ft[t], o, atol=1e-6)

@@ -89,28 +89,51 @@ def main(args):
     mk = lambda mode, b: gmeta_amd.Subgraphs(root, mode, info, n_way=args.n_way, k_shot=args.k_spt, k_query=args.k_qry, batchsz=b,  # noqa: E731
                                              args=args, adjs=store, h=args.h, verbose=rank == 0)
     db_train, db_val, db_test = mk('train', args.batchsz), mk('val', args.eval_tasks), mk('test', args.eval_tasks)
-    per = max(1, args.task_num // world)
+    if world > args.task_num:
+        raise SystemExit('task_num=%d cannot be sharded over %d ranks (every rank needs at least one task of a full meta-batch)' % (args.task_num, world))
+    n_steps = -(-len(db_train) // args.task_num)      # DataLoader(db_train, task_num, shuffle=True) keeps the short last batch (drop_last=False, train.py:96)
+    if n_steps == 0:
+        raise SystemExit('batchsz=%d yields no meta-batch' % len(db_train))
     max_acc, model_max = 0, copy.deepcopy(maml)
     s_start = time.time()
 
     def evaluate(model, db):
-        x = db.get_batch(list(range(len(db))))
-        return model.finetunning_batch(x[0], x[1], x[2], x[3]).mean(axis=0)        # mean over tasks (train.py:123,136)
+        """train.py:115-123,129-141: fine-tune every val/test task.  Under torch.distributed the tasks are split over the ranks
+        (independent, nothing is updated) and the accuracies all-gathered; every rank extracts only its slice."""
+        n = len(db)
+        if world > 1:
+            b = np.linspace(0, n, world + 1).round().astype(int)
+            mine = list(range(int(b[rank]), int(b[rank + 1])))
+            x = db.get_batch(mine) if mine else ([], [], [], [])
+            pad = lambda part: [None] * int(b[rank]) + list(part) + [None] * (n - int(b[rank + 1]))      # noqa: E731
+            accs = model.finetunning_batch(pad(x[0]), pad(x[1]), pad(x[2]), pad(x[3]), shard=True)
+        else:
+            x = db.get_batch(list(range(n)))
+            accs = model.finetunning_batch(x[0], x[1], x[2], x[3])
+        return accs.mean(axis=0)                                                     # mean over tasks (train.py:123,136)
 
     for epoch in range(args.epoch):
-        order = np.random.permutation(len(db_train))                                # DataLoader(shuffle=True), train.py:96
-        n_steps = len(order) // args.task_num
-        shards = [order[step * args.task_num:(step + 1) * args.task_num][rank * per:(rank + 1) * per] for step in range(n_steps)]
+        # DataLoader(shuffle=True) (train.py:96).  The permutation comes from a PRIVATE generator, identical on every rank: the
+        # global numpy RNG belongs to the node sampler of --sample_mode reference (sdp.py:313), whose consumption differs per rank.
+        order = np.random.RandomState(222 + epoch).permutation(len(db_train))
+        shards = []
+        for step in range(n_steps):
+            chunk = order[step * args.task_num:(step + 1) * args.task_num]            # the last one may be short
+            b = np.linspace(0, len(chunk), world + 1).round().astype(int)
+            shards.append(chunk[int(b[rank]):int(b[rank + 1])])                       # may be empty on a short trailing batch: contributes zeros
         it = iter(db_train.batches(shards, prefetch=args.num_workers, cone_layers=args.h if getattr(args, 'cone', 0) else 0))
         for step in range(n_steps):
             s = time.time()
             batch = next(it)            # extracted by the prefetch thread while the previous meta-step ran (num_workers > 0)
             t_load = time.time() - s
             s = time.time()
-            accs = maml(*batch, feat)
-            if step % args.train_result_report_steps == 0 and rank == 0:
-                print('Epoch:', epoch + 1, ' Step:', step, ' training acc:', str(accs[-1])[:5], ' time elapsed:', str(time.time() - s)[:5],
-                      ' data loading takes:', str(t_load)[:5])
+            report = step % args.train_result_report_steps == 0
+            res = maml.forward_deferred(*batch[:4])      # whole meta-step incl. all-reduce + Adam queued on the GPU
+            if report:                                   # the accuracies are only read when they are printed (train.py:110)
+                accs = res.accs()
+                if rank == 0:
+                    print('Epoch:', epoch + 1, ' Step:', step, ' training acc:', str(accs[-1])[:5], ' time elapsed:', str(time.time() - s)[:5],
+                          ' data loading takes:', str(t_load)[:5])
         accs = evaluate(maml, db_val)
         if rank == 0:
             print('Epoch:', epoch + 1, ' Val acc:', str(accs[-1])[:5])
