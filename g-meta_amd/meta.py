@@ -183,7 +183,7 @@ class Meta(nn.Module):
             # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)
             fg = self._bind_grads(head.device)               # (stands for meta_optim.zero_grad(); loss_q.backward())
             if getattr(self, '_found_inf', None) is None or self._found_inf.device != head.device:
-                self._found_inf = torch.zeros(1, dtype=torch.float32, device=head.device)
+                self._found_inf = torch.zeros((), dtype=torch.float32, device=head.device)      # 0-dim: what GradScaler hands a fused optimiser
             _lib.check(_lib.lib().gm_meta_finish(_lib.ptr(head), P, K1, _lib.ptr(fg), _lib.ptr(self._found_inf), _lib.stream_ptr()), 'gm_meta_finish')
             self.meta_optim.found_inf = self._found_inf
             self.meta_optim.grad_scale = None
