@@ -17,6 +17,7 @@ struct AggK {
     const int32_t* set_row_off; int n_sets; int relu; float* out; int64_t rows; int width; int nblocks;
     const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* heavy; int n_heavy, heavy_deg;
+    const int32_t* sched; int sched_len;      // optional block schedule: entry >= 0 window block, <= -2 hub row, -1 nothing
     int nt;                    // 1: non-temporal output stores (Z is not re-read by this kernel; keep L2 for the X gathers)
     int win;                   // rows per wave window (64 for big batches; smaller when the batch would underfill the chip)
 };
@@ -100,11 +101,9 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
 // The 1024/LPR lane groups take interleaved LPR-edge chunks (coalesced index loads, 8 row loads in flight each), the
 // partial rows are summed through LDS in a fixed order (deterministic), then the usual epilogue.
 #define AGG_HEAVY_BLOCK 1024
-template <int LPR, int NCH>
-__global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
-    constexpr int NG = AGG_HEAVY_BLOCK / LPR;
-    const int row = a.heavy[blockIdx.x];
-    __shared__ __attribute__((aligned(16))) float part[NG * LPR * 4 * NCH];
+template <int LPR, int NCH, int NTHREADS>
+__device__ __forceinline__ void agg_heavy_row(const AggK& a, const int row, float* part) {
+    constexpr int NG = NTHREADS / LPR;
     const int tid = threadIdx.x, gi = tid / LPR, l = tid % LPR, lane = tid & 63;
     const int gbase = (lane / LPR) * LPR;                 // first lane of this group inside its wave
     const int e0 = a.indptr[row], e1 = a.indptr[row + 1];
@@ -165,6 +164,11 @@ __global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
         *reinterpret_cast<float4*>(a.out + (int64_t)row * a.width + l * 4 + c * LPR * 4) = v;
     }
 }
+template <int LPR, int NCH>
+__global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
+    __shared__ __attribute__((aligned(16))) float part[(AGG_HEAVY_BLOCK / LPR) * LPR * 4 * NCH];
+    agg_heavy_row<LPR, NCH, AGG_HEAVY_BLOCK>(a, a.heavy[blockIdx.x], part);
+}
 
 // Wave-cooperative kernel (the production path for widths 64/128/256/512).  Induced subgraphs are very sparse
 // (arxiv config: median in-degree 1, p90 2), so a row-per-wave kernel spends its life in the dependent chain
@@ -178,7 +182,21 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     constexpr int G = GM_WAVE / LPR;           // rows processed side by side
     const int nb = a.nblocks, b = blockIdx.x;
     const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
-    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (a.sched) {
+        // One launch for everything: the schedule interleaves a 256-thread block per hub row (in-degree > heavy_deg) with the
+        // window blocks of the hub's own subgraph, on the XCD that owns them -- the hub gathers ~every row of its subgraph,
+        // which the neighbouring window blocks are pulling through that XCD's L2 at that moment.  (As a separate launch the
+        // hub rows re-read their subgraphs from HBM: 0.25 % of the rows caused ~40 % of the fetch traffic.)
+        const int e = a.sched[xcd * a.sched_len + idx];
+        if (e == -1) return;
+        if (e < -1) {
+            __shared__ __attribute__((aligned(16))) float part[AGG_BLOCK * 4 * NCH];
+            agg_heavy_row<LPR, NCH, AGG_BLOCK>(a, a.heavy[-e - 2], part);
+            return;
+        }
+        lb = e;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPR, l = lane % LPR;
     const int64_t R0 = ((int64_t)lb * (AGG_BLOCK / GM_WAVE) + wave) * a.win;
@@ -279,6 +297,46 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     }
 }
 
+int gm_agg_window(int64_t rows) {
+    static int min_waves = -1;
+    if (min_waves < 0) { const char* e = getenv("GM_AGG_MIN_WAVES"); min_waves = e ? atoi(e) : 65536; }
+    static int min_win = -1;
+    if (min_win < 0) { const char* e = getenv("GM_AGG_MIN_WIN"); min_win = e ? atoi(e) : 2; if (min_win < 1) min_win = 1; }
+    int win = 64;
+    while (win > min_win && rows / win < min_waves) win >>= 1;
+    return win;
+}
+
+int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heavy, int32_t** d_sched, int32_t* len_out, hipStream_t s) {
+    *d_sched = nullptr; *len_out = 0;
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("GM_AGG_SCHED"); on = e ? atoi(e) : 1; }
+    if (!on || n_heavy <= 0 || rows <= 0) return GM_OK;                  // no hub rows: the plain window launch
+    const int RPB = win * (AGG_BLOCK / GM_WAVE);
+    const int nwb = (int)((rows + RPB - 1) / RPB);
+    const int q = nwb / GM_NXCD, r = nwb % GM_NXCD;
+    std::vector<std::vector<int32_t>> lists(GM_NXCD);
+    int hk = 0;
+    for (int x = 0; x < GM_NXCD; ++x) {
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = x < r ? q + 1 : q;
+        lists[x].reserve(cnt + 8);
+        for (int wb = start; wb < start + cnt; ++wb) {
+            lists[x].push_back(wb);
+            while (hk < n_heavy && heavy_host[hk] / RPB == wb) { lists[x].push_back(-(hk) - 2); ++hk; }     // heavy_host is ascending
+        }
+    }
+    GM_REQUIRE(hk == n_heavy, GM_EINVAL, "aggregate schedule: hub-row list is not ascending / out of range");
+    size_t len = 0;
+    for (auto& l : lists) len = std::max(len, l.size());
+    std::vector<int32_t> flat(GM_NXCD * len, -1);
+    for (int x = 0; x < GM_NXCD; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * len);
+    GM_TRY(gm_alloc(d_sched, flat.size(), s));
+    GM_HIP(hipMemcpyAsync(*d_sched, flat.data(), 4 * flat.size(), hipMemcpyHostToDevice, s));
+    GM_HIP(hipStreamSynchronize(s));            // `flat` is pageable and goes out of scope
+    *len_out = (int32_t)len;
+    return GM_OK;
+}
+
 template <int LPR, int NCH>
 static void launch_win(const AggK& a0, hipStream_t s) {
     AggK a = a0;
@@ -286,21 +344,18 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     // keep the rows in flight on an XCD within reach of its 4-MiB L2 -- a source row is gathered by ~2 destination rows
     // of the same subgraph, and the second gather only hits if it follows the first closely (measured on the 1.1 M-row
     // query batch: 4.2 -> 4.6 TB/s) -- and spread small batches (support sets, a 4-task shard) over the whole chip.
-    static int min_waves = -1;
-    if (min_waves < 0) { const char* e = getenv("GM_AGG_MIN_WAVES"); min_waves = e ? atoi(e) : 65536; }
-    static int min_win = -1;
-    if (min_win < 0) { const char* e = getenv("GM_AGG_MIN_WIN"); min_win = e ? atoi(e) : 2; if (min_win < 1) min_win = 1; }
-    a.win = 64;
-    while (a.win > min_win && a.rows / a.win < min_waves) a.win >>= 1;
+    a.win = a.sched ? a0.win : gm_agg_window(a.rows);
     const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
     a.nblocks = (int)((a.rows + RPB - 1) / RPB);
-    if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
+    int grid = a.nblocks;
+    if (a.sched) grid = GM_NXCD * a.sched_len;
+    else if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
     static int unr = -1;
     if (unr < 0) { const char* e = getenv("GM_AGG_UNR"); unr = e ? atoi(e) : 24; }
-#define GM_AGG_CASE(U_, M_) if (unr == U_ * 10 + M_) { hipLaunchKernelGGL((k_agg_win<LPR, NCH, U_, M_>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a); return; }
+#define GM_AGG_CASE(U_, M_) if (unr == U_ * 10 + M_) { hipLaunchKernelGGL((k_agg_win<LPR, NCH, U_, M_>), dim3(grid), dim3(AGG_BLOCK), 0, s, a); return; }
     GM_AGG_CASE(1, 2) GM_AGG_CASE(1, 4) GM_AGG_CASE(2, 2) GM_AGG_CASE(2, 4) GM_AGG_CASE(4, 2) GM_AGG_CASE(4, 4) GM_AGG_CASE(3, 4) GM_AGG_CASE(2, 6)
 #undef GM_AGG_CASE
-    hipLaunchKernelGGL((k_agg_win<LPR, NCH, 2, 4>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
+    hipLaunchKernelGGL((k_agg_win<LPR, NCH, 2, 4>), dim3(grid), dim3(AGG_BLOCK), 0, s, a);
 }
 
 template <int VEC, int LPR>
@@ -325,13 +380,14 @@ static int agg_variant() {
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
-           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg, agg_nt(), 64};
+           g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
+           g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
     GM_REQUIRE(!(g.mask_b || g.relu_bits) || vec4, GM_EINVAL, "aggregate: packed relu masks need width %% 4 == 0 and 16-byte aligned operands");
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
-    if (!win) { a.heavy = nullptr; a.n_heavy = 0; }      // the generic kernel walks every row itself
+    if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; }      // the generic kernel walks every row itself
     if (win) {
         if (g.width == 64) launch_win<16, 1>(a, s);
         else if (g.width == 128) launch_win<32, 1>(a, s);
@@ -376,6 +432,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.x_row = gather ? b->d_feat_row : nullptr;
     a.ldx = width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
+    a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win;
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

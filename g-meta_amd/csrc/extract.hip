@@ -363,7 +363,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_parent, s); gm_dev_free(b->d_feat_row, s); gm_dev_free(b->d_indptr, s); gm_dev_free(b->d_indices, s);
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
-    gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s);
+    gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
     gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
     gm_dev_free(b->d_e1_chunks, s); gm_dev_free(b->d_e1_set_chunk_off, s);
@@ -408,13 +408,15 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     GM_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
     gm_dev_free(d_cnt, s);
+    b->sched_win = gm_agg_window(b->rows);
     for (int o = 0; o < 2; ++o) {
         b->n_heavy[o] = std::min(cnt[o], cap);
-        if (b->n_heavy[o] > 1) {         // deterministic order (atomic append order is not)
+        if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
             std::vector<int32_t> h(b->n_heavy[o]);
             GM_HIP(hipMemcpy(h.data(), b->d_heavy[o], 4 * h.size(), hipMemcpyDeviceToHost));
             std::sort(h.begin(), h.end());
-            GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
+            if (h.size() > 1) GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
+            GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), b->n_heavy[o], &b->d_sched[o], &b->sched_len[o], s));
         }
     }
     tm.lap("heavy");

@@ -1,0 +1,291 @@
+// fp32 GEMM on the bf16 matrix cores by exact operand splitting (gfx950).
+//
+// The update GEMMs of GraphConv (learner.py:36,47) are fp32 in the reference.  The f32-input MFMA
+// (v_mfma_f32_32x32x2_f32) runs at the vector rate, 1/16 of the bf16 rate, so the step was bound by it.  Here every
+// fp32 operand x is split EXACTLY into three bf16 pieces by truncation,
+//     x = x_h + x_m + x_l,   x_h = top 8 significand bits, x_m = next 8, x_l = last 8   (8+8+8 = 24 bits of an fp32),
+// and a*b is evaluated as the six products whose weight is >= 2^-16,
+//     a*b ~= a_h b_h + a_h b_m + a_m b_h + a_h b_l + a_l b_h + a_m b_m,
+// each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The three dropped terms are
+// bounded by (2^-24 + 2^-24 + 2^-32) |a||b| ~= 1.2e-7 |a||b| per product -- the size of ONE fp32 rounding -- so the
+// result is an fp32-accurate product (measured against fp64: same error as the fmaf chain, see tools/gemm_split_bench.hip),
+// at 6/16 of the f32-MFMA cost.  Splitting costs ~5.5 VALU ops per element and is done ONCE per block tile when the A
+// rows are staged into LDS; the (small, per-task) weights are split once per launch by k_split_w into three bf16 planes
+// stored [n][k] (k contiguous), so the B tiles are DMA-ed straight into LDS in MFMA fragment order.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
+
+#define GS_BM 128
+
+struct SplitGemmK {
+    const float* A; int64_t lda;
+    const uint16_t* Bt; int64_t bt_stride;     // split weights [set][3][K/8][N][8] bf16 (k_split_w), per-set stride in ELEMENTS (0 = shared)
+    float* C; int64_t ldc; int K, N;
+    const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
+    const uint8_t* mask_b; uint8_t* relu_bits;
+    const int32_t* tiles; int n_tiles; int n_col_tiles; int nt_store;
+};
+
+// x (4 floats) -> three packed bf16x4 (8 bytes each): h = trunc16(x), m = trunc16(x - h), l = x - h - m (exact in bf16)
+__device__ __forceinline__ void gs_split4(const float4 v, uint2& h, uint2& m, uint2& l) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    uint32_t xh[4], xm[4], xl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t b = __float_as_uint(x[i]);
+        xh[i] = b & 0xffff0000u;
+        const float r1 = x[i] - __uint_as_float(xh[i]);            // exact
+        const uint32_t b1 = __float_as_uint(r1);
+        xm[i] = b1 & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(xm[i]);              // exact, <= 8 significant bits
+        xl[i] = __float_as_uint(r2);
+    }
+    // pack pairs: (hi16 of element 1) << 16 | hi16 of element 0
+    h.x = __builtin_amdgcn_perm(xh[1], xh[0], 0x07060302u); h.y = __builtin_amdgcn_perm(xh[3], xh[2], 0x07060302u);
+    m.x = __builtin_amdgcn_perm(xm[1], xm[0], 0x07060302u); m.y = __builtin_amdgcn_perm(xm[3], xm[2], 0x07060302u);
+    l.x = __builtin_amdgcn_perm(xl[1], xl[0], 0x07060302u); l.y = __builtin_amdgcn_perm(xl[3], xl[2], 0x07060302u);
+}
+
+// Weights -> split planes.  W_t = params + t*pstride + w_off.  trans = 0: the GEMM's B is W itself, W stored [K][N]
+// (forward, B[k][n] = W[k][n]); trans = 1: B = W^T with W stored [N][K] (dZ = dQ W^T), i.e. Bt[n][k] = W[n][k] as stored.
+// Output Bt[t][p][k/8][n][8] (bf16 bits; K % 8 == 0), p = 0 h, 1 m, 2 l: the 8 k of one MFMA operand lane are contiguous and
+// 64 consecutive n of one k-octet form a contiguous 1-KiB DMA piece.  grid (ceil(K/32), ceil(N/32), sets), block 256.
+__global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, uint16_t* Bt) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z, k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const float* W = params + (int64_t)t * pstride + w_off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    // tile[kk][nn] = B[k0+kk][n0+nn]
+    for (int r = ty; r < 32; r += 8) {
+        float v = 0.f;
+        if (!trans) { const int k = k0 + r, n = n0 + tx; if (k < K && n < N) v = W[(int64_t)k * N + n]; tile[r][tx] = v; }
+        else { const int n = n0 + r, k = k0 + tx; if (k < K && n < N) v = W[(int64_t)n * K + k]; tile[tx][r] = v; }
+    }
+    __syncthreads();
+    uint16_t* O = Bt + (int64_t)t * 3 * N * K;
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n >= N || k >= K) continue;
+        const float x = tile[tx][r];
+        const uint32_t b = __float_as_uint(x), bh = b & 0xffff0000u;
+        const float r1 = x - __uint_as_float(bh);
+        const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(bm);
+        const int64_t plane = (int64_t)N * K, at = ((int64_t)(k >> 3) * N + n) * 8 + (k & 7);      // [k/8][n][8]
+        O[0 * plane + at] = (uint16_t)(bh >> 16);
+        O[1 * plane + at] = (uint16_t)(bm >> 16);
+        O[2 * plane + at] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+}
+
+// C[rows of tile] = epi( A[rows, K] @ B_set ), block tile 128 x (64*WC), 2*WC waves, each wave a 64x64 sub-tile
+// (2x2 MFMA 32x32 blocks; per 16-wide k chunk 6 bf16 MFMAs per block, issued product-major so that consecutive MFMAs hit
+// different accumulators).  LDS holds two stages of
+//   A planes [3][2][128 rows][8 k] bf16  +  B planes [3][2][BN n][8 k] bf16,
+// i.e. an MFMA fragment (lane (row|col = l&31, k octet = l>>5) reads 16 B) is two contiguous 512-B runs and the 16 lanes
+// ds_read_b128 services per LDS cycle cover all 64 banks (a [row][16 k] image is 2-way bank conflicted: 41 % of the LDS
+// cycles in the first version).
+// The two wave rows split the feeding work, and the two waves that share a SIMD are one of each kind (wave w and w + WC):
+//   wave row 0: DMA of the B planes (L2 -> LDS, one chunk ahead; 6 one-KiB pieces per wave and chunk).  Measured: issuing
+//               those pieces costs the issuing wave ~100 cycles each, during which its SIMD partner runs MFMAs.
+//   wave row 1: the A rows, HBM -> registers GS_D chunks ahead -> exact 3-way split -> LDS.  Its vmcnt queue holds nothing
+//               but these loads, so the in-order completion rule does not cut the prefetch depth short (with the DMA in
+//               the same queue, waiting for a one-chunk-old DMA would also wait for every older A load).
+// Requires K % (16*GS_D) == 0, N % (64*WC) == 0, lda % 4 == 0, 16-byte aligned A / C / bias.
+#ifndef GS_OCC
+#define GS_OCC
+#endif
+#ifndef GS_D
+#define GS_D 4
+#endif
+template <int WC, int BK>
+__global__ __launch_bounds__(128 * WC) GS_OCC void k_gemm_split(SplitGemmK g) {
+    static_assert(BK == 16, "one MFMA k step per chunk");
+    constexpr int NW = 2 * WC, BN = 64 * WC, KS = 1;
+    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16;                              // bytes of one [rows][8 k] bf16 octet slab
+    constexpr int A_SLAB = 2 * A_OCT, B_SLAB = 2 * B_OCT;                           // one MFMA k step (16 k)
+    constexpr int A_PLANE = KS * A_SLAB, B_PLANE = KS * B_SLAB;
+    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;
+    constexpr int EP_LD = 68, EPI_BYTES = NW * 32 * EP_LD * 4;
+    constexpr int MAIN_BYTES = 2 * STAGE > EPI_BYTES ? 2 * STAGE : EPI_BYTES;
+    constexpr int A_PER = (GS_BM * BK / 4) / (64 * WC);                            // float4 of the A tile per thread of wave row 1
+    constexpr int B_PPW = (3 * 2 * (BN / 64)) / WC;                                // 1-KiB DMA pieces (64 n x 8 k) per wave of wave row 0: 6
+    __shared__ __attribute__((aligned(16))) char smem[MAIN_BYTES + GS_BM * 4];
+    const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
+    const int q = nb / 8, r = nb % 8, xcd = b % 8, idx = b / 8;                   // XCD-contiguous logical ids
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb / g.n_col_tiles, ct = lb % g.n_col_tiles;
+    const int set = g.tiles[tile * 3], row0 = g.tiles[tile * 3 + 1], nrows = g.tiles[tile * 3 + 2];
+    const int n0 = ct * BN;
+    const uint16_t* Bt = g.Bt + (int64_t)set * g.bt_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int li = lane & 31, kh = lane >> 5;
+    float my_scale = 1.f;
+    if (tid < GS_BM && g.row_scale) my_scale = g.row_scale[row0 + min(tid, nrows - 1)];
+    float* scales = reinterpret_cast<float*>(smem + MAIN_BYTES);
+    // ---- A (wave row 1): this thread's float4 slots of the [128][16] tile (row = id/4, k = (id%4)*4); rows past the
+    // tile end are clamped (their products are never stored)
+    const float* asrc[A_PER]; int adst[A_PER];
+#pragma unroll
+    for (int p = 0; p < A_PER; ++p) {
+        const int id = (tid & (64 * WC - 1)) + p * (64 * WC), rr = id >> 2, c4 = (id & 3) * 4;
+        asrc[p] = g.A + (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + c4;
+        adst[p] = (c4 >> 3) * A_OCT + rr * 16 + (c4 & 7) * 2;
+    }
+    // ---- B (wave row 0): piece id = (plane * 2 + octet) * (BN/64) + colblock; wave wc takes pieces wc*B_PPW .. +B_PPW-1.
+    // Address = scalar base (set, chunk) + a per-lane 32-bit byte offset: one VGPR per piece, the base advances on the SALU.
+    unsigned boff[B_PPW]; int bdst[B_PPW];
+#pragma unroll
+    for (int p = 0; p < B_PPW; ++p) {
+        const int piece = wc * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % 2, plane = po / 2;
+        boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + n0 + cb * 64 + lane) * 8) * 2);
+        bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;                           // one 16-k chunk of a plane
+    auto issue_b = [&](int chunk, int buf) {
+#ifdef GS_EXP_NOB
+        return;
+#endif
+        const uint64_t base = (uint64_t)(uintptr_t)Bt + (uint64_t)(chunk * b_chunk_bytes);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+        const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+#pragma unroll
+        for (int p = 0; p < B_PPW; ++p) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * STAGE + bdst[p]));
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
+        }
+    };
+    float4 ra[GS_D][A_PER];
+    auto load_a = [&](int chunk, int slot) {
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+#ifdef GS_EXP_NOA
+            ra[slot][p] = make_float4(1.f + chunk, 2.f, 3.f, 4.f);
+#else
+            ra[slot][p] = *reinterpret_cast<const float4*>(asrc[p] + chunk * BK);      // (outer-loop base + compile-time offset after unrolling)
+#endif
+        }
+    };
+    auto store_a = [&](int buf, int slot) {
+#ifdef GS_EXP_NOSPLIT
+        if (ra[slot][0].x != 123.456f) return;
+#endif
+        char* As = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            uint2 h, m, l;
+            gs_split4(ra[slot][p], h, m, l);
+            *reinterpret_cast<uint2*>(As + adst[p]) = h;
+            *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+            *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+        }
+    };
+    gm_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nchunks = g.K / BK;                      // a multiple of GS_D
+    if (wr == 0) issue_b(0, 0);
+    else {
+#pragma unroll
+        for (int d = 0; d < GS_D; ++d) load_a(d, d);
+        store_a(0, 0);
+    }
+    if (tid < GS_BM) scales[tid] = my_scale;
+    if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int c0 = 0; c0 < nchunks; c0 += GS_D) {
+#pragma unroll
+        for (int u = 0; u < GS_D; ++u) {
+            const int c = c0 + u, buf = u & 1;                                     // GS_D is even: stage parity == u parity
+            if (wr == 0) { if (c + 1 < nchunks) issue_b(c + 1, buf ^ 1); }         // the other stage was last read before the previous barrier
+            else if (c + GS_D < nchunks) load_a(c + GS_D, u);                      // slot u held chunk c: split into LDS one iteration ago
+            const char* As = smem + buf * STAGE;
+            const char* Bs = As + 3 * A_PLANE;
+#ifndef GS_EXP_NOMFMA
+            gm_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = *reinterpret_cast<const gm_bf16x8*>(As + p * A_PLANE + kh * A_OCT + (wr * 64 + i * 32 + li) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(Bs + p * B_PLANE + kh * B_OCT + (wc * 64 + j * 32 + li) * 16);
+            // product-major: the four accumulators take turns (a dependent MFMA waits for its predecessor's result)
+#define GS_PROD(PA, PB)                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                   \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+            GS_PROD(2, 0) GS_PROD(0, 2) GS_PROD(1, 1) GS_PROD(1, 0) GS_PROD(0, 1) GS_PROD(0, 0)      // smallest terms first
+#undef GS_PROD
+#else
+            if (c == 1000) acc[0][0][0] = *reinterpret_cast<const float*>(As + lane * 4) + *reinterpret_cast<const float*>(Bs + lane * 4);
+#endif
+            if (wr == 0) {
+#ifndef GS_EXP_BNOWAIT
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            } else if (c + 1 < nchunks) store_a(buf ^ 1, (u + 1) % GS_D);
+            __syncthreads();
+        }
+    }
+    // ---- epilogue: each wave's 32x64 halves through LDS (the stages are free now), row-contiguous 16-B stores.
+    // (Swapped operands + direct row-per-lane 16-B stores were tried: 32-byte runs per row cost +0.4 ms on the 1.1 M-row launch.)
+    const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+    float* E = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+    const int er = lane >> 4, ec = (lane & 15) * 4;
+    const int col = n0 + wc * 64 + ec;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (biasp) b4 = *reinterpret_cast<const float4*>(biasp + col);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (i) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = wr * 64 + i * 32 + it * 4 + er;
+            if (rl >= nrows) continue;
+            const int64_t row = row0 + rl;
+            const float sc = scales[rl];
+            float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+            v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+            if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }   // NaN propagates like torch relu
+            if (g.mask_b) {
+                const unsigned m = g.mask_b[(row * g.ldc + col) >> 2];
+                v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+            } else if (g.mask_h) {
+                const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
+                v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+            }
+            if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+#ifdef GS_EXP_NOSTORE
+            if (v.x != 123.456f) continue;
+#endif
+            if (g.nt_store) {
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+            } else {
+                *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+            }
+        }
+    }
+}

@@ -99,6 +99,11 @@ struct gm_batch {
     int32_t* d_heavy[2] = {nullptr, nullptr};   // rows with more than gm_heavy_deg() edges, by-destination / by-source CSR
     int32_t n_heavy[2] = {0, 0};
     int32_t heavy_deg = 64;
+    // block schedule of the window aggregate (one launch: hub-row blocks are interleaved with the window blocks of their
+    // own subgraph on the XCD that owns them, see gm_agg_schedule): [8 * sched_len] entries per orientation
+    int32_t* d_sched[2] = {nullptr, nullptr};
+    int32_t sched_len[2] = {0, 0};
+    int32_t sched_win = 0;
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
@@ -178,7 +183,15 @@ struct gm_agg_args {
     const int32_t* heavy;      // optional list of rows with more than GM_HEAVY_DEG edges (processed by a whole workgroup)
     int n_heavy;
     int heavy_deg;
+    const int32_t* sched;      // optional block schedule (gm_agg_schedule): hub rows ride in the window launch
+    int sched_len, sched_win;
 };
+// Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
+int gm_agg_window(int64_t rows);
+// Block schedule for the window aggregate over `rows` rows with the given (ascending, host) hub-row list: 8 per-XCD lists of
+// equal length *len_out; entry >= 0: window block id, <= -2: hub row heavy[-(entry) - 2], -1: nothing.  A hub row's block
+// follows the window block that contains the row, on the XCD whose L2 is streaming that subgraph.
+int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heavy, int32_t** d_sched, int32_t* len_out, hipStream_t s);
 int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG, default 64)
 int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);
 

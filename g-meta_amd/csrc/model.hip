@@ -410,7 +410,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
-            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
@@ -418,7 +418,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = fi; }
                 else { a.x = xin; a.ldx = fi; }
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
@@ -474,7 +474,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -502,7 +502,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                     g.B = c.WT; g.b_stride = pstride ? (int64_t)fi * fo : 0; g.transB = 0;
                 } else { g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; }
                 GM_TRY(gm_launch_gemm_nn(g, st));
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));

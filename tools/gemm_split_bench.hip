@@ -1,0 +1,68 @@
+// Micro-benchmark + accuracy check of the split-bf16 fp32 GEMM (g-meta_amd/csrc/gemm_split.h) against an fp64 reference
+// and the plain fp32 fmaf chain, at the arxiv query-layer shape (rows x 256 x 256).
+//   hipcc --offload-arch=gfx950 -O3 -o tools/_build/gemm_split_bench tools/gemm_split_bench.hip && tools/_build/gemm_split_bench
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../g-meta_amd/csrc/gemm_split.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int WC, int BK> static void run(SplitGemmK g, hipStream_t s) {
+    hipLaunchKernelGGL((k_gemm_split<WC, BK>), dim3(g.n_tiles * g.n_col_tiles), dim3(128 * WC), 0, s, g);
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 1146880, K = argc > 2 ? atoi(argv[2]) : 256, N = argc > 3 ? atoi(argv[3]) : 256;
+    const int WC = argc > 4 ? atoi(argv[4]) : 4, BK = argc > 5 ? atoi(argv[5]) : 32;
+    printf("M=%d K=%d N=%d WC=%d BK=%d\n", M, K, N, WC, BK);
+    std::vector<float> A((size_t)M * K), W((size_t)K * N), bias(N);
+    srand(1);
+    auto rnd = []() { return (float)((rand() / (double)RAND_MAX) * 2.0 - 1.0); };
+    for (auto& v : W) v = rnd() * 0.1f;
+    for (auto& v : bias) v = rnd();
+    for (size_t i = 0; i < A.size(); ++i) A[i] = rnd() * (1.f + (i % 7)) ;
+    std::vector<int32_t> tiles;
+    for (int r = 0; r < M; r += 128) { tiles.push_back(0); tiles.push_back(r); tiles.push_back(std::min(128, M - r)); }
+    float *dA, *dW, *dC, *dBias; uint16_t* dBt; int32_t* dT;
+    CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dC, (size_t)M * N * 4)); CK(hipMalloc(&dBias, N * 4));
+    CK(hipMalloc(&dBt, (size_t)3 * N * K * 2)); CK(hipMalloc(&dT, tiles.size() * 4));
+    CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dBias, bias.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dT, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, 1), dim3(256), 0, 0, dW, 0, 0, K, N, 0, dBt);
+    SplitGemmK g{};
+    g.A = dA; g.lda = K; g.Bt = dBt; g.bt_stride = 0; g.C = dC; g.ldc = N; g.K = K; g.N = N; g.bias = dBias; g.relu = 0;
+    g.tiles = dT; g.n_tiles = (int)tiles.size() / 3; g.n_col_tiles = N / (64 * WC); g.nt_store = 1;
+    auto launch = [&]() {
+        if (BK == 32) { printf("BK=32 removed\n"); exit(1); }
+        else { if (WC == 4) run<4, 16>(g, 0); else if (WC == 2) run<2, 16>(g, 0); else run<1, 16>(g, 0); }
+    };
+    launch();
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int reps = 20;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    const double fl = 2.0 * M * K * N;
+    printf("split-bf16 GEMM: %.3f ms  %.1f TFLOP/s (fp32-equivalent)  %.1f TFLOP/s of bf16 MFMA work  %.2f TB/s of A+C traffic\n", ms, fl / ms / 1e9,
+           6 * fl / ms / 1e9, ((double)M * K * 4 + (double)M * N * 4) / ms / 1e9);
+    std::vector<float> C((size_t)M * N);
+    CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+    // accuracy on a sample of rows: vs fp64, next to the fp32 fmaf chain's own error
+    double e_split = 0, e_f32 = 0, mag = 0;
+    for (int s = 0; s < 256; ++s) {
+        const int row = (int)(((int64_t)s * 7919 * 131) % M);
+        for (int n = 0; n < N; ++n) {
+            double ref = 0; float f = 0.f;
+            for (int k = 0; k < K; ++k) { ref += (double)A[(size_t)row * K + k] * (double)W[(size_t)k * N + n]; f = fmaf(A[(size_t)row * K + k], W[(size_t)k * N + n], f); }
+            ref += bias[n]; f += bias[n];
+            e_split = fmax(e_split, fabs((double)C[(size_t)row * N + n] - ref)); e_f32 = fmax(e_f32, fabs((double)f - ref)); mag = fmax(mag, fabs(ref));
+        }
+    }
+    printf("max |C - fp64| over 256 rows: split-bf16 %.3e   fp32 fmaf chain %.3e   (max |C| %.3f)\n", e_split, e_f32, mag);
+    return e_split < 20 * e_f32 + 1e-6 ? 0 : 2;
+}
