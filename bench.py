@@ -151,6 +151,7 @@ def main():
     ap.add_argument('--serialize', type=int, default=0, help='1: run the timed region on one stream (what the rocprofv3 per-kernel summaries use)')
     ap.add_argument('--extra_steps', type=int, default=3, help='steps per flagged exact schedule reported under "extra" (N=1 only; 0 = skip)')
     ap.add_argument('--e2e_steps', type=int, default=10, help='N=1 only: extra steps with a FRESH extraction per step (prefetched on a second thread), reported under "end_to_end"; 0 = skip')
+    ap.add_argument('--defer', type=int, default=0, help='1: Meta.forward_deferred, accuracies of step k read after step k+1 is queued')
     ap.add_argument('--roofline_steps', type=int, default=2, help='extra serialised steps after the timed region for the per-kernel roofline')
     a = ap.parse_args()
 
@@ -201,8 +202,22 @@ def main():
     rows = sum(x.rows for x in (batches[0][0][0].view_of, batches[0][2][0].view_of))
     edges = sum(x.edges for x in (batches[0][0][0].view_of, batches[0][2][0].view_of))
 
+    pending = []
+
     def step(k):
+        if a.defer:
+            # deferred read-back (Meta.forward_deferred): the accuracies of step k are read while step k+1 is already queued,
+            # like a training loop that only prints them every few steps (train.py:110); all work of every step still runs
+            # inside the timed region (the last handle is drained before the clock stops)
+            pending.append(maml.forward_deferred(*batches[k % a.n_batches][:4]))
+            return pending.pop(0).accs() if len(pending) > 1 else None
         return maml(*batches[k % a.n_batches], data['feats'])
+
+    def drain():
+        out = None
+        while pending:
+            out = pending.pop(0).accs()
+        return out
 
     lib = _lib.lib()
 
@@ -213,6 +228,7 @@ def main():
 
     for k in range(a.warmup):
         step(k)
+    drain()
     lib.gm_profile_enable(1)           # HIP events around every aggregate launch, recorded on the stream it is launched on
     if world > 1:
         dist.barrier()
@@ -223,12 +239,16 @@ def main():
     strict_bytes = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
+        if a.defer:
+            continue                   # per-launch events are read in the serialised roofline steps below
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
         strict_bytes += prof_read(3)[2]
         for cat in (1, 2):
             ms, n, fl = prof_read(cat)
             ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
+    if a.defer:
+        accs = drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -246,10 +266,10 @@ def main():
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         maml.serialize = 1
-        step(0)
+        step(0); drain()
         agg_ms, agg_n, agg_bytes, strict_bytes = 0.0, 0, 0, 0
         for k in range(a.roofline_steps):
-            step(k)
+            step(k); drain()
             ms, n, by = prof_read()
             agg_ms += ms; agg_n += n; agg_bytes += by
             strict_bytes += prof_read(3)[2]
@@ -267,10 +287,11 @@ def main():
                          ('cone', dict(sparse_bwd=0, hoist_z1=0, cone=1)), ('cone+hoist_z1', dict(cone=1, hoist_z1=1))):
             for k_, v_ in kw.items():
                 setattr(maml, k_, v_)
-            step(0)
+            step(0); drain()
             torch.cuda.synchronize(); te = time.perf_counter()
             for k in range(a.extra_steps):
                 step(k)
+            drain()
             torch.cuda.synchronize()
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
@@ -311,6 +332,9 @@ def main():
         e2e = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1), 'steps': a.e2e_steps,
                'what': 'Subgraphs.get_batch (h-hop extraction + sampling + induced batch on the GPU, prefetched one step ahead on a second '
                        'thread/stream) + Meta.forward per step; same schedule as `value`'}
+    if use_dist:                           # tear the communicator down before printing: nothing follows the JSON line
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         ach = agg_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
         strict = strict_bytes / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
@@ -341,6 +365,7 @@ def main():
                                     'sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
                                     'full (reference-equivalent: every forward/backward dense over all subgraph rows)'),
                        'streams': 1 if a.serialize else 2,
+                       'readback': 'deferred by one step (Meta.forward_deferred)' if a.defer else 'every step (Meta.forward returns the accuracies)',
                        'parallelism': 'tasks sharded over %d rank(s) (rank 0: %d of %d), one all-reduce of the meta-gradient per step' % (world, hi - lo, T),
                        'rows_per_rank': int(rows), 'edges_per_rank': int(edges),
                        'extract_ms_per_meta_batch_rank0': round(float(np.min(ext_ms)), 2), 'last_accs': [round(float(x), 4) for x in accs]},
@@ -385,10 +410,11 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(db, data, cfg, config, batches[0])
             except Exception as e:   # the baseline is a reported number, never the product path
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        try:                               # RCCL / HIP runtime banners sit in the C stdio buffer: flush them first so that the JSON is the LAST line
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -671,7 +671,7 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
 }
 
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
-struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; };
+struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; };
 
 __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
                                float* db, int64_t db_stride, WgradSgd u) {
@@ -690,7 +690,11 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
         const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         if (j < KN) {
             dW[(int64_t)set * dw_stride + j] = s;
-            if (u.next) u.next[(int64_t)set * u.next_stride + u.w_off + j] = u.cur[(int64_t)set * u.cur_stride + u.w_off + j] - u.lr * s;
+            if (u.next) {
+                const float wn = u.cur[(int64_t)set * u.cur_stride + u.w_off + j] - u.lr * s;
+                u.next[(int64_t)set * u.next_stride + u.w_off + j] = wn;
+                if (u.wt) { const int k = j / N, n = j - k * N; u.wt[(int64_t)set * KN + (int64_t)n * (KN / N) + k] = wn; }
+            }
         } else if (db) {
             db[(int64_t)set * db_stride + (j - KN)] = s;
             if (u.next) u.next[(int64_t)set * u.next_stride + u.b_off + (j - KN)] = u.cur[(int64_t)set * u.cur_stride + u.b_off + (j - KN)] - u.lr * s;
@@ -706,7 +710,7 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     return rc;
 }
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
-    const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off};
+    const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off, a.sgd_next ? a.wt_next : nullptr};
     if (a.n_chunks <= 0) {      // no rows at all: the gradients are zero
         const int tot0 = (a.K + 1) * a.N;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot0 + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off, a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);

@@ -235,6 +235,8 @@ struct gm_wgrad_args {
     // optional fused inner-loop SGD (meta.py:126,151): next_t[off + j] = cur_t[off + j] - lr * grad, written together with the gradient
     const float* sgd_cur; int64_t sgd_cur_stride; float* sgd_next; int64_t sgd_next_stride; float sgd_lr;
     int64_t w_off, b_off;               // offsets of this layer's W and b inside a parameter vector
+    float* wt_next;                     // optional (with sgd_next): the updated W also written transposed, [set][N][K] -- what the NEXT
+                                        // step's dZ GEMM (dQ @ W^T on the row-major DMA kernel) reads, instead of a transpose launch
     int64_t rows;                       // total rows covered by the chunks (profiling: flops = 2*rows*K*N)
 };
 #define GM_WGRAD_ROWS 1024

@@ -318,7 +318,8 @@ struct Carver {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
-    float* WT;                   // per-task transposed weights of the layer whose dZ GEMM is running (dense backward)
+    float* WTl[GM_MAX_GCN];      // per-task transposed weights of layer l >= 1, [set][fo][fi]: B of the dZ GEMM (dense backward)
+    const float* wt_of[GM_MAX_GCN]; int64_t wt_stride[GM_MAX_GCN];      // the parameter vector (pointer, per-set stride) WTl[l] is the transpose of
     uint8_t* M[GM_MAX_GCN];      // packed relu' bits of H[l] (one byte per 4 columns): what the backward reads instead of H[l] (dense schedule)
     float* cG2; float* cT2; float* cG1; float* partial_c;      // compact matrices of the row-sparse backward
     const float* x0_user; const int32_t* centre; int z1_valid;
@@ -367,7 +368,7 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
     c.bufA = cv.take<float>(rows * maxd);
     c.bufB = cv.take<float>(rows * maxd);
     c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
-    c.WT = cv.take<float>((int64_t)c.b->sets * maxkn);
+    for (int l = 1; l < L.n_gcn; ++l) c.WTl[l] = cv.take<float>((int64_t)c.b->sets * L.dims[l] * L.dims[l + 1]);
     c.cG2 = cv.take<float>((int64_t)c.b->n_c * maxd); c.cT2 = cv.take<float>((int64_t)c.b->n_c * maxd);
     c.cG1 = cv.take<float>((int64_t)c.b->n_e1 * maxd);
     c.partial_c = cv.take<float>((int64_t)std::max(c.b->n_c_chunks, c.b->n_e1_chunks) * maxkn);
@@ -487,21 +488,32 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             }
         } else {
             // dW = (norm*Z)^T dQ ; db = colsum(dQ) ; dZ = norm * (dQ W^T) ; dQ_prev = relu'(H_prev) * norm * A^T dZ
+            // Order: dZ GEMM (reads dQ and the CURRENT weights) -> weight gradient (reads dQ; its reduction writes the updated
+            // weights and, for the next step's dZ GEMM, their transpose) -> transposed aggregate (overwrites dQ).
             w.A = c.Z[l]; w.lda = fi; w.G = dQ; w.ldg = fo;
-            GM_TRY(gm_launch_wgrad(w, st));
             if (l > 0) {
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 static int dz_glds = -1;
                 if (dz_glds < 0) { const char* e = getenv("GM_DZ_GLDS"); dz_glds = e ? atoi(e) : 1; }
-                if (dz_glds && c.WT && fi % 64 == 0 && fo % 16 == 0) {
-                    // dZ = dQ @ W^T through the direct-to-LDS kernel: transpose the (T x 256 KB) weights once, then a plain product
-                    const int nt = pstride ? b->sets : 1;             // shared theta (step 0): one transpose serves every task
-                    hipLaunchKernelGGL(k_transpose_w, dim3((fo + 31) / 32, (fi + 31) / 32, nt), dim3(256), 0, st, params, pstride, L.w_off[l], fi, fo, c.WT);
-                    GM_HIP(hipGetLastError());
-                    g.B = c.WT; g.b_stride = pstride ? (int64_t)fi * fo : 0; g.transB = 0;
+                const bool use_wt = dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
+                if (use_wt) {
+                    // dZ = dQ @ W^T through the direct-to-LDS kernel on transposed weights: left there by the previous step's
+                    // weight-gradient reduction (which wrote these very weights), else transposed now (T x 256 KB)
+                    if (!(c.wt_of[l] == params && c.wt_stride[l] == pstride)) {
+                        const int nt = pstride ? b->sets : 1;         // shared theta (step 0): one transpose serves every task
+                        hipLaunchKernelGGL(k_transpose_w, dim3((fo + 31) / 32, (fi + 31) / 32, nt), dim3(256), 0, st, params, pstride, L.w_off[l], fi, fo, c.WTl[l]);
+                        GM_HIP(hipGetLastError());
+                        c.wt_of[l] = params; c.wt_stride[l] = pstride;
+                    }
+                    g.B = c.WTl[l]; g.b_stride = pstride ? (int64_t)fi * fo : 0; g.transB = 0;
                 } else { g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1; }
                 GM_TRY(gm_launch_gemm_nn(g, st));
+                if (use_wt && c.sgd.next) { w.wt_next = c.WTl[l]; }
+            }
+            GM_TRY(gm_launch_wgrad(w, st));
+            if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
+            if (l > 0) {
                 gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
