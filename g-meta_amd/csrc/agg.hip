@@ -430,7 +430,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.indices = transposed ? b->d_indices_t : b->d_indices;
     a.x = gather ? b->store->d_feat : x;
     a.x_row = gather ? b->d_feat_row : nullptr;
-    a.ldx = width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
+    a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
     a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win;
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));

@@ -338,11 +338,11 @@ __global__ void k_centre_edges(const int32_t* crow, const int32_t* eoff, int n_c
 __global__ void k_copy_add(int32_t* dst, const int32_t* src, int64_t n, int32_t add) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) dst[k] = src[k] + add;
 }
-__global__ void k_gather_rows(const float* feat, const int32_t* feat_row, float* out, int64_t rows, int F) {
+__global__ void k_gather_rows(const float* feat, int64_t ld, const int32_t* feat_row, float* out, int64_t rows, int F) {
     const int64_t total = rows * F;
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < total; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = k / F; const int f = (int)(k - r * F);
-        out[k] = feat[(int64_t)feat_row[r] * F + f];
+        out[k] = feat[(int64_t)feat_row[r] * ld + f];
     }
 }
 
@@ -717,11 +717,10 @@ extern "C" int gm_batch_device_ptr(const gm_batch_t* b, int32_t field, void** dp
     return field_ptr(b, field, dptr, &bytes);
 }
 
-int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, float* out, hipStream_t st) {
-    if (n <= 0) return GM_OK;
-    const int F = store->feat_dim;
+int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, int F, float* out, hipStream_t st) {
+    if (n <= 0) return GM_OK;          // F: columns copied (feat_dim, or feat_ld for the padded internal model)
     const int blocks = (int)std::min<int64_t>(256 * 8, (n * F + 255) / 256);
-    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, store->d_feat, feat_row, out, n, F);
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, st, store->d_feat, (int64_t)store->feat_ld, feat_row, out, n, F);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
@@ -731,7 +730,7 @@ extern "C" int gm_gather_features(const gm_batch_t* b, float* x_out, void* strea
     const int F = b->store->feat_dim;
     const int64_t total = b->rows * F;
     const int blocks = (int)std::min<int64_t>(256 * 8, (total + 255) / 256);
-    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->store->d_feat, b->d_feat_row, x_out, b->rows, F);
+    hipLaunchKernelGGL(k_gather_rows, dim3(blocks), dim3(256), 0, (hipStream_t)stream, b->store->d_feat, (int64_t)b->store->feat_ld, b->d_feat_row, x_out, b->rows, F);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

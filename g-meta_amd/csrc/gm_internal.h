@@ -37,6 +37,8 @@ void gm_set_error(const char* fmt, ...);
 
 struct gm_store {
     int32_t n_graphs = 0, feat_dim = 0;
+    int32_t feat_ld = 0;             // row stride of d_feat: feat_dim padded with zero columns (32, else a multiple of 64) so that layer 1 runs on the
+                                     // vectorised aggregate / DMA GEMM / fast weight-gradient kernels whatever the dataset's feature width
     int64_t total_nodes = 0, total_edges = 0, max_nodes = 0;
     std::vector<int64_t> node_off, edge_off;      // host prefix sums per graph
     // device
@@ -45,7 +47,7 @@ struct gm_store {
     int32_t* d_in_idx = nullptr;     // [total_edges]     source node, LOCAL to its graph
     int64_t* d_out_ptr = nullptr;    // by-source CSR of the same edges (for the transposed induce)
     int32_t* d_out_idx = nullptr;    // destination node, LOCAL to its graph
-    float* d_feat = nullptr;         // [total_nodes, feat_dim]
+    float* d_feat = nullptr;         // [total_nodes, feat_ld]
 };
 
 // Receptive-field tables (cone.hip): level l = rows whose layer-l activation reaches a centre.
@@ -158,6 +160,7 @@ struct gm_layout {
     int64_t w_off[GM_MAX_GCN], b_off[GM_MAX_GCN], wl_off, bl_off, P;
 };
 int gm_make_layout(const gm_model_t* m, gm_layout* L);
+static inline int gm_pad_feat(int F) { return F <= 32 ? 32 : (F + 63) / 64 * 64; }
 
 // ---- kernels launched across translation units
 // Generic CSR aggregate: out[r,:] = epi( s_out[r] * sum_{c in row r} s_in[c] * x[src(c),:] ).

@@ -289,11 +289,14 @@ __global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t*
 }
 
 // out = [ sum_t (gq+gp) | sum_t lq[t,:] | sum_t aq[t,:] | T | aq[t,:] ... ]
-__global__ void k_finalize(const float* gq, const float* gp, int64_t stride, int64_t P, int T, const float* lq, const float* aq, int K1, float* out) {
+// (cut, shift): the kernels' parameter layout has `shift` extra floats after position `cut` (zero-padded W_1 rows when the store pads
+// its feature columns); `out` uses the caller's layout.
+__global__ void k_finalize(const float* gq, const float* gp, int64_t stride, int64_t P, int T, const float* lq, const float* aq, int K1, float* out,
+                           int64_t cut, int64_t shift) {
     const int64_t tot = P + 2 * K1 + 1 + (int64_t)T * K1;
     for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
-        if (id < P) { if (gq) for (int t = 0; t < T; ++t) s += gq[t * stride + id] + gp[t * stride + id]; }
+        if (id < P) { const int64_t src = id < cut ? id : id + shift; if (gq) for (int t = 0; t < T; ++t) s += gq[t * stride + src] + gp[t * stride + src]; }
         else if (id < P + K1) { for (int t = 0; t < T; ++t) s += lq[t * K1 + (id - P)]; }
         else if (id < P + 2 * K1) { for (int t = 0; t < T; ++t) s += aq[t * K1 + (id - P - K1)]; }
         else if (id == P + 2 * K1) s = (float)T;
@@ -392,6 +395,7 @@ static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
     return k;
 }
 
+int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, int F, float* out, hipStream_t st);
 static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head);
 static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head);
 
@@ -399,7 +403,7 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
 static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head = 0) {
     if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1, skip_head);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
-    GM_REQUIRE(L.dims[0] == b->store->feat_dim || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
+    GM_REQUIRE(L.dims[0] == b->store->feat_dim || L.dims[0] == b->store->feat_ld || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
     const float* xin = c.x0_user;           // NULL = gather rows of the store through feat_row
     for (int l = 0; l < L.n_gcn; ++l) {
@@ -407,7 +411,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
         const bool gather = (l == 0 && !c.x0_user);
         if (fi > fo) {                      // learner.py:34-40: multiply first, then aggregate
             const float* A = xin; int64_t lda = fi;
-            if (gather) { GM_TRY(gm_gather_features(b, c.X0, st)); A = c.X0; }
+            if (gather) { GM_TRY(gm_gather_rows(b->store, b->d_feat_row, b->rows, fi, c.X0, st)); A = c.X0; }
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
@@ -420,7 +424,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
         } else {                            // learner.py:41-47: aggregate first, then multiply
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
-                if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = fi; }
+                if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
                 {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
@@ -573,7 +577,6 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
 // ================================================================================ receptive-field ("cone") schedule
 // The same layer formulas as gcn_forward/gcn_backward, evaluated only on the rows that can reach a centre
 // (cone.hip): layer l maps level l (sources) to level l+1 (destinations); all matrices are compact.
-int gm_gather_rows(const gm_store* store, const int32_t* feat_row, int64_t n, float* out, hipStream_t st);
 
 static gm_agg_args cone_agg(const gm_cone* cn, const gm_cone_level& up, int transposed) {
     gm_agg_args a{};
@@ -584,7 +587,7 @@ static gm_agg_args cone_agg(const gm_cone* cn, const gm_cone_level& up, int tran
 
 static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head) {
     const gm_layout& L = c.L; const gm_batch* b = c.b; const gm_cone* cn = c.cone;
-    GM_REQUIRE(L.dims[0] == b->store->feat_dim, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
+    GM_REQUIRE(L.dims[0] == b->store->feat_dim || L.dims[0] == b->store->feat_ld, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
     GM_REQUIRE(!c.x0_user && !c.centre, GM_EINVAL, "forward: the cone schedule reads features and centres from the batch");
     const float* xin = nullptr;
@@ -593,7 +596,7 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
         const int fi = L.dims[l], fo = L.dims[l + 1];
         if (fi > fo) {                      // multiply on the source level, then aggregate into the destination level
             const float* A = xin;
-            if (l == 0) { GM_TRY(gm_gather_rows(b->store, lo.d_feat_row, lo.n, c.X0, st)); A = c.X0; }
+            if (l == 0) { GM_TRY(gm_gather_rows(b->store, lo.d_feat_row, lo.n, fi, c.X0, st)); A = c.X0; }
             gm_gemm_args g{}; g.A = A; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = lo.d_norm; g.tiles = lo.d_tiles; g.n_tiles = lo.n_tiles; g.rows = lo.n;
             GM_TRY(gm_launch_gemm_nn(g, st));
@@ -605,7 +608,7 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a = cone_agg(cn, up, 0);
                 a.s_in = lo.d_norm; a.out = c.Z[l]; a.rows = up.n; a.width = fi; a.ldx = fi;
-                if (l == 0) { a.x = b->store->d_feat; a.x_row = lo.d_feat_row; } else a.x = xin;
+                if (l == 0) { a.x = b->store->d_feat; a.x_row = lo.d_feat_row; a.ldx = b->store->feat_ld; } else a.x = xin;
                 GM_TRY(gm_launch_aggregate(a, st));
                 if (l == 0) c.z1_valid = 1;
             }
@@ -828,6 +831,24 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
 }
 
 // ================================================================================ the fused meta-step
+// theta in the caller's layout -> the kernels' layout: `shift` zeros inserted at `cut` (the zero weight rows of the padded feature columns)
+__global__ void k_pad_params(const float* theta, int64_t P, int64_t cut, int64_t shift, float* out) {
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < P + shift; id += (int64_t)gridDim.x * blockDim.x)
+        out[id] = id < cut ? theta[id] : (id < cut + shift ? 0.f : theta[id - shift]);
+}
+
+// The model the kernels run: layer 1 reads the store's padded feature rows (gm_store::feat_ld columns, the extra ones zero), so W_1
+// gets matching zero rows -- same sums, but the layer takes the vectorised aggregate / DMA GEMM / fast weight-gradient kernels
+// whatever the dataset's feature width (50 and 5 in the reference's Tissue-PPI / FirstMM-DB configs).
+static gm_model_t internal_model(const gm_model_t* m, const gm_store* store, int64_t* cut, int64_t* shift) {
+    gm_model_t mp = *m; *cut = 0; *shift = 0;
+    if (store->feat_ld != store->feat_dim && m->dims[0] == store->feat_dim) {
+        mp.dims[0] = store->feat_ld;
+        *cut = (int64_t)store->feat_dim * m->dims[1]; *shift = (int64_t)(store->feat_ld - store->feat_dim) * m->dims[1];
+    }
+    return mp;
+}
+
 struct MetaStreams {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ev;
@@ -891,7 +912,7 @@ static StageRing& stage_ring() {
 struct MetaPlan {
     gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
     GcnCtx S, Q;
-    float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq;
+    float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq, *theta_p;
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
     int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q]
     int Ct, ns, nq;
@@ -911,6 +932,7 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     Carver cv(ws, ws_bytes);
     const int64_t TP = (int64_t)p.T * p.Pp; const int C = p.L.n_out; const int K1 = p.K + 1;
     p.TP = TP; p.proto_sz = (int64_t)p.T * 256 * C;
+    p.theta_p = cv.take<float>(p.Pp);
     p.fw = cv.take<float>(TP * p.K); p.g = cv.take<float>(TP); p.gq = cv.take<float>(TP); p.gp = cv.take<float>(TP);
     p.logit_s = cv.take<float>((int64_t)spt->subs * C); p.logit_q = cv.take<float>((int64_t)qry->subs * C);
     p.dlog_s = cv.take<float>((int64_t)spt->subs * C); p.dlog_q = cv.take<float>((int64_t)qry->subs * C);
@@ -931,8 +953,9 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
 
 extern "C" int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry, const gm_model_t* m, const gm_hparams_t* hp) {
     if (!spt || !qry || !m || !hp) return -1;
-    MetaPlan p; int64_t need = 0;
-    if (meta_plan(p, spt, qry, m, hp, nullptr, 0, 1, 1, 1, &need) != GM_OK) return -1;
+    MetaPlan p; int64_t need = 0, cut, shift;
+    const gm_model_t mp = internal_model(m, spt->store, &cut, &shift);
+    if (meta_plan(p, spt, qry, &mp, hp, nullptr, 0, 1, 1, 1, &need) != GM_OK) return -1;
     return need;
 }
 
@@ -961,8 +984,17 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         GM_REQUIRE(cs.tab[t * 3 + 1] == cq.tab[t * 3 + 1], GM_EINVAL, "meta_step: task %d has %d support classes but %d query classes", t, cs.tab[t * 3 + 1], cq.tab[t * 3 + 1]);
     const int Ct = cs.Ct, ns = cs.n, nq = cq.n;
     MetaPlan p;
-    GM_TRY(meta_plan(p, spt, qry, m, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
+    int64_t cut = 0, shift = 0;
+    const gm_model_t mp = internal_model(m, spt->store, &cut, &shift);
+    gm_layout Lu;                                          // the caller's parameter layout (theta, out)
+    GM_TRY(gm_make_layout(m, &Lu));
+    GM_TRY(meta_plan(p, spt, qry, &mp, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
     const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
+    if (shift) {
+        hipLaunchKernelGGL(k_pad_params, dim3((int)std::min<int64_t>(512, (L.P + 255) / 256)), dim3(256), 0, st, theta, Lu.P, cut, shift, p.theta_p);
+        GM_HIP(hipGetLastError());
+        theta = p.theta_p;
+    }
     {   // class tables -> pinned staging -> ONE asynchronous copy (no host synchronisation in the meta-step)
         const size_t n_tab = (size_t)spt->subs + qry->subs + 6 * (size_t)T;
         void* h = nullptr; int slot = 0;
@@ -1048,9 +1080,9 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         }
     }
     wait(st, signal(sq));                                  // join
-    const int64_t tot = L.P + 2 * K1 + 1 + (int64_t)T * K1;
+    const int64_t tot = Lu.P + 2 * K1 + 1 + (int64_t)T * K1;
     hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
-                       have_grad ? p.gq : nullptr, p.gp, Pp, L.P, T, p.lq, p.aq, K1, out);
+                       have_grad ? p.gq : nullptr, p.gp, Pp, Lu.P, T, p.lq, p.aq, K1, out, cut, shift);
     GM_HIP(hipGetLastError());
     gm_batch_mark_use(spt, st); gm_batch_mark_use(qry, st);
     return GM_OK;

@@ -64,10 +64,21 @@ extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const i
     UP(s->d_out_ptr, out_ptr, int64_t)
     UP(s->d_out_idx, out_idx, int32_t)
 #undef UP
-    if (rc == GM_OK) rc = gm_dev_alloc((void**)&s->d_feat, (size_t)s->total_nodes * feat_dim * sizeof(float), st);
+    {
+        static int pad_on = -1;
+        if (pad_on < 0) { const char* e = getenv("GM_FEAT_PAD"); pad_on = e ? atoi(e) : 1; }
+        // 1 (default): pad only widths the vector kernels cannot take as they are (not a multiple of 4: 50, 5, ...); 2: always; 0: never.
+        // Aligned widths keep their native stride: padding is exact (zeros) but changes which kernels run, i.e. the fp summation order.
+        s->feat_ld = (pad_on == 2 || (pad_on == 1 && feat_dim % 4 != 0)) ? gm_pad_feat(feat_dim) : feat_dim;
+    }
+    const size_t feat_bytes = (size_t)s->total_nodes * s->feat_ld * sizeof(float);
+    if (rc == GM_OK) rc = gm_dev_alloc((void**)&s->d_feat, feat_bytes, st);
+    if (rc == GM_OK && s->feat_ld != feat_dim && hipMemset(s->d_feat, 0, feat_bytes) != hipSuccess) { gm_set_error("gm_store_create: feature memset failed"); rc = GM_EHIP; }
     for (int g = 0; g < n_graphs && rc == GM_OK; ++g) {
-        if (hipMemcpy(s->d_feat + s->node_off[g] * feat_dim, feat[g], (size_t)n_nodes[g] * feat_dim * sizeof(float),
-                      hipMemcpyHostToDevice) != hipSuccess) { gm_set_error("gm_store_create: feature upload failed"); rc = GM_EHIP; }
+        if (hipMemcpy2D(s->d_feat + s->node_off[g] * s->feat_ld, (size_t)s->feat_ld * sizeof(float), feat[g], (size_t)feat_dim * sizeof(float),
+                        (size_t)feat_dim * sizeof(float), (size_t)n_nodes[g], hipMemcpyHostToDevice) != hipSuccess) {
+            gm_set_error("gm_store_create: feature upload failed"); rc = GM_EHIP;
+        }
     }
     if (rc != GM_OK) { gm_store_destroy(s); return rc; }
     *out = s;
