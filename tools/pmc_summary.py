@@ -34,6 +34,7 @@ def collect(paths):
 def main(argv):
     if argv and argv[0] == '--agg-traffic':
         acc, cnt = collect(argv[1:3])
+        taken = argv[3] if len(argv) > 3 else 'unlabelled'
         tot = collections.defaultdict(float); launches = 0
         for k in acc:
             if 'k_agg' in k:
@@ -43,8 +44,8 @@ def main(argv):
                     launches += len(cnt[k].get('FETCH_SIZE', ()))
         fetch_raw = tot['FETCH_SIZE'] * 1024 / launches; write = tot['WRITE_SIZE'] * 1024 / launches
         json.dump({'hbm_bytes_per_launch': int(2 * fetch_raw + write), 'fetch_raw_bytes_per_launch': int(fetch_raw), 'write_bytes_per_launch': int(write),
-                   'launches': launches,
-                   'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the aggregate kernels (k_agg_win + k_agg_heavy) of '
+                   'launches': launches, 'taken': taken,
+                   'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the aggregate kernels (k_agg_win, hub rows included since round 2) of '
                            'bench.py --serialize 1 --steps 1 --warmup 1; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests '
                            'at 64 B; Infinity-Cache hits are included, so this is fabric-side traffic, an upper bound on HBM bytes); KB -> bytes x1024'},
                   sys.stdout, indent=1)

@@ -16,7 +16,7 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE -d $out/p_f -o x -- $B --serialize 1 --st
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $out/p_w -o x -- $B --serialize 1 --steps 1 --roofline_steps 0 > /dev/null 2>&1
 python tools/pmc_summary.py "$(db $out/p_f)" > $out/${tag}_pmc_fetch_size.txt
 python tools/pmc_summary.py "$(db $out/p_w)" > $out/${tag}_pmc_write_size.txt
-python tools/pmc_summary.py --agg-traffic "$(db $out/p_f)" "$(db $out/p_w)" > $out/${tag}_agg_traffic.json
+python tools/pmc_summary.py --agg-traffic "$(db $out/p_f)" "$(db $out/p_w)" "${tag} $(date +%Y-%m-%d)" > $out/${tag}_agg_traffic.json
 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE \
     -d $out/p_sq -o x -- $B --serialize 1 --steps 1 --roofline_steps 0 > /dev/null 2>&1
 python tools/pmc_summary.py "$(db $out/p_sq)" > $out/${tag}_pmc_sq.txt
