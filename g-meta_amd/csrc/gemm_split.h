@@ -20,6 +20,9 @@ typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
 
 #define GS_BM 128
+// hipcc's __syncthreads() is fence + barrier: it drains vmcnt(0), i.e. every prefetch in flight.  The main loops use the raw
+// barrier behind an explicit LDS wait (and counted vmcnt where a DMA must have landed).
+#define GS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
 struct SplitGemmK {
     const float* A; int64_t lda;
@@ -28,6 +31,7 @@ struct SplitGemmK {
     const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
     const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* tiles; int n_tiles; int n_col_tiles; int nt_store;
+    unsigned long long* dbg;                   // experiment: per-iteration timestamps of one workgroup (FC_TRACE)
 };
 
 // x (4 floats) -> three packed bf16x4 (8 bytes each): h = trunc16(x), m = trunc16(x - h), l = x - h - m (exact in bf16)
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(128 * WC) GS_OCC void k_gemm_split(SplitGemmK g) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
             } else if (c + 1 < nchunks) store_a(buf ^ 1, (u + 1) % GS_D);
-            __syncthreads();
+            GS_BARRIER();
         }
     }
     // ---- epilogue: each wave's 32x64 halves through LDS (the stages are free now), row-contiguous 16-B stores.
@@ -286,6 +290,264 @@ __global__ __launch_bounds__(128 * WC) GS_OCC void k_gemm_split(SplitGemmK g) {
             } else {
                 *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant (experiment): 12 waves per 128 x 256 tile, one workgroup per CU.
+//   waves 0..7   COMPUTE: 64x64 sub-tiles, LDS fragment reads + MFMAs only; they never touch global memory in the main loop,
+//                so nothing but the per-chunk barrier can stall their MFMA stream; the fragments of the chunk's second k step
+//                are fetched while the first step's MFMAs run (BK = 32: two steps per barrier).
+//   waves 8,9    A FEEDERS: HBM -> registers FC_DA chunks ahead -> exact split -> LDS planes (their vmcnt queue holds only
+//                these loads: deep, in-order prefetch).
+//   waves 10,11  B FEEDERS: DMA of the B planes, one chunk ahead (24 one-KiB pieces per wave and chunk).
+// Two LDS stages of 72 KiB.  Requires K % 32 == 0, N == 256 column tiles, lda % 4 == 0.
+#ifndef FC_DA
+#define FC_DA 3
+#endif
+#ifndef FC_NB
+#define FC_NB 2
+#endif
+__global__ __launch_bounds__(640 + 64 * FC_NB) void k_gemm_split_fc(SplitGemmK g) {
+    constexpr int BK = 32, BN = 256, KS = 2, WC = 4;
+    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_SLAB = 2 * A_OCT, B_SLAB = 2 * B_OCT;
+    constexpr int A_PLANE = KS * A_SLAB, B_PLANE = KS * B_SLAB, STAGE = 3 * A_PLANE + 3 * B_PLANE;          // 24 + 48 KiB
+    constexpr int EP_LD = 68;
+    constexpr int A_PER = (GS_BM * BK / 4) / 128;                   // float4 per A-feeder lane and chunk: 8
+    constexpr int B_PPW = (3 * (BK / 8) * (BN / 64)) / FC_NB;       // DMA pieces per B-feeder wave and chunk: 24 with two feeders
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + GS_BM * 4];
+    const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
+    const int q = nb / 8, r = nb % 8, xcd = b % 8, idx = b / 8;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb / g.n_col_tiles, ct = lb % g.n_col_tiles;
+    const int set = g.tiles[tile * 3], row0 = g.tiles[tile * 3 + 1], nrows = g.tiles[tile * 3 + 2];
+    const int n0 = ct * BN;
+    const uint16_t* Bt = g.Bt + (int64_t)set * g.bt_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = g.K / BK;
+    float* scales = reinterpret_cast<float*>(smem + 2 * STAGE);
+    if (tid < GS_BM) scales[tid] = g.row_scale ? g.row_scale[row0 + min(tid, nrows - 1)] : 1.f;
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+#ifdef FC_TRACE
+    const bool tr = (blockIdx.x == 2048) && lane == 0 && (wave == 0 || wave == 8 || wave == 10);
+    const int trole = wave == 0 ? 0 : wave == 8 ? 1 : 2;
+#define FC_T(C, WHICH) do { if (tr) g.dbg[((trole * 64 + (C)) * 4) + (WHICH)] = clock64(); } while (0)
+#else
+#define FC_T(C, WHICH) do {} while (0)
+#endif
+
+    if (wave >= 10) {
+        // ================= B feeder
+        const int fw = wave - 10;
+        unsigned boff[B_PPW]; int bdst[B_PPW];
+#pragma unroll
+        for (int p = 0; p < B_PPW; ++p) {
+            const int piece = fw * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % (BK / 8), plane = po / (BK / 8);
+            boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + n0 + cb * 64 + lane) * 8) * 2);
+            bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+        }
+        const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
+        auto issue_b = [&](int chunk, int buf) {
+#ifdef FC_EXP_NOB
+            return;
+#endif
+            const uint64_t base = (uint64_t)(uintptr_t)Bt + (uint64_t)(chunk * b_chunk_bytes);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+            const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * STAGE + bdst[p]));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
+            }
+        };
+#ifdef FC_B_REGS
+        // register path: global_load_dwordx4 -> ds_write_b128 (issue ~30-40 cycles per KiB against ~100 for an LDS-DMA piece)
+        auto fetch_b = [&](int chunk, int buf) {
+            float4 rb[B_PPW];
+            const char* base = reinterpret_cast<const char*>(Bt) + chunk * b_chunk_bytes;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) rb[p] = *reinterpret_cast<const float4*>(base + boff[p]);
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) *reinterpret_cast<float4*>(smem + buf * STAGE + bdst[p] + lane * 16) = rb[p];
+        };
+        fetch_b(0, 0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) fetch_b(c + 1, (c + 1) & 1);
+            __syncthreads();
+        }
+#else
+        issue_b(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            FC_T(c, 0);
+            if (c + 1 < nchunks) issue_b(c + 1, (c + 1) & 1);
+            FC_T(c, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FC_T(c, 2);
+            GS_BARRIER();
+            FC_T(c, 3);
+        }
+#endif
+    } else if (wave >= 8) {
+        // ================= A feeder
+        const int ft = tid - 512;                                    // 0..127
+        const float* asrc[A_PER]; int adst[A_PER];
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) {
+            const int id = ft + p * 128, rr = id / (BK / 4), c4 = (id % (BK / 4)) * 4;
+            asrc[p] = g.A + (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + c4;
+            adst[p] = (c4 >> 3) * A_OCT + rr * 16 + (c4 & 7) * 2;
+        }
+        // The loads are issued through inline asm and their completion is counted by hand: with compiler-managed waits a
+        // register prefetch deeper than one chunk degenerates (hipcc's vmcnt model goes conservative at the loop back-edge and
+        // waits for the NEWEST loads before it touches the oldest slot -- measured: prefetch depth 2, 4 and 8 all ran alike).
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v ra[FC_DA][A_PER];
+        auto load_a = [&](int chunk, int slot) {
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+#ifdef FC_EXP_NOA
+                ra[slot][p] = f4v{1.f + chunk, 2.f, 3.f, 4.f};
+#else
+                #ifdef FC_A_NT
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(ra[slot][p]) : "v"(asrc[p] + chunk * BK) : "memory");      // streamed once: keep L2 for the B planes
+#else
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(asrc[p] + chunk * BK) : "memory");
+#endif
+#endif
+            }
+        };
+        // wait until at most `newer` chunk groups (A_PER loads each) are outstanding, then the slot's registers are valid
+#define FC_WAIT_SLOT(NEWER, SLOT)                                                                                              \
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(ra[SLOT][0]), "+v"(ra[SLOT][1]), "+v"(ra[SLOT][2]), "+v"(ra[SLOT][3]),      \
+                     "+v"(ra[SLOT][4]), "+v"(ra[SLOT][5]), "+v"(ra[SLOT][6]), "+v"(ra[SLOT][7]) : "n"((NEWER) * A_PER) : "memory")
+        auto wait_slot = [&](int newer, int slot_static) {};
+        (void)wait_slot;
+        auto store_a = [&](int buf, int slot) {
+            char* As = smem + buf * STAGE;
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                uint2 h, m, l;
+                const f4v v = ra[slot][p];
+                gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+                *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+            }
+        };
+        static_assert(A_PER == 8 && FC_DA >= 2 && FC_DA <= 8, "wait macro is written for 8 loads per chunk");
+#pragma unroll
+        for (int d = 0; d < FC_DA; ++d) if (d < nchunks) load_a(d, d);
+#ifndef FC_EXP_NOA
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[0][2]), "+v"(ra[0][3]), "+v"(ra[0][4]), "+v"(ra[0][5]), "+v"(ra[0][6]), "+v"(ra[0][7]) :: "memory");
+#endif
+        store_a(0, 0);
+        __syncthreads();
+        for (int c0 = 0; c0 < nchunks; c0 += FC_DA) {
+#pragma unroll
+            for (int u = 0; u < FC_DA; ++u) {
+                const int c = c0 + u;
+                if (c < nchunks) {
+                    FC_T(c, 0);
+                    if (c + FC_DA < nchunks) load_a(c + FC_DA, u);                 // slot u held chunk c (already in LDS)
+                    FC_T(c, 1);
+                    if (c + 1 < nchunks) {
+#ifndef FC_EXP_NOA
+                        // chunk c+1 sits in slot (u+1)%FC_DA; newer groups outstanding: chunks c+2 .. min(c+FC_DA, nchunks-1)
+                        const int newer = min(FC_DA - 1, nchunks - 2 - c);
+                        const int SL = (u + 1) % FC_DA;
+                        if (newer >= FC_DA - 1) FC_WAIT_SLOT(FC_DA - 1, SL);
+                        else if (newer == 1 && FC_DA > 2) FC_WAIT_SLOT(1, SL);
+                        else if (newer == 2 && FC_DA > 3) FC_WAIT_SLOT(2, SL);
+                        else if (newer == 3 && FC_DA > 4) FC_WAIT_SLOT(3, SL);
+                        else FC_WAIT_SLOT(0, SL);
+#endif
+                        store_a((c + 1) & 1, (u + 1) % FC_DA);
+                    }
+                    FC_T(c, 2);
+                    GS_BARRIER();
+                    FC_T(c, 3);
+                }
+            }
+        }
+#undef FC_WAIT_SLOT
+    } else {
+        // ================= compute
+        const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
+        gm_f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        const int a_lane = kh * A_OCT + (wr * 64 + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            FC_T(c, 0);
+            const char* S = smem + (c & 1) * STAGE;
+            gm_bf16x8 af[2][2][3], bf[2][2][3];                      // [k step][block][plane]
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[ks][i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + ks * A_SLAB + i * 512);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[ks][j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + ks * B_SLAB + j * 512);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#define FC_PROD(PA, PB)                                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA], bf[ks][j][PB], acc[i][j], 0, 0, 0);
+                FC_PROD(2, 0) FC_PROD(0, 2) FC_PROD(1, 1) FC_PROD(1, 0) FC_PROD(0, 1) FC_PROD(0, 0)
+#undef FC_PROD
+            }
+            FC_T(c, 2);
+            GS_BARRIER();
+            FC_T(c, 3);
+        }
+        // epilogue (compute waves only; the feeders are done): 32x64 halves through LDS, row-contiguous 16-B stores
+        const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+        float* E = reinterpret_cast<float*>(smem) + wave * (32 * EP_LD);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        const int col = n0 + wc * 64 + ec;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (biasp) b4 = *reinterpret_cast<const float4*>(biasp + col);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+            // each wave reads back only its OWN staging region: no workgroup barrier needed (wave-level LDS ordering suffices)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = wr * 64 + i * 32 + it * 4 + er;
+                if (rl >= nrows) continue;
+                const int64_t row = row0 + rl;
+                const float sc = scales[rl];
+                float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+                v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+                if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+#ifdef FC_EXP_NOSTORE
+                if (v.x != 123.456f) continue;
+#endif
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                f4v vv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
 }

@@ -34,8 +34,11 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, 1), dim3(256), 0, 0, dW, 0, 0, K, N, 0, dBt);
     SplitGemmK g{};
     g.A = dA; g.lda = K; g.Bt = dBt; g.bt_stride = 0; g.C = dC; g.ldc = N; g.K = K; g.N = N; g.bias = dBias; g.relu = 0;
+    unsigned long long* dDbg; CK(hipMalloc(&dDbg, 3 * 64 * 4 * 8)); CK(hipMemset(dDbg, 0, 3 * 64 * 4 * 8)); g.dbg = dDbg;
     g.tiles = dT; g.n_tiles = (int)tiles.size() / 3; g.n_col_tiles = N / (64 * WC); g.nt_store = 1;
+    const bool fc = argc > 6 && atoi(argv[6]) == 1;
     auto launch = [&]() {
+        if (fc) { hipLaunchKernelGGL(k_gemm_split_fc, dim3(g.n_tiles * g.n_col_tiles), dim3(640 + 64 * FC_NB), 0, 0, g); return; }
         if (BK == 32) { printf("BK=32 removed\n"); exit(1); }
         else { if (WC == 4) run<4, 16>(g, 0); else if (WC == 2) run<2, 16>(g, 0); else run<1, 16>(g, 0); }
     };
@@ -50,6 +53,18 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * M * K * N;
     printf("split-bf16 GEMM: %.3f ms  %.1f TFLOP/s (fp32-equivalent)  %.1f TFLOP/s of bf16 MFMA work  %.2f TB/s of A+C traffic\n", ms, fl / ms / 1e9,
            6 * fl / ms / 1e9, ((double)M * K * 4 + (double)M * N * 4) / ms / 1e9);
+#ifdef FC_TRACE
+    {
+        std::vector<unsigned long long> d(3 * 64 * 4);
+        CK(hipMemcpy(d.data(), dDbg, d.size() * 8, hipMemcpyDeviceToHost));
+        const char* names[3] = {"compute", "A-feeder", "B-feeder"};
+        const unsigned long long t0 = d[0];
+        for (int r = 0; r < 3; ++r) {
+            printf("%s (ticks since compute chunk 0 start; s_memtime ticks = 100 MHz?)\n", names[r]);
+            for (int c = 0; c < K / 32; ++c) printf("  c%d: start %lld  issued %lld  ready %lld  after-barrier %lld\n", c, (long long)(d[(r * 64 + c) * 4] - t0), (long long)(d[(r * 64 + c) * 4 + 1] - t0), (long long)(d[(r * 64 + c) * 4 + 2] - t0), (long long)(d[(r * 64 + c) * 4 + 3] - t0));
+        }
+    }
+#endif
     std::vector<float> C((size_t)M * N);
     CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
     // accuracy on a sample of rows: vs fp64, next to the fp32 fmaf chain's own error
