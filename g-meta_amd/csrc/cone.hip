@@ -202,9 +202,11 @@ static int heavy_list(const int32_t* indptr, int n, int nnz, int thr, int32_t** 
     c = std::min(c, cap);
     if (c > 1) {                          // deterministic order
         std::vector<int32_t> h(c);
-        GM_HIP(hipMemcpy(h.data(), *list, 4 * (size_t)c, hipMemcpyDeviceToHost));
+        GM_HIP(hipMemcpyAsync(h.data(), *list, 4 * (size_t)c, hipMemcpyDeviceToHost, s));      // stream-ordered: a plain hipMemcpy would serialise with the default stream
+        GM_HIP(hipStreamSynchronize(s));
         std::sort(h.begin(), h.end());
-        GM_HIP(hipMemcpy(*list, h.data(), 4 * (size_t)c, hipMemcpyHostToDevice));
+        GM_HIP(hipMemcpyAsync(*list, h.data(), 4 * (size_t)c, hipMemcpyHostToDevice, s));
+        GM_HIP(hipStreamSynchronize(s));
     }
     *count = c;
     return GM_OK;

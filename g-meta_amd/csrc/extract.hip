@@ -413,9 +413,12 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
         b->n_heavy[o] = std::min(cnt[o], cap);
         if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
             std::vector<int32_t> h(b->n_heavy[o]);
-            GM_HIP(hipMemcpy(h.data(), b->d_heavy[o], 4 * h.size(), hipMemcpyDeviceToHost));
+            // stream-ordered copies + a wait on THIS stream only: a plain hipMemcpy is a null-stream operation and would
+            // serialise the prefetch thread's batch build with whatever the training thread has queued on the default stream
+            GM_HIP(hipMemcpyAsync(h.data(), b->d_heavy[o], 4 * h.size(), hipMemcpyDeviceToHost, s));
+            GM_HIP(hipStreamSynchronize(s));
             std::sort(h.begin(), h.end());
-            if (h.size() > 1) GM_HIP(hipMemcpy(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice));
+            if (h.size() > 1) { GM_HIP(hipMemcpyAsync(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice, s)); GM_HIP(hipStreamSynchronize(s)); }
             GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), b->n_heavy[o], &b->d_sched[o], &b->sched_len[o], s));
         }
     }
