@@ -347,6 +347,118 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
     }
 }
 
+// Small-launch variant of k_gemm_glds<1> (tile 128 x 64): EIGHT waves of 32 x 32 instead of two of 64 x 64.  A launch with
+// a few hundred tiles (support batches of a 4-task shard, the Tissue / FirstMM shapes) puts about one workgroup on a CU, where
+// the two-wave version walks a chain of K/2 * 4 dependent-issue MFMAs (64 cycles each) with one wave per SIMD and nothing to
+// cover the per-chunk LDS latency: 34 us for a 14-us chain.  Same tiles, same DMA pipeline, a quarter of the MFMA chain per wave.
+__global__ __launch_bounds__(512) void k_gemm_glds_small(GemmK g) {
+    constexpr int NW = 8, BN = 64;
+    constexpr int A_FLOATS = GM_GEMM_BM * BK, B_FLOATS = BK * BN, STAGE = A_FLOATS + B_FLOATS;         // 2048 + 1024 floats
+    constexpr int EP_LD = 36, EPI_FLOATS = NW * 32 * EP_LD;                                              // == 3 * STAGE
+    constexpr int MAIN_FLOATS = 3 * STAGE > EPI_FLOATS ? 3 * STAGE : EPI_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[MAIN_FLOATS + 256 + GM_GEMM_BM];                 // + one dummy DMA piece + the row scales
+    const int nb = g.n_tiles * g.n_col_tiles, b = blockIdx.x;
+    const int q = nb / GM_NXCD, r = nb % GM_NXCD, xcd = b % GM_NXCD, idx = b / GM_NXCD;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb / g.n_col_tiles, ct = lb % g.n_col_tiles;
+    const int set = g.tiles[tile * 3], row0 = g.tiles[tile * 3 + 1], nrows = g.tiles[tile * 3 + 2];
+    const int n0 = ct * BN;
+    const float* Bp = g.B + (int64_t)set * g.b_stride;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float my_scale = 1.f;
+    if (tid < GM_GEMM_BM && g.row_scale) my_scale = g.row_scale[row0 + min(tid, nrows - 1)];
+    const int wr = wave >> 1, wc = wave & 1;                               // 4 x 2 grid of 32 x 32 sub-tiles
+    const int li = lane & 31, kh = lane >> 5;
+    // 12 one-KiB DMA pieces per chunk (8 of A, 4 of B) over 8 waves: two slots per wave, the last four slots re-read A piece 0
+    // into a scratch KiB so that every wave issues exactly two loads per chunk (the vmcnt wait is a fixed count)
+    constexpr int A_PIECES = 8, PIECES = 12, PPW = 2;
+    const float* src[PPW]; int dstoff[PPW]; int64_t kstep[PPW]; bool dummy[PPW];
+#pragma unroll
+    for (int p = 0; p < PPW; ++p) {
+        const int piece = wave * PPW + p;
+        dummy[p] = piece >= PIECES;
+        if (piece < A_PIECES || dummy[p]) {
+            const int pc = dummy[p] ? 0 : piece, rr = pc * 16 + (lane >> 2);
+            src[p] = g.A + (int64_t)(row0 + min(rr, nrows - 1)) * g.lda + (lane & 3) * 4;
+            kstep[p] = BK; dstoff[p] = pc * 256;
+        } else {
+            const int e = (piece - A_PIECES) * 256 + lane * 4, kk = e / BN, n = e % BN;
+            src[p] = Bp + (int64_t)kk * g.N + n0 + n;
+            kstep[p] = (int64_t)BK * g.N; dstoff[p] = A_FLOATS + (piece - A_PIECES) * 256;
+        }
+    }
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) float*)smem);
+    auto issue = [&](int chunk) {
+        const unsigned st = lds_base + (unsigned)((chunk % 3) * STAGE * 4);
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) {
+            const float* gsrc = src[p] + chunk * kstep[p];
+            const unsigned dst = __builtin_amdgcn_readfirstlane(dummy[p] ? lds_base + (unsigned)MAIN_FLOATS * 4u : st + (unsigned)dstoff[p] * 4u);
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int nchunks = g.K / BK;
+    issue(0);
+    if (nchunks > 1) issue(1);
+    if (tid < GM_GEMM_BM) smem[MAIN_FLOATS + 256 + tid] = my_scale;
+    for (int c = 0; c < nchunks; ++c) {
+        if (c + 1 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 2 < nchunks) issue(c + 2);
+        const float* As = smem + (c % 3) * STAGE;
+        const float* Bs = As + A_FLOATS;
+        float4 af[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) af[qq] = *reinterpret_cast<const float4*>(&As[(wr * 32 + li) * BK + qq * 8 + kh * 4]);
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int kk = qq * 8 + kh * 4 + rr;
+                const float b0 = Bs[kk * BN + wc * 32 + li];
+                const float a0 = rr == 0 ? af[qq].x : rr == 1 ? af[qq].y : rr == 2 ? af[qq].z : af[qq].w;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc, 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    const float* biasp = g.bias ? g.bias + (int64_t)set * g.bias_stride : nullptr;
+    float* E = smem + wave * (32 * EP_LD);
+    const int er = lane >> 3, ec = (lane & 7) * 4;                          // 8 rows x 32 columns per pass
+    const int col = n0 + wc * 32 + ec;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (biasp) b4 = *reinterpret_cast<const float4*>(biasp + col);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + li] = acc[e];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int rl = wr * 32 + it * 8 + er;
+        if (rl >= nrows) continue;
+        const int64_t row = row0 + rl;
+        const float sc = smem[MAIN_FLOATS + 256 + rl];
+        float4 v = *reinterpret_cast<const float4*>(&E[(it * 8 + er) * EP_LD + ec]);
+        v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+        if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+        if (g.mask_h) {
+            const float4 m = *reinterpret_cast<const float4*>(g.mask_h + row * g.ldc + col);
+            v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        }
+        if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+        if (g.nt_store) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            f4v vv = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+        } else *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+    }
+}
+
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
@@ -392,7 +504,12 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         const dim3 grid(g.n_tiles * g.n_col_tiles);
         if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);
         else if (bn == 128) hipLaunchKernelGGL((k_gemm_glds<2>), grid, dim3(256), 0, s, g);
-        else hipLaunchKernelGGL((k_gemm_glds<1>), grid, dim3(128), 0, s, g);
+        else {
+            static int small = -1;            // 1 (default): 8 x (32 x 32) waves per 128 x 64 tile when the launch leaves CUs mostly empty
+            if (small < 0) { const char* e = getenv("GM_GEMM_SMALL"); small = e ? atoi(e) : 1; }
+            if (small && (int64_t)g.n_tiles * g.n_col_tiles <= 4 * gm_num_cus()) hipLaunchKernelGGL(k_gemm_glds_small, grid, dim3(512), 0, s, g);
+            else hipLaunchKernelGGL((k_gemm_glds<1>), grid, dim3(128), 0, s, g);
+        }
         GM_HIP(hipGetLastError());
         return GM_OK;
     }

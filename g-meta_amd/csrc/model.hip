@@ -212,9 +212,23 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
         float* lg_s = wl_s + hk.C * hk.hc + hk.C;
         float* dl_s = lg_s + S * D;
         const float* P = hk.params + (int64_t)set * hk.pstride;
-        for (int id = tid; id < S * hk.nc * hk.Hd; id += HL_THREADS) {
-            const int q = id / hk.Hd, col = id - q * hk.Hd;
-            hs[id] = hk.H[centre_row(hk, s0 + q / hk.nc, q % hk.nc) * hk.ldh + col];
+        // centre rows of H_L -> LDS.  The row ids (two dependent loads each) are resolved first, then the row reads are
+        // issued eight deep: the kernel is one workgroup per task and pure latency, so a serial chain of 18 dependent
+        // global loads per thread (the first version) was most of its time.
+        int* crow = reinterpret_cast<int*>(dl_s + S * D);               // [S * nc] row of every centre (scratch past the dlogits copy)
+        const int nq = S * hk.nc;
+        for (int q = tid; q < nq; q += HL_THREADS) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
+        __syncthreads();
+        const int total = nq * hk.Hd;
+        for (int id0 = tid; id0 < total; id0 += 8 * HL_THREADS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int id = min(id0 + u * HL_THREADS, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
+                v[u] = hk.H[(int64_t)crow[q] * hk.ldh + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total) hs[id] = v[u]; }
         }
         for (int id = tid; id < hk.C * hk.hc; id += HL_THREADS) wl_s[id] = P[hk.wl_off + id];
         for (int id = tid; id < hk.C; id += HL_THREADS) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
@@ -818,7 +832,8 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     const size_t proto_bytes = (proto_lds(pk.Ct, pk.n, pk.D, HL_THREADS) + 15) / 16 * 16;
     int max_subs = 0;
     for (int t = 0; t < b->sets; ++t) max_subs = std::max(max_subs, b->h_set_sub_off[t + 1] - b->h_set_sub_off[t]);
-    const size_t hs_bytes = sizeof(float) * ((size_t)max_subs * b->centres * L.dims[L.n_gcn] + (size_t)L.n_out * (L.hc + 1) + 2 * (size_t)max_subs * L.n_out);
+    const size_t hs_bytes = sizeof(float) * ((size_t)max_subs * b->centres * L.dims[L.n_gcn] + (size_t)L.n_out * (L.hc + 1) + 2 * (size_t)max_subs * L.n_out +
+                                             (size_t)max_subs * b->centres);      // + the centre-row scratch
     static int stage_on = -1;
     if (stage_on < 0) { const char* e = getenv("GM_HEAD_STAGE"); stage_on = e ? atoi(e) : 1; }
     const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
