@@ -296,6 +296,18 @@ def main():
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
+        if lib.gm_get_gemm_mode() == 1:      # the same dense schedule with every GEMM on the exact-fp32 MFMA kernels (include/gmeta_hip.h, gm_set_gemm_mode)
+            lib.gm_set_gemm_mode(0)
+            step(0); drain()
+            torch.cuda.synchronize(); te = time.perf_counter()
+            for k in range(a.extra_steps):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
+            extra['exact_f32_mfma_gemm'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
+                                            'what': 'default schedule with GM_GEMM_MODE=f32: every update GEMM on v_mfma_f32_32x32x2_f32'}
+            lib.gm_set_gemm_mode(1)
         lv = {}
         for side, x in (('spt', batches[0][0][0].view_of), ('qry', batches[0][2][0].view_of)):      # what the cone schedule touches
             ok = C.c_int32(); nr = (C.c_int64 * (cfg['h'] + 1))(); ne = (C.c_int64 * (cfg['h'] + 1))()
@@ -349,11 +361,14 @@ def main():
                 traffic_source = 'profiles/agg_traffic.json (%s; separate rocprofv3 --pmc pass, not this run)' % tj.get('taken', 'date unknown')
             except Exception:
                 traffic = None
-        gemm_mode = os.environ.get('GM_GEMM_MODE', 'default')
+        gemm_mode = ('split-bf16: large N=256 launches on v_mfma_f32_32x32x16_bf16 with every fp32 operand split exactly into three bf16 pieces, six '
+                     'products, fp32 accumulation (error vs fp64 <= the fp32 fmaf chain\'s; DESIGN.md section 4); other launches exact fp32'
+                     if lib.gm_get_gemm_mode() == 1 else 'exact fp32 (v_mfma_f32_32x32x2_f32) everywhere')
         out = {
             'metric': 'meta-tasks/sec (inner-loop fwd+bwd) at task_num=%d' % T, 'value': round(T / (ms_per_step * 1e-3), 3),
             'unit': 'meta-tasks/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'arithmetic': 'fp32 storage and accumulation throughout; update GEMMs: ' + gemm_mode,
             'config': {'workload': synth.WORKLOADS[a.config] +
                                    ' (synthetic %s, F0=%d), %s%s, h=%d, hidden=%d, %d-way %d-shot %d-qry, task_num=%d, update_step=%d, '
                                    'sample_nodes=%d; subgraphs pre-extracted in HBM'
@@ -400,7 +415,7 @@ def main():
                                      'ms_at_fp32_mfma_peak': round(t_mfma, 2), 'ms_at_hbm_peak': round(t_hbm, 2),
                                      'frac_of_serial_bound': round((t_mfma + t_hbm) / ms_per_step, 3),
                                      'frac_of_overlapped_bound': round(max(t_mfma, t_hbm) / ms_per_step, 3),
-                                     'note': 'bounds priced with the exact-fp32 MFMA peak (157.3 TF); a split-bf16 GEMM mode can beat the fp32 bound'}
+                                     'note': 'bounds priced with the exact-fp32 MFMA peak (157.3 TF); the split-bf16 GEMM kernel does 6 bf16 MFMA flops per fp32 flop on a 2.5 PF pipe, so it can beat the fp32 bound'}
         if e2e:
             out['end_to_end'] = e2e
         if extra:

@@ -46,12 +46,15 @@ PROTOTYPES = {
     'gm_gcn_ws_bytes': (i64, [vp, vp]),
     'gm_gcn_forward': (C.c_int, [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp]),
     'gm_gcn_backward': (C.c_int, [vp, vp, vp, i64, vp, vp, vp, vp, i64, vp, i64, vp]),
+    'gm_dense_update': (C.c_int, [vp, vp, i32, vp, i64, i32, vp, i32, vp]),
     'gm_proto_loss_spt': (C.c_int, [vp, vp, i32, vp, i32, vp, vp, vp, vp, vp]),
     'gm_proto_loss_qry': (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     'gm_meta_ws_bytes': (i64, [vp, vp, vp, vp]),
     'gm_meta_out_floats': (i64, [vp, vp, vp]),
     'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
     'gm_meta_finish': (C.c_int, [vp, i64, i32, vp, vp, vp]),
+    'gm_set_gemm_mode': (None, [i32]),
+    'gm_get_gemm_mode': (i32, []),
     'gm_profile_enable': (None, [i32]),
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
     'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),

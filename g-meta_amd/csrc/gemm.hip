@@ -6,10 +6,14 @@
 #include <algorithm>
 #include <stdlib.h>
 #include "gm_internal.h"
+#include "gemm_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
+#ifndef GM_GEMM_MODE_DEFAULT
+#define GM_GEMM_MODE_DEFAULT 1
+#endif
 #define AS_LD 20            // 16 + 4 pad (keeps 16-B alignment of every row)
 
 struct GemmK {
@@ -459,6 +463,24 @@ __global__ __launch_bounds__(512) void k_gemm_glds_small(GemmK g) {
     }
 }
 
+// ---- split-bf16 path (gemm_split.h): mode switch, eligibility, weight planes
+static int g_gemm_mode = -1;
+int gm_gemm_mode() {
+    if (g_gemm_mode < 0) { const char* e = getenv("GM_GEMM_MODE"); g_gemm_mode = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : GM_GEMM_MODE_DEFAULT; }
+    return g_gemm_mode;
+}
+extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode = mode ? 1 : 0; }
+extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
+// The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
+bool gm_gemm_split_ok(int n_tiles, int K, int N) {
+    return gm_gemm_mode() == 1 && N == 256 && K % 16 == 0 && K >= 32 && n_tiles >= gm_num_cus();
+}
+int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, sets), dim3(256), 0, s, params, pstride, w_off, K, N, trans, out);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
@@ -468,6 +490,19 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     return rc;
 }
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
+    if (a.Bsplit) {
+        // fp32-accurate product on the bf16 matrix cores (exact 3-way operand split, 6 MFMA products, fp32 accumulation)
+        const bool ok = a.N == 256 && a.K % 16 == 0 && a.K >= 32 && !a.mask_h && !a.mask_b && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+                        (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.bias || a.bias_stride % 4 == 0);
+        GM_REQUIRE(ok, GM_EINVAL, "gemm: launch not eligible for the split-bf16 kernel (N=%d K=%d)", a.N, a.K);
+        SplitGemmK k{};
+        k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
+        k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
+        k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1;
+        hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(a.n_tiles, gm_num_cus())), dim3(1024), 0, s, k);
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
             a.mask_b, a.relu_bits, a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
     }
 }
 
+#ifdef GS_EXPERIMENTS      // the non-persistent prototypes (tools/gemm_split_bench.hip): kept for the ablations in DESIGN.md, not built into the library
 // C[rows of tile] = epi( A[rows, K] @ B_set ), block tile 128 x (64*WC), 2*WC waves, each wave a 64x64 sub-tile
 // (2x2 MFMA 32x32 blocks; per 16-wide k chunk 6 bf16 MFMAs per block, issued product-major so that consecutive MFMAs hit
 // different accumulators).  LDS holds two stages of
@@ -548,6 +549,291 @@ __global__ __launch_bounds__(640 + 64 * FC_NB) void k_gemm_split_fc(SplitGemmK g
                 __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+#endif  // GS_EXPERIMENTS
+
+// ------------------------------------------------------------------------------------------------------------------
+// PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 (one 128 x 256 tile per step, 16-k chunks):
+//   waves 0..7    COMPUTE  64x64 sub-tiles: LDS fragments -> 24 bf16 MFMAs per chunk; at the end of a tile the accumulators go
+//                 through a wave-PRIVATE LDS staging area to row-contiguous 16-B global stores.  These waves never issue a
+//                 global LOAD, so they never wait on vmcnt: the stores of tile i drain while tile i+1 is being computed.
+//   waves 8,9     A FEEDERS  HBM -> registers PF_DA chunks ahead (inline-asm loads, hand-counted vmcnt) -> exact split -> LDS;
+//                 they also stage the tile's row scales and bias (so that the compute waves need no global load).
+//   waves 10..13  B FEEDERS  LDS-DMA of the three bf16 weight planes, one chunk ahead (6 one-KiB pieces per wave and chunk).
+// Every wave runs the same flattened (tile, chunk) sequence with ONE raw barrier per chunk; feeders run one chunk ahead across
+// tile boundaries.  One workgroup per CU, grid = min(tiles, CUs); workgroup b walks tiles b, b + G, ... of the XCD-contiguous
+// order.  LDS: 2 stages x 36 KiB + 8 x 8.5 KiB staging + scales/bias = 143 KiB.
+#ifndef PF_DA
+#define PF_DA 4
+#endif
+__global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
+    constexpr int BK = 16, BN = 256, WC = 4;
+    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
+    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;                                  // 12 + 24 KiB
+    constexpr int EP_LD = 68, E_WAVE = 32 * EP_LD * 4;                                // 8704 B per compute wave
+    constexpr int OFF_E = 2 * STAGE, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
+    constexpr int A_PER = (GS_BM * BK / 4) / 256;                                     // float4 per A-feeder lane and chunk: 2 (four feeder waves)
+    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = g.K / BK;
+    const int G = gridDim.x, b = blockIdx.x;
+    // XCD-contiguous tile order over this launch: hardware id t -> logical tile
+    const int nb = g.n_tiles, q8 = nb / 8, r8 = nb % 8;
+    auto logical = [&](int t) -> int { const int x = t % 8, i = t / 8; return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; };
+    const int ntb = b < nb ? (nb - b + G - 1) / G : 0;                                // tiles of this workgroup
+    const int total = ntb * nchunks;                                                  // flattened chunk count
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
+    float* biasl = reinterpret_cast<float*>(smem + OFF_BIAS);                         // [2][256]
+    if (total == 0) return;
+#ifdef PF_TRACE
+    const bool tr = (blockIdx.x == 77) && lane == 0 && (wave == 0 || wave == 8 || wave == 12);
+    const int trole = wave == 0 ? 0 : wave == 8 ? 1 : 2;
+#define PF_T(C, WHICH) do { if (tr && (C) < 64) g.dbg[((trole * 64 + (C)) * 4) + (WHICH)] = clock64(); } while (0)
+#else
+#define PF_T(C, WHICH) do {} while (0)
+#endif
+
+    if (wave >= 12) {
+        // ================= B feeder
+        __builtin_amdgcn_s_setprio(2);            // feeders ahead of the MFMA-heavy compute waves in VALU / LDS arbitration
+        const int fw = wave - 12;
+        unsigned boff[B_PPW]; int bdst[B_PPW];
+#pragma unroll
+        for (int p = 0; p < B_PPW; ++p) {
+            const int piece = fw * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % 2, plane = po / 2;
+            boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + cb * 64 + lane) * 8) * 2);
+            bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+        }
+        const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
+        auto issue_b = [&](int gc) {                                                  // global chunk gc -> stage gc & 1
+            const int ti = gc / nchunks, c = gc - ti * nchunks;
+            const int lt = logical(b + ti * G);
+            const int set = g.tiles[lt * 3];
+            const uint64_t base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)set * g.bt_stride) + (uint64_t)(c * b_chunk_bytes);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+            const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((gc & 1) * STAGE + bdst[p]));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
+            }
+        };
+#ifdef PF_B_REGS
+        // register path for B: global_load_dwordx4 (L2 hits) two chunks ahead -> ds_write_b128, hand-counted vmcnt
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v rb[2][B_PPW];
+        auto load_b = [&](int gc, int slot) {
+            const int ti = gc / nchunks, c = gc - ti * nchunks;
+            const int lt = logical(b + ti * G);
+            const int set = g.tiles[lt * 3];
+            const char* base = reinterpret_cast<const char*>(g.Bt + (int64_t)set * g.bt_stride) + c * b_chunk_bytes;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[slot][p]) : "v"(base + boff[p]) : "memory");
+        };
+        auto store_b = [&](int gc, int slot) {
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) *reinterpret_cast<f4v*>(smem + (gc & 1) * STAGE + bdst[p] + lane * 16) = rb[slot][p];
+        };
+#define PF_WAITB(N, SLOT) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rb[SLOT][0]), "+v"(rb[SLOT][1]), "+v"(rb[SLOT][2]), "+v"(rb[SLOT][3]), "+v"(rb[SLOT][4]), "+v"(rb[SLOT][5]) : "n"(N) : "memory")
+        load_b(0, 0);
+        if (total > 1) load_b(1, 1);
+        if (total > 1) PF_WAITB(6, 0); else PF_WAITB(0, 0);
+        store_b(0, 0);
+        GS_BARRIER();
+        for (int g0 = 0; g0 < total; g0 += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gc = g0 + u;
+                if (gc < total) {
+                    PF_T(gc, 0);
+                    if (gc + 2 < total) load_b(gc + 2, u);                            // slot u held chunk gc (already in LDS)
+                    PF_T(gc, 1);
+                    if (gc + 1 < total) {
+                        if (gc + 2 < total) PF_WAITB(6, (u + 1) & 1); else PF_WAITB(0, (u + 1) & 1);
+                        store_b(gc + 1, (u + 1) & 1);
+                    }
+                    PF_T(gc, 2);
+                    GS_BARRIER();
+                    PF_T(gc, 3);
+                }
+            }
+        }
+#undef PF_WAITB
+#else
+        issue_b(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GS_BARRIER();
+        for (int gc = 0; gc < total; ++gc) {
+            PF_T(gc, 0);
+            if (gc + 1 < total) issue_b(gc + 1);
+            PF_T(gc, 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PF_T(gc, 2);
+            GS_BARRIER();
+            PF_T(gc, 3);
+        }
+#endif
+    } else if (wave >= 8) {
+        // ================= A feeder
+        __builtin_amdgcn_s_setprio(3);
+        const int ft = tid - 512;                                                     // 0..255
+        const int rr[A_PER] = {ft >> 2, (ft + 256) >> 2};
+        const int c4 = (ft & 3) * 4;
+        int adst[A_PER];
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) adst[p] = (c4 >> 3) * A_OCT + rr[p] * 16 + (c4 & 7) * 2;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v ra[PF_DA][A_PER];
+        auto load_a = [&](int gc, int slot) {
+            const int ti = gc / nchunks, c = gc - ti * nchunks;
+            const int lt = logical(b + ti * G);
+            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                const float* src = g.A + (int64_t)(row0 + min(rr[p], nrows - 1)) * g.lda + c4 + c * BK;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(src) : "memory");
+            }
+        };
+        auto store_a = [&](int gc, int slot) {
+            char* As = smem + (gc & 1) * STAGE;
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                uint2 h, m, l;
+                const f4v v = ra[slot][p];
+                gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+                *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+            }
+        };
+        // row scales + bias of tile ti -> LDS (parity ti & 1); ordinary loads, completed with the vmcnt(0) below
+        auto stage_tile_consts = [&](int ti) {
+            const int lt = logical(b + ti * G);
+            const int set = g.tiles[lt * 3], row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+            float sc = 1.f;
+            if (g.row_scale) sc = g.row_scale[row0 + min(ft & 127, nrows - 1)];
+            float b0 = 0.f;
+            if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[ft];
+            if (ft < GS_BM) scales[(ti & 1) * GS_BM + ft] = sc;
+            biasl[(ti & 1) * BN + ft] = b0;
+        };
+        static_assert(A_PER == 2 && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 2 loads per chunk");
+#define PF_WAIT_SLOT(NEWER, SLOT) \
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0]), "+v"(ra[SLOT][1]) : "n"((NEWER) * A_PER) : "memory")
+        stage_tile_consts(0);                                                          // (compiler-managed loads: done before the asm loads below are counted)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < PF_DA; ++d) if (d < total) load_a(d, d);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]) :: "memory");
+        store_a(0, 0);
+        GS_BARRIER();
+        for (int g0 = 0; g0 < total; g0 += PF_DA) {
+#pragma unroll
+            for (int u = 0; u < PF_DA; ++u) {
+                const int gc = g0 + u;
+                if (gc < total) {
+                    PF_T(gc, 0);
+                    if (gc + 1 < total) {
+                        // chunk gc+1 sits in slot (u+1) % PF_DA; newer groups in flight: chunks gc+2 .. min(gc+PF_DA-1, total-1)
+                        const int newer = min(PF_DA - 2, total - 2 - gc);
+                        const int SL = (u + 1) % PF_DA;
+                        if (newer >= PF_DA - 2 && PF_DA >= 2) PF_WAIT_SLOT(PF_DA - 2, SL);
+                        else if (newer == 1 && PF_DA > 3) PF_WAIT_SLOT(1, SL);
+                        else if (newer == 2 && PF_DA > 4) PF_WAIT_SLOT(2, SL);
+                        else PF_WAIT_SLOT(0, SL);
+                        PF_T(gc, 1);
+                        store_a(gc + 1, SL);
+                        // the first chunk of the NEXT tile is about to become visible: its scales / bias must be there as well
+                        if ((gc + 1) % nchunks == 0) { stage_tile_consts((gc + 1) / nchunks); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    }
+                    if (gc + PF_DA < total) load_a(gc + PF_DA, u);                     // slot u held chunk gc: already split into LDS
+                    PF_T(gc, 2);
+                    GS_BARRIER();
+                    PF_T(gc, 3);
+                }
+            }
+        }
+#undef PF_WAIT_SLOT
+    } else {
+        // ================= compute
+        const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
+        const int a_lane = kh * A_OCT + (wr * 64 + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        GS_BARRIER();
+        int gc = 0;
+        for (int ti = 0; ti < ntb; ++ti) {
+            gm_f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int c = 0; c < nchunks; ++c, ++gc) {
+                PF_T(gc, 0);
+                const char* S = smem + (gc & 1) * STAGE;
+                gm_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
+#define PF_PROD(PA, PB)                                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+                PF_PROD(2, 0) PF_PROD(0, 2) PF_PROD(1, 1) PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)
+#undef PF_PROD
+                PF_T(gc, 2);
+                GS_BARRIER();
+                PF_T(gc, 3);
+            }
+            // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
+            const int lt = logical(b + ti * G);
+            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];       // scalar (SMEM) loads: lgkmcnt, not vmcnt
+            const float* sc_t = scales + (ti & 1) * GS_BM;
+            const int col = wc * 64 + ec;
+            const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int rl = wr * 64 + i * 32 + it * 4 + er;
+                    if (rl >= nrows) continue;
+                    const int64_t row = row0 + rl;
+                    const float sc = sc_t[rl];
+                    float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+                    v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+                    if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                    if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+#ifdef PF_EXP_NOSTORE
+                    if (v.x != 123.456f) continue;
+#endif
+                    if (g.nt_store) {
+                        typedef float f4v __attribute__((ext_vector_type(4)));
+                        f4v vv = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+                    } else {
+                        *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         }
     }
 }

@@ -211,12 +211,18 @@ struct gm_gemm_args {
     const float* mask_h;                // optional [rows, ldc]: zero C where mask_h <= 0 (relu')
     const uint8_t* mask_b;              // same mask packed, byte (row*ldc + col)/4 = bits of 4 consecutive columns (needs vector stores)
     uint8_t* relu_bits;                 // optional output: packed relu' bits of C (with relu; N % 4 == 0, ldc == N)
+    const uint16_t* Bsplit; int64_t bsplit_stride;   // optional: B_t as three bf16 planes (gm_split_weights) -> the split-bf16 kernel (gemm_split.h)
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
     int64_t rows;                       // total rows covered by the tiles (profiling: flops = 2*rows*K*N)
 };
 #define GM_GEMM_BM 128
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
+// fp32 GEMM on the bf16 matrix cores by exact 3-way operand splitting (gemm_split.h): eligibility of a launch and the weight planes.
+// gm_gemm_mode(): 0 = exact-fp32 MFMA kernels only, 1 = split-bf16 kernel where eligible (env GM_GEMM_MODE=f32|split, gm_set_gemm_mode).
+int gm_gemm_mode();
+bool gm_gemm_split_ok(int n_tiles, int K, int N);
+int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s);
 
 // Grouped transposed-A GEMM for weight gradients:
 //   dW_t[K,N] = sum_{rows of set t} a_scale[row] * A[row,:]^T  G[row,:]   and   db_t[N] = sum G[row,:]

@@ -335,6 +335,7 @@ struct Carver {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    uint16_t* Wsplit;            // per-task weights of the GEMM being launched as three bf16 planes (split-bf16 kernel, gemm_split.h)
     float* WTl[GM_MAX_GCN];      // per-task transposed weights of layer l >= 1, [set][fo][fi]: B of the dZ GEMM (dense backward)
     const float* wt_of[GM_MAX_GCN]; int64_t wt_stride[GM_MAX_GCN];      // the parameter vector (pointer, per-set stride) WTl[l] is the transpose of
     uint8_t* M[GM_MAX_GCN];      // packed relu' bits of H[l] (one byte per 4 columns): what the backward reads instead of H[l] (dense schedule)
@@ -386,6 +387,7 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
     c.bufB = cv.take<float>(rows * maxd);
     c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
     for (int l = 1; l < L.n_gcn; ++l) c.WTl[l] = cv.take<float>((int64_t)c.b->sets * L.dims[l] * L.dims[l + 1]);
+    c.Wsplit = cv.take<uint16_t>((int64_t)c.b->sets * 3 * maxd * maxd);
     c.cG2 = cv.take<float>((int64_t)c.b->n_c * maxd); c.cT2 = cv.take<float>((int64_t)c.b->n_c * maxd);
     c.cG1 = cv.take<float>((int64_t)c.b->n_e1 * maxd);
     c.partial_c = cv.take<float>((int64_t)std::max(c.b->n_c_chunks, c.b->n_e1_chunks) * maxkn);
@@ -453,6 +455,10 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             g.relu_bits = c.M[l];
+            if (c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0) {
+                GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st));
+                g.Bsplit = c.Wsplit; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+            }
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
         xin = c.H[l];
@@ -514,8 +520,14 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
                 static int dz_glds = -1;
                 if (dz_glds < 0) { const char* e = getenv("GM_DZ_GLDS"); dz_glds = e ? atoi(e) : 1; }
-                const bool use_wt = dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
-                if (use_wt) {
+                const bool use_split = c.Wsplit && gm_gemm_split_ok(b->n_tiles, fo, fi);
+                const bool use_wt = !use_split && dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
+                if (use_split) {
+                    // B = W^T with W stored [fi][fo]: the planes are W's own rows (no transpose), K = fo, N = fi
+                    GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fo, fi, 1, pstride ? b->sets : 1, c.Wsplit, st));
+                    g.Bsplit = c.Wsplit; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+                    g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1;
+                } else if (use_wt) {
                     // dZ = dQ @ W^T through the direct-to-LDS kernel on transposed weights: left there by the previous step's
                     // weight-gradient reduction (which wrote these very weights), else transposed now (T x 256 KB)
                     if (!(c.wt_of[l] == params && c.wt_stride[l] == pstride)) {
@@ -1117,4 +1129,28 @@ extern "C" int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* g
     hipLaunchKernelGGL(k_meta_finish, dim3((int)std::min<int64_t>(512, (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head, P, K1, grad, found_inf);
     GM_HIP(hipGetLastError());
     return GM_OK;
+}
+
+// ================================================================================ dense update, exported for numerics tests
+extern "C" int gm_dense_update(const gm_batch_t* b, const float* x, int32_t K, const float* W, int64_t w_stride, int32_t N, float* out, int32_t mode,
+                               void* stream) {
+    GM_REQUIRE(b && x && W && out && K >= 1 && N >= 1, GM_EINVAL, "dense_update: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    gm_gemm_args g{};
+    g.A = x; g.lda = K; g.B = W; g.b_stride = w_stride; g.C = out; g.ldc = N; g.K = K; g.N = N;
+    g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
+    uint16_t* planes = nullptr;
+    const bool split = mode == 1 || (mode < 0 && gm_gemm_split_ok(b->n_tiles, K, N));
+    if (split) {
+        GM_REQUIRE(N == 256 && K % 16 == 0 && K >= 32, GM_EINVAL, "dense_update: the split-bf16 kernel needs N = 256 and K a multiple of 16 (>= 32)");
+        const int sets = w_stride ? b->sets : 1;
+        GM_TRY(gm_alloc(&planes, (size_t)sets * 3 * K * N, st));
+        int rc = gm_split_weights(W, w_stride, 0, K, N, 0, sets, planes, st);
+        if (rc != GM_OK) { gm_dev_free(planes, st); return rc; }
+        g.Bsplit = planes; g.bsplit_stride = w_stride ? (int64_t)3 * K * N : 0;
+    }
+    const int rc = gm_launch_gemm_nn(g, st);
+    if (planes) gm_dev_free(planes, st);
+    gm_batch_mark_use(b, st);
+    return rc;
 }

@@ -159,6 +159,12 @@ int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* param
                     const float* x0, const int32_t* centre_local, const float* dlogits, float* dparams,
                     int64_t dparam_stride, void* ws, int64_t ws_bytes, void* stream);
 
+/* torch.matmul(feat, weight) of GraphConv.forward (learner.py:36,47) over the rows of a batch: out[rows, N] = x[rows, K] @ W_t with
+ * W_t = W + set * w_stride ([K, N] row-major; w_stride = 0: one matrix for every set).  Exported for numerics tests of the GEMM kernels.
+ * mode -1: what the library would pick (gm_set_gemm_mode + launch size), 0: exact-fp32 MFMA kernels, 1: split-bf16 kernel (N = 256). */
+int gm_dense_update(const gm_batch_t* b, const float* x, int32_t K, const float* W, int64_t w_stride, int32_t N, float* out, int32_t mode,
+                    void* stream);
+
 /* ---- Prototypical losses (meta.py:28-54 proto_loss_spt, 56-79 proto_loss_qry), per set.
  * y: HOST int32 [subs] labels.  Outputs (device): loss[sets], acc[sets], protos[sets, c_task, n_out]
  * (c_task = the LARGEST number of classes of any set; every set keeps its own class layout -- classes, rows per class --
@@ -193,6 +199,13 @@ int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_
  * found_inf: device fp32 [1] <- 1.0 if losses_q[K] / task count is NaN else 0.0 (a fused Adam skips its step on 1.0, which
  * is the reference's `if torch.isnan(loss_q): pass`).  K1 = update_step + 1. */
 int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream);
+
+/* Update-GEMM arithmetic.  mode 0: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere.  mode 1 (default): large N = 256 launches run
+ * on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 pieces and the six products of weight >= 2^-16
+ * accumulated in fp32 (dropped terms <= 1.2e-7 |a||b|: the result is within one fp32 rounding per product of the exact one;
+ * measured error against fp64 <= the fmaf chain's).  Also settable with the environment variable GM_GEMM_MODE=f32|split. */
+void gm_set_gemm_mode(int32_t mode);
+int32_t gm_get_gemm_mode(void);
 
 /* Profiling aid for bench.py: HIP-event time (ms) of the aggregate launches of the last
  * gm_meta_step on this thread, their count and their summed algorithmic bytes.  Events are only

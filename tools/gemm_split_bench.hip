@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
+#define GS_EXPERIMENTS
 #include "../g-meta_amd/csrc/gemm_split.h"
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
@@ -35,9 +36,10 @@ int main(int argc, char** argv) {
     SplitGemmK g{};
     g.A = dA; g.lda = K; g.Bt = dBt; g.bt_stride = 0; g.C = dC; g.ldc = N; g.K = K; g.N = N; g.bias = dBias; g.relu = 0;
     unsigned long long* dDbg; CK(hipMalloc(&dDbg, 3 * 64 * 4 * 8)); CK(hipMemset(dDbg, 0, 3 * 64 * 4 * 8)); g.dbg = dDbg;
-    g.tiles = dT; g.n_tiles = (int)tiles.size() / 3; g.n_col_tiles = N / (64 * WC); g.nt_store = 1;
-    const bool fc = argc > 6 && atoi(argv[6]) == 1;
+    g.tiles = dT; g.n_tiles = (int)tiles.size() / 3; g.n_col_tiles = N / (64 * WC); g.nt_store = getenv("GS_NT") ? atoi(getenv("GS_NT")) : 1;
+    const bool fc = argc > 6 && atoi(argv[6]) == 1, pers = argc > 6 && atoi(argv[6]) == 2;
     auto launch = [&]() {
+        if (pers) { hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(g.n_tiles, 256)), dim3(1024), 0, 0, g); return; }
         if (fc) { hipLaunchKernelGGL(k_gemm_split_fc, dim3(g.n_tiles * g.n_col_tiles), dim3(640 + 64 * FC_NB), 0, 0, g); return; }
         if (BK == 32) { printf("BK=32 removed\n"); exit(1); }
         else { if (WC == 4) run<4, 16>(g, 0); else if (WC == 2) run<2, 16>(g, 0); else run<1, 16>(g, 0); }
@@ -53,7 +55,7 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * M * K * N;
     printf("split-bf16 GEMM: %.3f ms  %.1f TFLOP/s (fp32-equivalent)  %.1f TFLOP/s of bf16 MFMA work  %.2f TB/s of A+C traffic\n", ms, fl / ms / 1e9,
            6 * fl / ms / 1e9, ((double)M * K * 4 + (double)M * N * 4) / ms / 1e9);
-#ifdef FC_TRACE
+#if defined(FC_TRACE) || defined(PF_TRACE)
     {
         std::vector<unsigned long long> d(3 * 64 * 4);
         CK(hipMemcpy(d.data(), dDbg, d.size() * 8, hipMemcpyDeviceToHost));
@@ -61,7 +63,7 @@ int main(int argc, char** argv) {
         const unsigned long long t0 = d[0];
         for (int r = 0; r < 3; ++r) {
             printf("%s (ticks since compute chunk 0 start; s_memtime ticks = 100 MHz?)\n", names[r]);
-            for (int c = 0; c < K / 32; ++c) printf("  c%d: start %lld  issued %lld  ready %lld  after-barrier %lld\n", c, (long long)(d[(r * 64 + c) * 4] - t0), (long long)(d[(r * 64 + c) * 4 + 1] - t0), (long long)(d[(r * 64 + c) * 4 + 2] - t0), (long long)(d[(r * 64 + c) * 4 + 3] - t0));
+            for (int c = 0; c < 40; ++c) printf("  c%d: start %lld  issued %lld  ready %lld  after-barrier %lld\n", c, (long long)(d[(r * 64 + c) * 4] - t0), (long long)(d[(r * 64 + c) * 4 + 1] - t0), (long long)(d[(r * 64 + c) * 4 + 2] - t0), (long long)(d[(r * 64 + c) * 4 + 3] - t0));
         }
     }
 #endif
