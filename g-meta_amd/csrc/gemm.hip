@@ -473,7 +473,9 @@ extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode = mode ? 1 : 0; }
 extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
 // The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
 bool gm_gemm_split_ok(int n_tiles, int K, int N) {
-    return gm_gemm_mode() == 1 && N == 256 && K % 16 == 0 && K >= 32 && n_tiles >= gm_num_cus();
+    static int min_tiles = -1;        // default: from a quarter of the CUs busy upwards (measured on the 141-tile support batch of a 4-task shard: still ahead of the fp32 small-tile kernel)
+    if (min_tiles < 0) { const char* e = getenv("GM_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atoi(e) : gm_num_cus() / 4; }
+    return gm_gemm_mode() == 1 && N == 256 && K % 16 == 0 && K >= 32 && n_tiles >= min_tiles;
 }
 int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, sets), dim3(256), 0, s, params, pstride, w_off, K, N, trans, out);
