@@ -578,7 +578,8 @@ struct WgradK {
 #define WG_PF 2     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 2 * 1024 * 4 floats per stage
 
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(WgradK w) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+    extern __shared__ __attribute__((aligned(16))) float sm_f[];
+    float* sm = sm_f;
     // One LDS matrix S[RK][ld]: columns [0, ldA) hold norm-scaled A rows (zero padded to 32), [ldA, ld) hold G rows.
     const int ldA = w.TK * 32, ldG = w.TN * 32, ld = ldA + ldG, ld4 = ld >> 2, ldA4 = ldA >> 2;
     const int chunk = blockIdx.x, zt = blockIdx.y;     // zt: group of 64 output tiles
@@ -824,6 +825,134 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
     return GM_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores (same exact 3-way operand split as gemm_split.h; K, N in {128, 256}).
+// The MFMA k dimension is the ROW index, so an operand lane needs 8 consecutive rows of one column: the staged planes are
+// [row octet][column][8 rows] bf16 -- a fragment read is a contiguous ds_read_b128 run (conflict-free) and a thread that loads
+// one column of 8 rows (8 dword loads, lanes on consecutive columns: 256-B coalesced rows) writes one 16-byte unit per plane.
+// Stage = 16 rows (one MFMA k step): 2 octets x (K + N) columns = 1024 or 768 (octet, column) items over 1024 threads;
+// loads of stage s+1 fly under the MFMAs of stage s, split + LDS store follow (double-buffered planes, one barrier per stage).
+// 16 waves in a 4 x 4 grid, wave (wy, wx) owns tiles tk in [wy*NTK, +NTK) x tn in [wx*NTN, +NTN).  db = column sums of G from
+// the loader registers.  Output: the same per-chunk partial [(K+1) x N] as k_wgrad_fast (reduced by k_wgrad_reduce).
+template <int NTK, int NTN>
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_split(WgradK w) {
+    constexpr int K = NTK * 128, N = NTN * 128, COLS = K + N;
+    constexpr int A_PLANE = 2 * K * 16, G_PLANE = 2 * N * 16;                       // bytes: [2 octets][cols][8 rows] bf16
+    constexpr int STAGE = 3 * A_PLANE + 3 * G_PLANE;                                // 96 * (K + N) bytes: 48 KiB at 256 + 256
+    constexpr int ITEMS = 2 * COLS, IPT = (ITEMS + WG_THREADS - 1) / WG_THREADS;    // (octet, column) items per thread: 1
+    static_assert(IPT == 1, "one (octet, column) item per thread");
+    extern __shared__ __attribute__((aligned(16))) float sm_f[];
+    char* sm = reinterpret_cast<char*>(sm_f);
+    const int chunk = blockIdx.x;
+    const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
+    const int wy = wave >> 2, wx = wave & 3;
+    gm_f32x16 acc[NTK][NTN];
+#pragma unroll
+    for (int a = 0; a < NTK; ++a)
+#pragma unroll
+        for (int b = 0; b < NTN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    // ---- loader item of this thread: octet `oct` of the stage, column `col` of [A | G]
+    const bool active = tid < ITEMS;
+    const int oct = tid / COLS, col = tid - oct * COLS;
+    const bool isA = col < K;
+    const float* src = isA ? w.A + col : w.G + (col - K);
+    const int64_t ld = isA ? w.lda : w.ldg;
+    const int dst = (isA ? 0 : 3 * A_PLANE) + oct * (isA ? K : N) * 16 + (isA ? col : col - K) * 16;
+    const int plane = isA ? A_PLANE : G_PLANE;
+    float pf[8], ps[8];
+    float bsum = 0.f;
+    const bool scaled = isA && w.a_scale;
+    auto load_stage = [&](int r0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = min(r0 + oct * 8 + j, nrows - 1);                         // clamped; validity applied at split time
+            pf[j] = active ? src[(int64_t)(row0 + r) * ld] : 0.f;
+            ps[j] = scaled ? w.a_scale[row0 + r] : 1.f;                             // prefetched with the data (wave-uniform address)
+        }
+    };
+    auto store_stage = [&](int r0, char* S) {
+        if (!active) return;
+        uint32_t h[8], m[8], l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = r0 + oct * 8 + j;
+            float x = r < nrows ? pf[j] * ps[j] : 0.f;                              // rows past the chunk end contribute zeros
+            if (!isA) bsum += x;
+            const uint32_t bx = __float_as_uint(x);
+            h[j] = bx & 0xffff0000u;
+            const float r1 = x - __uint_as_float(h[j]);
+            m[j] = __float_as_uint(r1) & 0xffff0000u;
+            l[j] = __float_as_uint(r1 - __uint_as_float(m[j]));
+        }
+        uint4 vh, vm, vl;
+        vh.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); vh.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
+        vh.z = __builtin_amdgcn_perm(h[5], h[4], 0x07060302u); vh.w = __builtin_amdgcn_perm(h[7], h[6], 0x07060302u);
+        vm.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); vm.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+        vm.z = __builtin_amdgcn_perm(m[5], m[4], 0x07060302u); vm.w = __builtin_amdgcn_perm(m[7], m[6], 0x07060302u);
+        vl.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); vl.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+        vl.z = __builtin_amdgcn_perm(l[5], l[4], 0x07060302u); vl.w = __builtin_amdgcn_perm(l[7], l[6], 0x07060302u);
+        *reinterpret_cast<uint4*>(S + dst) = vh;
+        *reinterpret_cast<uint4*>(S + dst + plane) = vm;
+        *reinterpret_cast<uint4*>(S + dst + 2 * plane) = vl;
+    };
+    const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = 3 * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
+    load_stage(0);
+    store_stage(0, sm);
+    __syncthreads();
+    int cur = 0;
+    for (int r0 = 0; r0 < nrows; r0 += 16, cur ^= 1) {
+        const bool more = r0 + 16 < nrows;
+        const char* S = sm + cur * STAGE;
+        if (more) load_stage(r0 + 16);
+#pragma unroll
+        for (int a = 0; a < NTK; ++a) {
+            gm_bf16x8 af[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + a * 512);
+#pragma unroll
+            for (int b = 0; b < NTN; ++b) {
+                gm_bf16x8 gf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>(S + g_lane + p * G_PLANE + b * 512);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], gf[0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[2], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[0], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[1], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[0], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (more) store_stage(r0 + 16, sm + (cur ^ 1) * STAGE);        // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+    float* out = w.partial + (int64_t)chunk * (K + 1) * N;
+#pragma unroll
+    for (int a = 0; a < NTK; ++a)
+#pragma unroll
+        for (int b = 0; b < NTN; ++b) {
+            const int tk = wy * NTK + a, tn = wx * NTN + b;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * N + tn * 32 + li] = acc[a][b][e];
+        }
+    // db: the two octet threads of a G column add up through LDS (fixed order)
+    float* red = reinterpret_cast<float*>(sm);
+    if (active && !isA) red[oct * N + (col - K)] = bsum;
+    __syncthreads();
+    if (tid < N) out[(int64_t)K * N + tid] = red[tid] + red[N + tid];
+}
+
+template <int NTK, int NTN>
+static int launch_wgrad_split(const WgradK& w, hipStream_t s) {
+    constexpr int K = NTK * 128, N = NTN * 128;
+    const size_t lds = 2 * 96 * (size_t)(K + N);
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<NTK, NTN>));
+    hipLaunchKernelGGL((k_wgrad_split<NTK, NTN>), dim3(w.n_chunks), dim3(WG_THREADS), lds, s, w);
+    return GM_OK;
+}
+
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
 struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; };
 
@@ -878,6 +1007,16 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     bool launched = false;
     const bool fast_ok = (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
                          (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
+    static int wsplit = -1;
+    if (wsplit < 0) { const char* e = getenv("GM_WGRAD_SPLIT"); wsplit = e ? atoi(e) : 1; }
+    if (fast_ok && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= gm_num_cus() / 4 && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256)) {
+        // exact 3-way bf16 split of both operands, fp32 accumulation (see k_wgrad_split): the same arithmetic as the split GEMM
+        if (a.K == 256 && a.N == 256) GM_TRY((launch_wgrad_split<2, 2>(w, s)));
+        else if (a.K == 128 && a.N == 256) GM_TRY((launch_wgrad_split<1, 2>(w, s)));
+        else if (a.K == 256 && a.N == 128) GM_TRY((launch_wgrad_split<2, 1>(w, s)));
+        else GM_TRY((launch_wgrad_split<1, 1>(w, s)));
+        launched = true;
+    }
     if (fast_ok && !launched) {
 #define GM_WG_CASE(TK_, TN_) if (!launched && w.TK == TK_ && w.TN == TN_) { GM_TRY((launch_wgrad_fast<TK_, TN_>(w, s))); launched = true; }
         GM_WG_CASE(8, 8) GM_WG_CASE(4, 8) GM_WG_CASE(8, 4) GM_WG_CASE(4, 4) GM_WG_CASE(2, 4) GM_WG_CASE(4, 2) GM_WG_CASE(2, 2)
