@@ -229,7 +229,10 @@ def main():
     for k in range(a.warmup):
         step(k)
     drain()
-    lib.gm_profile_enable(1)           # HIP events around every aggregate launch, recorded on the stream it is launched on
+    # Per-launch HIP events (roofline / MFMA utilisation) cost a few microseconds per launch, which is noise at the arxiv shape but
+    # 30-50 % on the launch-latency-bound configs: the timed region runs WITHOUT them unless it is itself the roofline sample
+    # (--serialize 1); otherwise they are switched on for the extra steps right after it.
+    lib.gm_profile_enable(1 if a.serialize else 0)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -239,8 +242,8 @@ def main():
     strict_bytes = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
-        if a.defer:
-            continue                   # per-launch events are read in the serialised roofline steps below
+        if a.defer or not a.serialize:
+            continue                   # per-launch events are read in the extra steps below
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
         strict_bytes += prof_read(3)[2]
@@ -265,6 +268,9 @@ def main():
     mm = ov_mm if a.serialize else {1: [0.0, 0, 0], 2: [0.0, 0, 0]}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
+        lib.gm_profile_enable(1)
+        step(0); drain()                                    # one two-stream step with events: the aggregate's rate while it shares the GPU
+        ov_ms, ov_n, ov_bytes = prof_read()
         maml.serialize = 1
         step(0); drain()
         agg_ms, agg_n, agg_bytes, strict_bytes = 0.0, 0, 0, 0
