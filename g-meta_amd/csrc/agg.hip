@@ -20,6 +20,10 @@ struct AggK {
     const int32_t* sched; int sched_len;      // optional block schedule: entry >= 0 window block, <= -2 hub row, -1 nothing
     int nt;                    // 1: non-temporal output stores (Z is not re-read by this kernel; keep L2 for the X gathers)
     int win;                   // rows per wave window (64 for big batches; smaller when the batch would underfill the chip)
+    // hub rows split over several blocks (gm_agg_schedule): hub = [part_off: n_heavy+1][part_hub: parts][arrival counters: n_heavy],
+    // part g of the schedule covers edges [hub_part * p, hub_part * (p+1)) of its row; the last block to arrive sums the partial rows
+    // (hub_scratch, [parts][hub_ld]) in part order -- deterministic -- and runs the epilogue.  hub == NULL: one block per hub row.
+    const int32_t* hub; float* hub_scratch; int hub_part, hub_ld;
 };
 
 template <int VEC> struct VecT;
@@ -102,24 +106,29 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
 // partial rows are summed through LDS in a fixed order (deterministic), then the usual epilogue.
 #define AGG_HEAVY_BLOCK 1024
 template <int LPR, int NCH, int NTHREADS>
-__device__ __forceinline__ void agg_heavy_row(const AggK& a, const int row, float* part) {
+__device__ __forceinline__ void agg_heavy_row(const AggK& a, const int g, float* part) {
     constexpr int NG = NTHREADS / LPR;
+    constexpr int PS = 16;                                 // edges per group visit (<= LPR): two batches of 8 row loads
     const int tid = threadIdx.x, gi = tid / LPR, l = tid % LPR, lane = tid & 63;
     const int gbase = (lane / LPR) * LPR;                 // first lane of this group inside its wave
-    const int e0 = a.indptr[row], e1 = a.indptr[row + 1];
+    int h = g, p = 0, P = 1;
+    if (a.hub) { h = a.hub[a.n_heavy + 1 + g]; p = g - a.hub[h]; P = a.hub[h + 1] - a.hub[h]; }
+    const int row = a.heavy[h];
+    int e0 = a.indptr[row], e1 = a.indptr[row + 1];
+    if (P > 1) { e0 += p * a.hub_part; e1 = min(e1, e0 + a.hub_part); }
     const float* xl = a.x + l * 4;
     float4 acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int eb = e0 + gi * LPR; eb < e1; eb += NG * LPR) {
+    for (int eb = e0 + gi * PS; eb < e1; eb += NG * PS) {
         int mu = 0; float mw = 0.f;
-        if (eb + l < e1) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
-        const int cnt = min(LPR, e1 - eb);
+        if (l < PS && eb + l < e1) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
+        const int cnt = min(PS, e1 - eb);
         for (int j = 0; j < cnt; j += 8) {
             float4 v[8][NCH]; float ww[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int sl = gbase + ((j + i) & (LPR - 1));
+                const int sl = gbase + j + i;
                 const int uu = __shfl(mu, sl, 64);
                 ww[i] = (j + i < cnt) ? __shfl(mw, sl, 64) : 0.f;
 #pragma unroll
@@ -134,6 +143,51 @@ __device__ __forceinline__ void agg_heavy_row(const AggK& a, const int row, floa
 #pragma unroll
     for (int c = 0; c < NCH; ++c) *reinterpret_cast<float4*>(&part[(gi * NCH + c) * LPR * 4 + l * 4]) = acc[c];
     __syncthreads();
+    float4 s4[NCH];
+    if (gi == 0) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            s4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < NG; ++k) { const float4 t = *reinterpret_cast<const float4*>(&part[(k * NCH + c) * LPR * 4 + l * 4]); s4[c].x += t.x; s4[c].y += t.y; s4[c].z += t.z; s4[c].w += t.w; }
+        }
+    }
+    if (P > 1) {
+        // Partial row -> scratch with write-through (sc1) 16-byte stores, drained by every wave; one relaxed agent-scope ticket;
+        // only the last block to arrive goes on: one lane's agent-scope acquire, then plain loads of the P partial rows, summed
+        // in part order.  Correct wherever the parts run (the schedule keeps them on one XCD only because that is faster).
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        if (gi == 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                float* dst = a.hub_scratch + (int64_t)g * a.hub_ld + l * 4 + c * LPR * 4;
+                const f4v val = {s4[c].x, s4[c].y, s4[c].z, s4[c].w};
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // also: every read of `part` above is done
+        int* ctr = const_cast<int*>(a.hub) + a.n_heavy + 1 + a.hub[a.n_heavy] + h;
+        int* flag = reinterpret_cast<int*>(part);
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == P - 1) {
+                __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            *flag = (old == P - 1);
+        }
+        __syncthreads();
+        if (!*flag || gi != 0) return;
+        const float* sc = a.hub_scratch + (int64_t)a.hub[h] * a.hub_ld + l * 4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            s4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < P; ++k) {
+                const float4 t = *reinterpret_cast<const float4*>(sc + (int64_t)k * a.hub_ld + c * LPR * 4);
+                s4[c].x += t.x; s4[c].y += t.y; s4[c].z += t.z; s4[c].w += t.w;
+            }
+        }
+    }
     if (gi != 0) return;
     const float so = a.s_out ? a.s_out[row] : 1.f;
     const float* bp = nullptr;
@@ -148,9 +202,7 @@ __device__ __forceinline__ void agg_heavy_row(const AggK& a, const int row, floa
     }
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < NG; ++k) { const float4 t = *reinterpret_cast<const float4*>(&part[(k * NCH + c) * LPR * 4 + l * 4]); s4.x += t.x; s4.y += t.y; s4.z += t.z; s4.w += t.w; }
-        float4 v = make_float4(s4.x * so, s4.y * so, s4.z * so, s4.w * so);
+        float4 v = make_float4(s4[c].x * so, s4[c].y * so, s4[c].z * so, s4[c].w * so);
         if (bp) { const float4 bb = *reinterpret_cast<const float4*>(bp + c * LPR * 4); v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w; }
         if (a.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
         if (a.mask_b) {
@@ -167,7 +219,7 @@ __device__ __forceinline__ void agg_heavy_row(const AggK& a, const int row, floa
 template <int LPR, int NCH>
 __global__ __launch_bounds__(AGG_HEAVY_BLOCK) void k_agg_heavy(AggK a) {
     __shared__ __attribute__((aligned(16))) float part[(AGG_HEAVY_BLOCK / LPR) * LPR * 4 * NCH];
-    agg_heavy_row<LPR, NCH, AGG_HEAVY_BLOCK>(a, a.heavy[blockIdx.x], part);
+    agg_heavy_row<LPR, NCH, AGG_HEAVY_BLOCK>(a, blockIdx.x, part);
 }
 
 // Wave-cooperative kernel (the production path for widths 64/128/256/512).  Induced subgraphs are very sparse
@@ -192,7 +244,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
         if (e == -1) return;
         if (e < -1) {
             __shared__ __attribute__((aligned(16))) float part[AGG_BLOCK * 4 * NCH];
-            agg_heavy_row<LPR, NCH, AGG_BLOCK>(a, a.heavy[-e - 2], part);
+            agg_heavy_row<LPR, NCH, AGG_BLOCK>(a, -e - 2, part);
             return;
         }
         lb = e;
@@ -307,11 +359,28 @@ int gm_agg_window(int64_t rows) {
     return win;
 }
 
-int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heavy, int32_t** d_sched, int32_t* len_out, hipStream_t s) {
-    *d_sched = nullptr; *len_out = 0;
-    static int on = -1;
+int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s) {
+    *out = gm_agg_sched{};
+    static int on = -1, part_env = -1;
     if (on < 0) { const char* e = getenv("GM_AGG_SCHED"); on = e ? atoi(e) : 1; }
+    if (part_env < 0) { const char* e = getenv("GM_AGG_HUB_PART"); part_env = e ? atoi(e) : 128; }      // 0: one block per hub row
     if (!on || n_heavy <= 0 || rows <= 0) return GM_OK;                  // no hub rows: the plain window launch
+    // edges per hub part: a multiple of 16, at most 32 parts for the widest row
+    int hub_part = 0;
+    std::vector<int32_t> tab;                                           // [part_off: n_heavy+1][part_hub: parts][counters: n_heavy]
+    if (part_env > 0 && heavy_deg_host) {
+        int maxdeg = 0;
+        for (int k = 0; k < n_heavy; ++k) maxdeg = std::max(maxdeg, heavy_deg_host[k]);
+        hub_part = std::max((part_env + 15) / 16 * 16, ((maxdeg + 31) / 32 + 15) / 16 * 16);
+        tab.assign(n_heavy + 1, 0);
+        for (int k = 0; k < n_heavy; ++k) tab[k + 1] = tab[k] + std::max(1, (heavy_deg_host[k] + hub_part - 1) / hub_part);
+        const int parts = tab[n_heavy];
+        if (parts == n_heavy) { hub_part = 0; tab.clear(); }             // nothing to split
+        else {
+            tab.resize(n_heavy + 1 + parts + n_heavy, 0);
+            for (int k = 0; k < n_heavy; ++k) for (int g = tab[k]; g < tab[k + 1]; ++g) tab[n_heavy + 1 + g] = k;
+        }
+    }
     const int RPB = win * (AGG_BLOCK / GM_WAVE);
     const int nwb = (int)((rows + RPB - 1) / RPB);
     const int q = nwb / GM_NXCD, r = nwb % GM_NXCD;
@@ -322,7 +391,11 @@ int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heav
         lists[x].reserve(cnt + 8);
         for (int wb = start; wb < start + cnt; ++wb) {
             lists[x].push_back(wb);
-            while (hk < n_heavy && heavy_host[hk] / RPB == wb) { lists[x].push_back(-(hk) - 2); ++hk; }     // heavy_host is ascending
+            while (hk < n_heavy && heavy_host[hk] / RPB == wb) {        // heavy_host is ascending
+                if (hub_part) for (int g = tab[hk]; g < tab[hk + 1]; ++g) lists[x].push_back(-g - 2);
+                else lists[x].push_back(-hk - 2);
+                ++hk;
+            }
         }
     }
     GM_REQUIRE(hk == n_heavy, GM_EINVAL, "aggregate schedule: hub-row list is not ascending / out of range");
@@ -330,10 +403,16 @@ int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heav
     for (auto& l : lists) len = std::max(len, l.size());
     std::vector<int32_t> flat(GM_NXCD * len, -1);
     for (int x = 0; x < GM_NXCD; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * len);
-    GM_TRY(gm_alloc(d_sched, flat.size(), s));
-    GM_HIP(hipMemcpyAsync(*d_sched, flat.data(), 4 * flat.size(), hipMemcpyHostToDevice, s));
-    GM_HIP(hipStreamSynchronize(s));            // `flat` is pageable and goes out of scope
-    *len_out = (int32_t)len;
+    GM_TRY(gm_alloc(&out->d_sched, flat.size(), s));
+    GM_HIP(hipMemcpyAsync(out->d_sched, flat.data(), 4 * flat.size(), hipMemcpyHostToDevice, s));
+    if (hub_part) {
+        GM_TRY(gm_alloc(&out->d_hub, tab.size(), s));
+        GM_HIP(hipMemcpyAsync(out->d_hub, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
+        GM_TRY(gm_alloc(&out->d_hub_scratch, (size_t)tab[n_heavy] * GM_AGG_HUB_LD, s));
+        out->hub_part = hub_part;
+    }
+    GM_HIP(hipStreamSynchronize(s));            // the host vectors are pageable and go out of scope
+    out->len = (int32_t)len;
     return GM_OK;
 }
 
@@ -381,13 +460,14 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
            g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
-           g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64};
+           g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64,
+           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
     GM_REQUIRE(!(g.mask_b || g.relu_bits) || vec4, GM_EINVAL, "aggregate: packed relu masks need width %% 4 == 0 and 16-byte aligned operands");
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
-    if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; }      // the generic kernel walks every row itself
+    if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; a.hub = nullptr; }      // the generic kernel walks every row itself
     if (win) {
         if (g.width == 64) launch_win<16, 1>(a, s);
         else if (g.width == 128) launch_win<32, 1>(a, s);
@@ -432,7 +512,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.x_row = gather ? b->d_feat_row : nullptr;
     a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
-    a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win;
+    a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, transposed ? 1 : 0);
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

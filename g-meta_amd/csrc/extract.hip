@@ -317,7 +317,8 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
 // rows whose degree exceeds gm_heavy_deg() (hubs inside their own neighbourhood): appended to a list, sorted on the host
 __global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list, int32_t* count, int cap, int thr) {
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        if (indptr[r + 1] - indptr[r] > thr) { const int k = atomicAdd(count, 1); if (k < cap) list[k] = (int32_t)r; }
+        const int d = indptr[r + 1] - indptr[r];
+        if (d > thr) { const int k = atomicAdd(count, 1); if (k < cap) { list[k] = (int32_t)r; list[cap + k] = d; } }      // [rows: cap][degrees: cap]
     }
 }
 // centre rows, their norms and in-degrees (row-sparse backward tables)
@@ -364,6 +365,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
     gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
+    gm_dev_free(b->d_hub[0], s); gm_dev_free(b->d_hub[1], s); gm_dev_free(b->d_hub_scratch[0], s); gm_dev_free(b->d_hub_scratch[1], s);
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
     gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
     gm_dev_free(b->d_e1_chunks, s); gm_dev_free(b->d_e1_set_chunk_off, s);
@@ -400,7 +402,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     GM_TRY(gm_alloc(&d_cnt, 2, s));
     GM_HIP(hipMemsetAsync(d_cnt, 0, 8, s));
     for (int o = 0; o < 2; ++o) {
-        GM_TRY(gm_alloc(&b->d_heavy[o], cap, s));
+        GM_TRY(gm_alloc(&b->d_heavy[o], 2 * (size_t)cap, s));
         const int blocks = (int)std::min<int64_t>(2048, (b->rows + 255) / 256);
         hipLaunchKernelGGL(k_find_heavy, dim3(blocks), dim3(256), 0, s, o ? b->d_indptr_t : b->d_indptr, b->rows, b->d_heavy[o], d_cnt + o, cap, b->heavy_deg);
     }
@@ -412,14 +414,21 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     for (int o = 0; o < 2; ++o) {
         b->n_heavy[o] = std::min(cnt[o], cap);
         if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
-            std::vector<int32_t> h(b->n_heavy[o]);
+            const size_t nh = b->n_heavy[o];
+            std::vector<int32_t> h(nh), hd(nh);
             // stream-ordered copies + a wait on THIS stream only: a plain hipMemcpy is a null-stream operation and would
             // serialise the prefetch thread's batch build with whatever the training thread has queued on the default stream
-            GM_HIP(hipMemcpyAsync(h.data(), b->d_heavy[o], 4 * h.size(), hipMemcpyDeviceToHost, s));
+            GM_HIP(hipMemcpyAsync(h.data(), b->d_heavy[o], 4 * nh, hipMemcpyDeviceToHost, s));
+            GM_HIP(hipMemcpyAsync(hd.data(), b->d_heavy[o] + cap, 4 * nh, hipMemcpyDeviceToHost, s));
             GM_HIP(hipStreamSynchronize(s));
-            std::sort(h.begin(), h.end());
-            if (h.size() > 1) { GM_HIP(hipMemcpyAsync(b->d_heavy[o], h.data(), 4 * h.size(), hipMemcpyHostToDevice, s)); GM_HIP(hipStreamSynchronize(s)); }
-            GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), b->n_heavy[o], &b->d_sched[o], &b->sched_len[o], s));
+            std::vector<std::pair<int32_t, int32_t>> pr(nh);
+            for (size_t k = 0; k < nh; ++k) pr[k] = {h[k], hd[k]};
+            std::sort(pr.begin(), pr.end());
+            for (size_t k = 0; k < nh; ++k) { h[k] = pr[k].first; hd[k] = pr[k].second; }
+            if (nh > 1) { GM_HIP(hipMemcpyAsync(b->d_heavy[o], h.data(), 4 * nh, hipMemcpyHostToDevice, s)); GM_HIP(hipStreamSynchronize(s)); }
+            gm_agg_sched sc;
+            GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s));
+            b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
         }
     }
     tm.lap("heavy");

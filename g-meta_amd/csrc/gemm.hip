@@ -954,7 +954,7 @@ static int launch_wgrad_split(const WgradK& w, hipStream_t s) {
 }
 
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
-struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; };
+struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; uint16_t* pl_fwd; uint16_t* pl_dz; };
 
 __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
                                float* db, int64_t db_stride, WgradSgd u) {
@@ -977,6 +977,21 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
                 const float wn = u.cur[(int64_t)set * u.cur_stride + u.w_off + j] - u.lr * s;
                 u.next[(int64_t)set * u.next_stride + u.w_off + j] = wn;
                 if (u.wt) { const int k = j / N, n = j - k * N; u.wt[(int64_t)set * KN + (int64_t)n * (KN / N) + k] = wn; }
+                if (u.pl_fwd || u.pl_dz) {          // exact 3-way bf16 split of the new weight, straight into the next step's GEMM operand planes
+                    const int K = KN / N, k = j / N, n = j - k * N;
+                    const uint32_t bx = __float_as_uint(wn), bh = bx & 0xffff0000u;
+                    const float r1 = wn - __uint_as_float(bh);
+                    const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
+                    const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
+                    if (u.pl_fwd) {                 // B[k][n] = W[k][n]  ->  [k/8][n][8]
+                        uint16_t* o = u.pl_fwd + (int64_t)set * 3 * KN + ((int64_t)(k >> 3) * N + n) * 8 + (k & 7);
+                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
+                    }
+                    if (u.pl_dz) {                  // B[k'][n'] = W[n'][k'] (k' = n, n' = k)  ->  [n/8][k][8]
+                        uint16_t* o = u.pl_dz + (int64_t)set * 3 * KN + ((int64_t)(n >> 3) * K + k) * 8 + (n & 7);
+                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
+                    }
+                }
             }
         } else if (db) {
             db[(int64_t)set * db_stride + (j - KN)] = s;
@@ -993,7 +1008,8 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     return rc;
 }
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
-    const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off, a.sgd_next ? a.wt_next : nullptr};
+    const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off, a.sgd_next ? a.wt_next : nullptr,
+                       a.sgd_next ? a.pl_fwd : nullptr, a.sgd_next ? a.pl_dz : nullptr};
     if (a.n_chunks <= 0) {      // no rows at all: the gradients are zero
         const int tot0 = (a.K + 1) * a.N;
         hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot0 + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off, a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);

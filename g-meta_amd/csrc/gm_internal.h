@@ -106,6 +106,9 @@ struct gm_batch {
     int32_t* d_sched[2] = {nullptr, nullptr};
     int32_t sched_len[2] = {0, 0};
     int32_t sched_win = 0;
+    // hub rows split into parts of hub_part edges, one block each (gm_agg_schedule): part table + arrival counters, and the partial
+    // rows.  One aggregate launch per orientation at a time (a batch's launches are stream-ordered: they share the layer buffers too).
+    int32_t* d_hub[2] = {nullptr, nullptr}; float* d_hub_scratch[2] = {nullptr, nullptr}; int32_t hub_part[2] = {0, 0};
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
@@ -188,13 +191,18 @@ struct gm_agg_args {
     int heavy_deg;
     const int32_t* sched;      // optional block schedule (gm_agg_schedule): hub rows ride in the window launch
     int sched_len, sched_win;
+    const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
 };
+#define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
+struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; };
+template <class A, class B> inline void gm_agg_hub(A& a, const B* b, int o) { a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o]; }
 // Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
 int gm_agg_window(int64_t rows);
 // Block schedule for the window aggregate over `rows` rows with the given (ascending, host) hub-row list: 8 per-XCD lists of
-// equal length *len_out; entry >= 0: window block id, <= -2: hub row heavy[-(entry) - 2], -1: nothing.  A hub row's block
-// follows the window block that contains the row, on the XCD whose L2 is streaming that subgraph.
-int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, int n_heavy, int32_t** d_sched, int32_t* len_out, hipStream_t s);
+// equal length out->len; entry >= 0: window block id, <= -2: hub part -(entry) - 2 (hub row heavy[..] itself when the rows are not
+// split: out->d_hub == NULL), -1: nothing.  A hub row's blocks follow the window block that contains the row, on the XCD whose L2 is
+// streaming that subgraph.  heavy_deg_host: the rows' edge counts (NULL: never split).
+int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s);
 int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG, default 64)
 int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);
 
@@ -244,6 +252,8 @@ struct gm_wgrad_args {
     // optional fused inner-loop SGD (meta.py:126,151): next_t[off + j] = cur_t[off + j] - lr * grad, written together with the gradient
     const float* sgd_cur; int64_t sgd_cur_stride; float* sgd_next; int64_t sgd_next_stride; float sgd_lr;
     int64_t w_off, b_off;               // offsets of this layer's W and b inside a parameter vector
+    uint16_t* pl_fwd; uint16_t* pl_dz;  // optional (with sgd_next): the updated W also written as split-bf16 planes for the NEXT step's GEMMs
+                                        // ([set][3][K/8][N][8] for X @ W, [set][3][N/8][K][8] for dQ @ W^T; gemm_split.h layouts): no k_split_w launches
     float* wt_next;                     // optional (with sgd_next): the updated W also written transposed, [set][N][K] -- what the NEXT
                                         // step's dZ GEMM (dQ @ W^T on the row-major DMA kernel) reads, instead of a transpose launch
     int64_t rows;                       // total rows covered by the chunks (profiling: flops = 2*rows*K*N)

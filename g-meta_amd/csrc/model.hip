@@ -332,8 +332,28 @@ struct Carver {
     bool ok() const { return !base || used <= cap; }
 };
 
+// Split-bf16 operand planes of the fast weights fw_1..fw_K, written by the weight-gradient reduction that produces each vector
+// (gm_wgrad_args::pl_fwd / pl_dz) and looked up by the GEMMs that consume it -- on either stream; the vector's own ready event
+// orders them.  One slot per (k, layer, orientation); theta (shared by all tasks) is split on the fly: one set, one tiny launch.
+struct PlaneDir {
+    const float* fw0 = nullptr; int64_t TP = 0; int K = 0;                  // fw_k = fw0 + (k-1) * TP, k = 1..K
+    uint16_t* base = nullptr; int64_t per_k = 0;                            // planes of fw_k at base + (k-1) * per_k
+    int64_t off[GM_MAX_GCN][2] = {};                                        // [layer][0 fwd, 1 dz] inside a k block; -1 = not kept
+    bool valid[64][GM_MAX_GCN][2] = {};
+    int index_of(const float* params) const {                               // 1..K, or 0
+        if (!base || !fw0 || params < fw0) return 0;
+        const int64_t d = params - fw0;
+        if (d % TP) return 0;
+        const int64_t k = d / TP + 1;
+        return (k >= 1 && k <= K && k < 64) ? (int)k : 0;
+    }
+    uint16_t* slot(int k, int l, int o) const { return (k && off[l][o] >= 0) ? base + (int64_t)(k - 1) * per_k + off[l][o] : nullptr; }
+    uint16_t* lookup(const float* params, int l, int o) const { const int k = index_of(params); return (k && off[l][o] >= 0 && valid[k][l][o]) ? slot(k, l, o) : nullptr; }
+};
+
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
+    PlaneDir* pd;                // non-NULL inside gm_meta_step
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
     uint16_t* Wsplit;            // per-task weights of the GEMM being launched as three bf16 planes (split-bf16 kernel, gemm_split.h)
     float* WTl[GM_MAX_GCN];      // per-task transposed weights of layer l >= 1, [set][fo][fi]: B of the dZ GEMM (dense backward)
@@ -431,7 +451,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
-            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
@@ -439,7 +459,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
@@ -456,8 +476,9 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             g.relu_bits = c.M[l];
             if (c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0) {
-                GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st));
-                g.Bsplit = c.Wsplit; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+                uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 0) : nullptr;      // left by the reduction that wrote these weights
+                if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
+                g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
             }
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
@@ -499,7 +520,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -524,8 +545,9 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 const bool use_wt = !use_split && dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
                 if (use_split) {
                     // B = W^T with W stored [fi][fo]: the planes are W's own rows (no transpose), K = fo, N = fi
-                    GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fo, fi, 1, pstride ? b->sets : 1, c.Wsplit, st));
-                    g.Bsplit = c.Wsplit; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+                    uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 1) : nullptr;
+                    if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fo, fi, 1, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
+                    g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
                     g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1;
                 } else if (use_wt) {
                     // dZ = dQ @ W^T through the direct-to-LDS kernel on transposed weights: left there by the previous step's
@@ -541,10 +563,13 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 if (use_wt && c.sgd.next) { w.wt_next = c.WTl[l]; }
             }
+            int kn = 0;
+            if (c.pd && c.sgd.next && (kn = c.pd->index_of(c.sgd.next)) != 0) { w.pl_fwd = c.pd->slot(kn, l, 0); w.pl_dz = c.pd->slot(kn, l, 1); }
             GM_TRY(gm_launch_wgrad(w, st));
+            if (kn) { c.pd->valid[kn][l][0] = w.pl_fwd != nullptr; c.pd->valid[kn][l][1] = w.pl_dz != nullptr; }
             if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
             if (l > 0) {
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
@@ -940,6 +965,7 @@ struct MetaPlan {
     gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
     GcnCtx S, Q;
     float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq, *theta_p;
+    PlaneDir pd;
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
     int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q]
     int Ct, ns, nq;
@@ -972,6 +998,24 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
         p.tab_s = blk ? p.rows_q + qry->subs : nullptr; p.tab_q = blk ? p.tab_s + 3 * p.T : nullptr;
     }
     gcn_carve(p.S, cv); gcn_carve(p.Q, cv);
+    // split-bf16 planes of every fast-weight vector (dense schedule, layers the split GEMM can take): forward planes for every such
+    // layer, dZ planes for layers >= 1; ~1 MB per task and inner step at 128/256/256
+    p.pd = PlaneDir{};
+    if (gm_gemm_mode() == 1 && !p.S.cone && p.K < 64) {
+        int64_t per_k = 0;
+        for (int l = 0; l < p.L.n_gcn; ++l) {
+            const int fi = p.L.dims[l], fo = p.L.dims[l + 1];
+            p.pd.off[l][0] = p.pd.off[l][1] = -1;
+            if (fi > fo) continue;                                           // multiply-first layers keep the on-the-fly path
+            const int64_t sz = (int64_t)p.T * 3 * fi * fo;
+            if (fo == 256 && fi % 16 == 0 && fi >= 32) { p.pd.off[l][0] = per_k; per_k += sz; }                 // X @ W: K = fi, N = fo
+            if (l > 0 && fi == 256 && fo % 16 == 0 && fo >= 32) { p.pd.off[l][1] = per_k; per_k += sz; }        // dQ @ W^T: K = fo, N = fi
+        }
+        if (per_k > 0) {
+            p.pd.base = cv.take<uint16_t>(per_k * p.K); p.pd.per_k = per_k; p.pd.fw0 = p.fw; p.pd.TP = TP; p.pd.K = p.K;
+            if (!p.pd.base) p.pd.base = reinterpret_cast<uint16_t*>(1);      // sizing pass (no workspace yet): keep the layout decisions identical
+        }
+    }
     p.Ct = Ct; p.ns = ns; p.nq = nq;
     if (need) *need = cv.used + 256;
     GM_REQUIRE(cv.ok(), GM_ENOMEM, "meta_step: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)cv.used);
@@ -1017,6 +1061,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_TRY(gm_make_layout(m, &Lu));
     GM_TRY(meta_plan(p, spt, qry, &mp, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
     const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
+    p.S.pd = p.Q.pd = p.pd.base ? &p.pd : nullptr;
     if (shift) {
         hipLaunchKernelGGL(k_pad_params, dim3((int)std::min<int64_t>(512, (L.P + 255) / 256)), dim3(256), 0, st, theta, Lu.P, cut, shift, p.theta_p);
         GM_HIP(hipGetLastError());
