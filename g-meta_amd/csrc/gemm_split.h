@@ -32,6 +32,7 @@ struct SplitGemmK {
     const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* tiles; int n_tiles; int n_col_tiles; int nt_store;
     unsigned long long* dbg;                   // experiment: per-iteration timestamps of one workgroup (FC_TRACE)
+    int dephase;                               // k_gemm_split_h: s_sleep(127) count for the second-slot workgroups
 };
 
 // x (4 floats) -> three packed bf16x4 (8 bytes each): h = trunc16(x), m = trunc16(x - h), l = x - h - m (exact in bf16)
@@ -672,7 +673,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         GS_BARRIER();
         for (int gc = 0; gc < total; ++gc) {
             PF_T(gc, 0);
+#ifndef PF_EXP_NOBDMA
             if (gc + 1 < total) issue_b(gc + 1);
+#endif
             PF_T(gc, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             PF_T(gc, 2);
@@ -769,6 +772,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
         int gc = 0;
+#ifdef PF_EXP_NOBLDS
+        gm_bf16x8 bfx[2][3];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfx[j][p] = *reinterpret_cast<const gm_bf16x8*>(smem + b_lane + p * B_PLANE + j * 512);
+#endif
         for (int ti = 0; ti < ntb; ++ti) {
             gm_f32x16 acc[2][2];
 #pragma unroll
@@ -780,15 +790,27 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             for (int c = 0; c < nchunks; ++c, ++gc) {
                 PF_T(gc, 0);
                 const char* S = smem + (gc & 1) * STAGE;
+#ifdef PF_EXP_NOBLDS
+                gm_bf16x8 af[2][3];
+                static_assert(true, "");
+                gm_bf16x8 bf[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[j][p] = bfx[j][p];
+#else
                 gm_bf16x8 af[2][3], bf[2][3];
+#endif
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
+#ifndef PF_EXP_NOBLDS
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
+#endif
 #define PF_PROD(PA, PB)                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
@@ -837,3 +859,231 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         }
     }
 }
+
+#ifdef GS_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (tools/gemm_split_bench.hip mode 3; measured 1.12-1.13 ms against 0.99 ms for k_gemm_split_p on the 1.15 M x 256 x 256
+// product, whatever the de-phasing: the doubled A feeding -- loads, split VALU work, LDS writes -- costs more than the hidden store
+// epilogue returns; grids that are not a multiple of 16 are not handled).  Kept for the ablation table, not built into the library.
+// TWO workgroups per CU, each a 512-thread copy of the structure above on a 128 x 128 half tile (N == 256 split in two):
+//   waves 0..3  COMPUTE (64 x 64 sub-tiles)   waves 4,5  A FEEDERS   waves 6,7  B FEEDERS
+// The persistent kernel above loses ~18 % of a tile's lifetime to its store epilogue (the compute waves wait for the CU's write
+// path and the feeders wait for the compute waves).  With two independent half-size workgroups on a CU, one's epilogue runs under
+// the other's MFMAs; the second-slot workgroups start half a tile late so that the pair stays out of phase.  The two halves of a
+// row tile are walked by neighbouring workgroups of the same XCD at about the same time (the second read of the A rows is an L2 /
+// Infinity-Cache hit).  LDS: 2 stages x 24 KiB + 4 x 4.25 KiB staging (16-row passes) + scales/bias = 67 KiB per workgroup.
+#ifndef PH_DA
+#define PH_DA 4
+#endif
+__global__ __launch_bounds__(512, 2) void k_gemm_split_h(SplitGemmK g) {
+    constexpr int BK = 16, BN = 128, WC = 2;
+    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
+    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;                                  // 12 + 12 KiB
+    constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
+    constexpr int OFF_E = 2 * STAGE, OFF_SC = OFF_E + 4 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
+    constexpr int A_PER = (GS_BM * BK / 4) / 128;                                     // float4 per A-feeder lane and chunk: 4 (two feeder waves)
+    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 2;                                    // DMA pieces per B-feeder wave and chunk: 6
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = g.K / BK;
+    // workgroup b: XCD x = b % 8, slot i = b / 8 on it; slots 2j and 2j+1 take the two halves of the same row tiles
+    const int G2 = gridDim.x / 2, b = blockIdx.x;                                     // grid is even: G2 row-tile walkers per half
+    const int xcd = b % 8, slot = b / 8, half = slot & 1;
+    const int walker = (slot >> 1) * 8 + xcd;                                         // 0 .. G2-1
+    const int n0 = half * BN;
+    const int nb = g.n_tiles, q8 = nb / 8, r8 = nb % 8;
+    auto logical = [&](int t) -> int { const int x = t % 8, i = t / 8; return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; };
+    const int ntb = walker < nb ? (nb - walker + G2 - 1) / G2 : 0;                    // row tiles of this workgroup
+    const int total = ntb * nchunks;
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
+    float* biasl = reinterpret_cast<float*>(smem + OFF_BIAS);                         // [2][128]
+    if (total == 0) return;
+    // de-phase the two workgroups of a CU (the dispatcher fills every CU of an XCD once before it doubles up: slots >= 32 are the
+    // second residents -- a speed heuristic only): about half a tile of MFMA time
+    if (g.dephase && slot >= 32 && ntb >= 3) {
+        for (int i = 0; i < g.dephase; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+
+    if (wave >= 6) {
+        // ================= B feeder
+        __builtin_amdgcn_s_setprio(2);
+        const int fw = wave - 6;
+        unsigned boff[B_PPW]; int bdst[B_PPW];
+#pragma unroll
+        for (int p = 0; p < B_PPW; ++p) {
+            const int piece = fw * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % 2, plane = po / 2;
+            boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + n0 + cb * 64 + lane) * 8) * 2);
+            bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+        }
+        const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
+        auto issue_b = [&](int gc) {                                                  // global chunk gc -> stage gc & 1
+            const int ti = gc / nchunks, c = gc - ti * nchunks;
+            const int lt = logical(walker + ti * G2);
+            const int set = g.tiles[lt * 3];
+            const uint64_t base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)set * g.bt_stride) + (uint64_t)(c * b_chunk_bytes);
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+            const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((gc & 1) * STAGE + bdst[p]));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
+            }
+        };
+        issue_b(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GS_BARRIER();
+        for (int gc = 0; gc < total; ++gc) {
+            if (gc + 1 < total) issue_b(gc + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GS_BARRIER();
+        }
+    } else if (wave >= 4) {
+        // ================= A feeder
+        __builtin_amdgcn_s_setprio(3);
+        const int ft = tid - 256;                                                     // 0..127
+        int rr[A_PER], adst[A_PER];
+        const int c4 = (ft & 3) * 4;
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) { rr[p] = (ft + p * 128) >> 2; adst[p] = (c4 >> 3) * A_OCT + rr[p] * 16 + (c4 & 7) * 2; }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v ra[PH_DA][A_PER];
+        auto load_a = [&](int gc, int slot_) {
+            const int ti = gc / nchunks, c = gc - ti * nchunks;
+            const int lt = logical(walker + ti * G2);
+            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                const float* src = g.A + (int64_t)(row0 + min(rr[p], nrows - 1)) * g.lda + c4 + c * BK;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot_][p]) : "v"(src) : "memory");
+            }
+        };
+        auto store_a = [&](int gc, int slot_) {
+            char* As = smem + (gc & 1) * STAGE;
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                uint2 h, m, l;
+                const f4v v = ra[slot_][p];
+                gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+                *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+            }
+        };
+        auto stage_tile_consts = [&](int ti) {
+            const int lt = logical(walker + ti * G2);
+            const int set = g.tiles[lt * 3], row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+            float sc = 1.f;
+            if (g.row_scale) sc = g.row_scale[row0 + min(ft, nrows - 1)];
+            float b0 = 0.f;
+            if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[n0 + ft];
+            scales[(ti & 1) * GS_BM + ft] = sc;
+            biasl[(ti & 1) * BN + ft] = b0;
+        };
+        static_assert(A_PER == 4 && PH_DA >= 2 && PH_DA <= 8, "wait macro is written for 4 loads per chunk");
+#define PH_WAIT_SLOT(NEWER, SLOT) \
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[SLOT][0]), "+v"(ra[SLOT][1]), "+v"(ra[SLOT][2]), "+v"(ra[SLOT][3]) : "n"((NEWER) * A_PER) : "memory")
+        stage_tile_consts(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < PH_DA; ++d) if (d < total) load_a(d, d);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]), "+v"(ra[0][2]), "+v"(ra[0][3]) :: "memory");
+        store_a(0, 0);
+        GS_BARRIER();
+        for (int g0 = 0; g0 < total; g0 += PH_DA) {
+#pragma unroll
+            for (int u = 0; u < PH_DA; ++u) {
+                const int gc = g0 + u;
+                if (gc < total) {
+                    if (gc + 1 < total) {
+                        const int newer = min(PH_DA - 2, total - 2 - gc);
+                        const int SL = (u + 1) % PH_DA;
+                        if (newer >= PH_DA - 2 && PH_DA >= 2) PH_WAIT_SLOT(PH_DA - 2, SL);
+                        else if (newer == 1 && PH_DA > 3) PH_WAIT_SLOT(1, SL);
+                        else if (newer == 2 && PH_DA > 4) PH_WAIT_SLOT(2, SL);
+                        else PH_WAIT_SLOT(0, SL);
+                        store_a(gc + 1, SL);
+                        if ((gc + 1) % nchunks == 0) { stage_tile_consts((gc + 1) / nchunks); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    }
+                    if (gc + PH_DA < total) load_a(gc + PH_DA, u);
+                    GS_BARRIER();
+                }
+            }
+        }
+#undef PH_WAIT_SLOT
+    } else {
+        // ================= compute
+        const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
+        const int a_lane = kh * A_OCT + (wr * 64 + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        GS_BARRIER();
+        int gc = 0;
+        for (int ti = 0; ti < ntb; ++ti) {
+            gm_f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int c = 0; c < nchunks; ++c, ++gc) {
+                const char* S = smem + (gc & 1) * STAGE;
+                gm_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
+#define PH_PROD(PA, PB)                                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+                PH_PROD(2, 0) PH_PROD(0, 2) PH_PROD(1, 1) PH_PROD(1, 0) PH_PROD(0, 1) PH_PROD(0, 0)
+#undef PH_PROD
+                GS_BARRIER();
+            }
+            // ---- epilogue of tile ti: wave-private staging in 16-row passes, stores only (no global load, no barrier)
+            const int lt = logical(walker + ti * G2);
+            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+            const float* sc_t = scales + (ti & 1) * GS_BM;
+            const int lcol = wc * 64 + ec, col = n0 + lcol;
+            const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + lcol);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 8 * hh; e < 8 * hh + 8; ++e) E[((e & 3) + 8 * ((e >> 2) & 1) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rl = wr * 64 + i * 32 + hh * 16 + it * 4 + er;
+                        if (rl >= nrows) continue;
+                        const int64_t row = row0 + rl;
+                        const float sc = sc_t[rl];
+                        float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+                        v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+                        if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                        if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+                        if (g.nt_store) {
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+                        } else {
+                            *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+    }
+}
+#endif  // GS_EXPERIMENTS (k_gemm_split_h)

@@ -104,6 +104,19 @@ def test_aggregate_properties_full_size(world, width):
     assert torch.allclose(agg(x, 0, si, so), so[:, None] * agg(si[:, None] * x), atol=2e-4, rtol=1e-5)
     # run-to-run determinism (bitwise)
     assert torch.equal(agg(x), ax)
+    # hub rows are split over several blocks whose partial rows meet in a scratch buffer that every launch reuses: alternate the
+    # inputs and check the hub rows against an fp64 gather each time (a stale partial row would be off by O(1))
+    indptr, indices = Q.csr()[:2]
+    deg_i = np.diff(indptr)
+    hubs = np.nonzero(deg_i > 256)[0][:64]
+    assert len(hubs) > 0, 'no hub row with more than one part in this batch'
+    idx = torch.from_numpy(np.asarray(indices)).cuda().long()
+    for rep in range(6):
+        v = x if rep % 2 == 0 else y
+        got = agg(v)
+        for r in hubs[:: max(1, len(hubs) // 8)]:
+            want = v[idx[int(indptr[r]):int(indptr[r + 1])]].double().sum(0)
+            assert torch.allclose(got[r].double(), want, atol=1e-3, rtol=1e-5), (rep, int(r))
 
 
 def _meta(world, **kw):
