@@ -24,8 +24,18 @@ struct AggK {
     // part g of the schedule covers edges [hub_part * p, hub_part * (p+1)) of its row; the last block to arrive sums the partial rows
     // (hub_scratch, [parts][hub_ld]) in part order -- deterministic -- and runs the epilogue.  hub == NULL: one block per hub row.
     const int32_t* hub; float* hub_scratch; int hub_part, hub_ld;
+    const float* e_w; const int32_t* x_idx;     // per-edge source scale / source row of x (see gm_agg_args)
 };
 
+// edge e -> (row of x to read, its scale): from the per-edge tables when the launch has them, else through indices / s_in / x_row
+__device__ __forceinline__ void agg_edge(const AggK& a, const int e, int& u, float& w) {
+    if (a.e_w && (a.x_idx || !a.x_row)) {
+        w = a.e_w[e]; u = a.x_idx ? a.x_idx[e] : a.indices[e];
+    } else {
+        u = a.indices[e]; w = a.s_in ? a.s_in[u] : 1.f;
+        if (a.x_idx) u = a.x_idx[e]; else if (a.x_row) u = a.x_row[u];
+    }
+}
 template <int VEC> struct VecT;
 template <> struct VecT<4> { using T = float4; };
 template <> struct VecT<1> { using T = float; };
@@ -65,9 +75,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
         V acc0, acc1; vzero(acc0); vzero(acc1);
         int e = e0;
         for (; e + 4 <= e1; e += 4) {                   // 4 independent gathers in flight per lane
-            int u0 = a.indices[e], u1 = a.indices[e + 1], u2 = a.indices[e + 2], u3 = a.indices[e + 3];
-            const float w0 = a.s_in ? a.s_in[u0] : 1.f, w1 = a.s_in ? a.s_in[u1] : 1.f, w2 = a.s_in ? a.s_in[u2] : 1.f, w3 = a.s_in ? a.s_in[u3] : 1.f;
-            if (a.x_row) { u0 = a.x_row[u0]; u1 = a.x_row[u1]; u2 = a.x_row[u2]; u3 = a.x_row[u3]; }
+            int u0, u1, u2, u3; float w0, w1, w2, w3;
+            agg_edge(a, e, u0, w0); agg_edge(a, e + 1, u1, w1); agg_edge(a, e + 2, u2, w2); agg_edge(a, e + 3, u3, w3);
             const V v0 = *reinterpret_cast<const V*>(a.x + (int64_t)u0 * a.ldx + c0);
             const V v1 = *reinterpret_cast<const V*>(a.x + (int64_t)u1 * a.ldx + c0);
             const V v2 = *reinterpret_cast<const V*>(a.x + (int64_t)u2 * a.ldx + c0);
@@ -75,9 +84,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg(AggK a) {
             vfma(acc0, v0, w0); vfma(acc1, v1, w1); vfma(acc0, v2, w2); vfma(acc1, v3, w3);
         }
         for (; e < e1; ++e) {
-            int u = a.indices[e];
-            const float w = a.s_in ? a.s_in[u] : 1.f;
-            if (a.x_row) u = a.x_row[u];
+            int u; float w;
+            agg_edge(a, e, u, w);
             vfma(acc0, *reinterpret_cast<const V*>(a.x + (int64_t)u * a.ldx + c0), w);
         }
         V res;
@@ -122,7 +130,7 @@ __device__ __forceinline__ void agg_heavy_row(const AggK& a, const int g, float*
     for (int c = 0; c < NCH; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int eb = e0 + gi * PS; eb < e1; eb += NG * PS) {
         int mu = 0; float mw = 0.f;
-        if (l < PS && eb + l < e1) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
+        if (l < PS && eb + l < e1) agg_edge(a, eb + l, mu, mw);
         const int cnt = min(PS, e1 - eb);
         for (int j = 0; j < cnt; j += 8) {
             float4 v[8][NCH]; float ww[8];
@@ -259,8 +267,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     if (lane < a.win && myrow < a.rows) {
         p0 = a.indptr[myrow]; dg = a.indptr[myrow + 1] - p0;
         if (a.s_out) so = a.s_out[myrow];
-        if (dg >= 1) { u0 = a.indices[p0]; w0 = a.s_in ? a.s_in[u0] : 1.f; if (a.x_row) u0 = a.x_row[u0]; }
-        if (dg >= 2) { u1 = a.indices[p0 + 1]; w1 = a.s_in ? a.s_in[u1] : 1.f; if (a.x_row) u1 = a.x_row[u1]; }
+        if (dg >= 1) agg_edge(a, p0, u0, w0);
+        if (dg >= 2) agg_edge(a, p0 + 1, u1, w1);
     }
     const int nwin = (int)min((int64_t)a.win, a.rows - R0);
     const float* xl = a.x + l * 4;
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
             const int eend = rp0[k] + rdg[k];
             for (int eb = rp0[k] + 2; eb < eend; eb += LPR) {
                 int mu = 0; float mw = 0.f;
-                if (eb + l < eend) { mu = a.indices[eb + l]; mw = a.s_in ? a.s_in[mu] : 1.f; if (a.x_row) mu = a.x_row[mu]; }
+                if (eb + l < eend) agg_edge(a, eb + l, mu, mw);
                 const int cnt = min(LPR, eend - eb);
                 for (int j = 0; j < cnt; j += MB) {
                     float4 v[MB][NCH]; float ww[MB];
@@ -461,7 +469,7 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
            g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
            g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64,
-           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD};
+           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
@@ -510,6 +518,8 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.indices = transposed ? b->d_indices_t : b->d_indices;
     a.x = gather ? b->store->d_feat : x;
     a.x_row = gather ? b->d_feat_row : nullptr;
+    if (gather && !transposed) a.x_idx = b->d_efeat;
+    if (s_in && s_in == b->d_norm) a.e_w = b->d_enorm[transposed ? 1 : 0];
     a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
     a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, transposed ? 1 : 0);

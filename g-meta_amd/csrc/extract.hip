@@ -321,6 +321,14 @@ __global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list,
         if (d > thr) { const int k = atomicAdd(count, 1); if (k < cap) { list[k] = (int32_t)r; list[cap + k] = d; } }      // [rows: cap][degrees: cap]
     }
 }
+// per-edge tables: source norm (both orientations) and source feature row (forward orientation)
+__global__ void k_edge_tables(const int32_t* indices, const int32_t* indices_t, int64_t edges, const float* norm, const int32_t* feat_row,
+                              float* enorm, float* enorm_t, int32_t* efeat) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < edges; e += (int64_t)gridDim.x * blockDim.x) {
+        const int u = indices[e], v = indices_t[e];
+        enorm[e] = norm[u]; enorm_t[e] = norm[v]; efeat[e] = feat_row[u];
+    }
+}
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
                               int32_t* crow, float* cnorm, int32_t* cdeg) {
@@ -365,6 +373,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
     gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
+    gm_dev_free(b->d_enorm[0], s); gm_dev_free(b->d_enorm[1], s); gm_dev_free(b->d_efeat, s);
     gm_dev_free(b->d_hub[0], s); gm_dev_free(b->d_hub[1], s); gm_dev_free(b->d_hub_scratch[0], s); gm_dev_free(b->d_hub_scratch[1], s);
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
     gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
@@ -430,6 +439,12 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s));
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
         }
+    }
+    if (b->edges > 0) {
+        GM_TRY(gm_alloc(&b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_efeat, (size_t)b->edges, s));
+        hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
+                           b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);
+        GM_HIP(hipGetLastError());
     }
     tm.lap("heavy");
     // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres

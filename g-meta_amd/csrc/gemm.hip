@@ -501,7 +501,11 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
         k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
         k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1;
-        hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(a.n_tiles, gm_num_cus())), dim3(1024), 0, s, k);
+        // persistent: one workgroup per CU (it fills the CU's register file, so nothing else co-resides).  GM_GEMM_SPLIT_GRID caps the
+        // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
+        static int grid_cap = -1;
+        if (grid_cap < 0) { const char* e = getenv("GM_GEMM_SPLIT_GRID"); grid_cap = e ? atoi(e) : 0; if (grid_cap <= 0 || grid_cap > gm_num_cus()) grid_cap = gm_num_cus(); }
+        hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
         GM_HIP(hipGetLastError());
         return GM_OK;
     }

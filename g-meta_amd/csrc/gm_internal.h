@@ -109,6 +109,9 @@ struct gm_batch {
     // hub rows split into parts of hub_part edges, one block each (gm_agg_schedule): part table + arrival counters, and the partial
     // rows.  One aggregate launch per orientation at a time (a batch's launches are stream-ordered: they share the layer buffers too).
     int32_t* d_hub[2] = {nullptr, nullptr}; float* d_hub_scratch[2] = {nullptr, nullptr}; int32_t hub_part[2] = {0, 0};
+    // per-edge tables (gm_batch_finalize): the source's norm for both CSR orientations (enorm[o][e] = norm[indices_o[e]]) and the source's
+    // feature row (efeat[e] = feat_row[indices[e]]): what the aggregate would otherwise fetch with a dependent 4-byte gather per edge
+    float* d_enorm[2] = {nullptr, nullptr}; int32_t* d_efeat = nullptr;
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
@@ -172,6 +175,8 @@ struct gm_agg_args {
     const int32_t* indices;
     const float* x;            // [*, ldx]
     const int32_t* x_row;      // optional indirection applied to the column index (feature gather)
+    const float* e_w;          // optional per-edge source scale (= s_in[indices[e]]; gm_batch::d_enorm): replaces the s_in gather
+    const int32_t* x_idx;      // optional per-edge source row of x (= x_row[indices[e]]; gm_batch::d_efeat): replaces the x_row gather
     int64_t ldx;
     const float* s_in;         // optional per-source scale
     const float* s_out;        // optional per-destination scale

@@ -459,8 +459,8 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
-                if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.ldx = b->store->feat_ld; }
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
                 {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
@@ -520,7 +520,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
