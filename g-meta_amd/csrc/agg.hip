@@ -123,7 +123,7 @@ __device__ __forceinline__ void agg_heavy_row(const AggK& a, const int g, float*
     if (a.hub) { h = a.hub[a.n_heavy + 1 + g]; p = g - a.hub[h]; P = a.hub[h + 1] - a.hub[h]; }
     const int row = a.heavy[h];
     int e0 = a.indptr[row], e1 = a.indptr[row + 1];
-    if (P > 1) { e0 += p * a.hub_part; e1 = min(e1, e0 + a.hub_part); }
+    if (P > 1) { e0 += p * a.hub_part; if (p < P - 1) e1 = e0 + a.hub_part; }      // the last part takes the remainder (up to 1.5 parts)
     const float* xl = a.x + l * 4;
     float4 acc[NCH];
 #pragma unroll
@@ -381,7 +381,7 @@ int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int3
         for (int k = 0; k < n_heavy; ++k) maxdeg = std::max(maxdeg, heavy_deg_host[k]);
         hub_part = std::max((part_env + 15) / 16 * 16, ((maxdeg + 31) / 32 + 15) / 16 * 16);
         tab.assign(n_heavy + 1, 0);
-        for (int k = 0; k < n_heavy; ++k) tab[k + 1] = tab[k] + std::max(1, (heavy_deg_host[k] + hub_part - 1) / hub_part);
+        for (int k = 0; k < n_heavy; ++k) tab[k + 1] = tab[k] + std::max(1, (heavy_deg_host[k] + hub_part / 2) / hub_part);      // nearest: a row is split from 1.5 parts upwards
         const int parts = tab[n_heavy];
         if (parts == n_heavy) { hub_part = 0; tab.clear(); }             // nothing to split
         else {

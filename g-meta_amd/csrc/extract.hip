@@ -440,7 +440,9 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
         }
     }
-    if (b->edges > 0) {
+    static int edge_tables = -1;
+    if (edge_tables < 0) { const char* e = getenv("GM_AGG_EDGE_TABLES"); edge_tables = e ? atoi(e) : 1; }
+    if (b->edges > 0 && edge_tables) {
         GM_TRY(gm_alloc(&b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_efeat, (size_t)b->edges, s));
         hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
                            b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);

@@ -24,6 +24,19 @@ typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
 // barrier behind an explicit LDS wait (and counted vmcnt where a DMA must have landed).
 #define GS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 
+// Tile descriptor {set, row0, nrows} through the SCALAR cache: a vector load here would sit in the wave's in-order vmcnt queue, and the
+// wait for it would drain every prefetched operand load (and every store of the previous tile) with it.
+struct GsTile { int set, row0, nrows; };
+__device__ __forceinline__ GsTile gs_tile(const int32_t* tiles, int lt) {
+    const uint64_t p = (uint64_t)(uintptr_t)(tiles + (int64_t)lt * 3);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const uint64_t sp = ((uint64_t)hi << 32) | lo;
+    int a, b, c;
+    asm volatile("s_load_dword %0, %3, 0x0\n\ts_load_dword %1, %3, 0x4\n\ts_load_dword %2, %3, 0x8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c) : "s"(sp) : "memory");
+    return GsTile{a, b, c};
+}
+
 struct SplitGemmK {
     const float* A; int64_t lda;
     const uint16_t* Bt; int64_t bt_stride;     // split weights [set][3][K/8][N][8] bf16 (k_split_w), per-set stride in ELEMENTS (0 = shared)
@@ -611,11 +624,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
         }
         const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
-        auto issue_b = [&](int gc) {                                                  // global chunk gc -> stage gc & 1
-            const int ti = gc / nchunks, c = gc - ti * nchunks;
-            const int lt = logical(b + ti * G);
-            const int set = g.tiles[lt * 3];
-            const uint64_t base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)set * g.bt_stride) + (uint64_t)(c * b_chunk_bytes);
+        // chunks are issued in order: (tile, chunk) counters instead of a division per chunk, the tile's set looked up once per tile
+        int ib_c = 0, ib_ti = 0;
+        uint64_t ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b)).set * g.bt_stride);
+        auto issue_b = [&](int gc) {                                                  // global chunk gc (= the next in order) -> stage gc & 1
+            if (ib_c == nchunks) { ib_c = 0; ++ib_ti; ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b + ib_ti * G)).set * g.bt_stride); }
+            const uint64_t base = ib_base + (uint64_t)(ib_c * b_chunk_bytes);
+            ++ib_c;
             const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
             const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
 #pragma unroll
@@ -626,48 +641,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                              : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
             }
         };
-#ifdef PF_B_REGS
-        // register path for B: global_load_dwordx4 (L2 hits) two chunks ahead -> ds_write_b128, hand-counted vmcnt
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v rb[2][B_PPW];
-        auto load_b = [&](int gc, int slot) {
-            const int ti = gc / nchunks, c = gc - ti * nchunks;
-            const int lt = logical(b + ti * G);
-            const int set = g.tiles[lt * 3];
-            const char* base = reinterpret_cast<const char*>(g.Bt + (int64_t)set * g.bt_stride) + c * b_chunk_bytes;
-#pragma unroll
-            for (int p = 0; p < B_PPW; ++p) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rb[slot][p]) : "v"(base + boff[p]) : "memory");
-        };
-        auto store_b = [&](int gc, int slot) {
-#pragma unroll
-            for (int p = 0; p < B_PPW; ++p) *reinterpret_cast<f4v*>(smem + (gc & 1) * STAGE + bdst[p] + lane * 16) = rb[slot][p];
-        };
-#define PF_WAITB(N, SLOT) asm volatile("s_waitcnt vmcnt(%6)" : "+v"(rb[SLOT][0]), "+v"(rb[SLOT][1]), "+v"(rb[SLOT][2]), "+v"(rb[SLOT][3]), "+v"(rb[SLOT][4]), "+v"(rb[SLOT][5]) : "n"(N) : "memory")
-        load_b(0, 0);
-        if (total > 1) load_b(1, 1);
-        if (total > 1) PF_WAITB(6, 0); else PF_WAITB(0, 0);
-        store_b(0, 0);
-        GS_BARRIER();
-        for (int g0 = 0; g0 < total; g0 += 2) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int gc = g0 + u;
-                if (gc < total) {
-                    PF_T(gc, 0);
-                    if (gc + 2 < total) load_b(gc + 2, u);                            // slot u held chunk gc (already in LDS)
-                    PF_T(gc, 1);
-                    if (gc + 1 < total) {
-                        if (gc + 2 < total) PF_WAITB(6, (u + 1) & 1); else PF_WAITB(0, (u + 1) & 1);
-                        store_b(gc + 1, (u + 1) & 1);
-                    }
-                    PF_T(gc, 2);
-                    GS_BARRIER();
-                    PF_T(gc, 3);
-                }
-            }
-        }
-#undef PF_WAITB
-#else
         issue_b(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GS_BARRIER();
@@ -682,7 +655,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             GS_BARRIER();
             PF_T(gc, 3);
         }
-#endif
     } else if (wave >= 8) {
         // ================= A feeder
         __builtin_amdgcn_s_setprio(3);
@@ -694,23 +666,51 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         for (int p = 0; p < A_PER; ++p) adst[p] = (c4 >> 3) * A_OCT + rr[p] * 16 + (c4 & 7) * 2;
         typedef float f4v __attribute__((ext_vector_type(4)));
         f4v ra[PF_DA][A_PER];
-        auto load_a = [&](int gc, int slot) {
-            const int ti = gc / nchunks, c = gc - ti * nchunks;
-            const int lt = logical(b + ti * G);
-            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+        // Chunks are loaded in order: (tile, chunk) counters, the tile looked up once per tile through the scalar cache.  From the second
+        // tile on, the tile's row scales and bias ride in the same counted queue (two loads issued right before the tile's first A loads,
+        // i.e. older than them; written to LDS when that chunk is stored): no vmcnt(0) drain of the prefetch at tile boundaries.
+        const bool fast_consts = nchunks >= PF_DA;                                    // the const registers are reused every nchunks chunks
+        int la_c = 0, la_ti = 0;
+        const float* la_src[A_PER];
+        float rc_sc = 1.f, rc_b = 0.f;
+        auto la_tile = [&](int ti, bool consts) {
+            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
 #pragma unroll
-            for (int p = 0; p < A_PER; ++p) {
-                const float* src = g.A + (int64_t)(row0 + min(rr[p], nrows - 1)) * g.lda + c4 + c * BK;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(src) : "memory");
+            for (int p = 0; p < A_PER; ++p) la_src[p] = g.A + (int64_t)(t.row0 + min(rr[p], t.nrows - 1)) * g.lda + c4;
+            if (consts) {
+                if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & 127, t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
+                if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + ft; asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
             }
         };
+        la_tile(0, false);
+        auto load_a = [&](int slot) {                                                 // the next chunk in order
+            if (la_c == nchunks) { la_c = 0; ++la_ti; la_tile(la_ti, fast_consts); }
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                const float* src = la_src[p] + la_c * BK;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(src) : "memory");
+            }
+            ++la_c;
+        };
+        int sa_c = 0, sa_ti = 0;                                                      // (tile, chunk) of the next store_a
         auto store_a = [&](int gc, int slot) {
+            if (sa_c == nchunks) { sa_c = 0; ++sa_ti; }
+            if (sa_c == 0 && sa_ti > 0 && fast_consts) {                               // first chunk of a later tile: its consts arrived with (before) this chunk's loads
+                asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
+                if (ft < GS_BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
+                biasl[(sa_ti & 1) * BN + ft] = rc_b;
+            }
+            ++sa_c;
             char* As = smem + (gc & 1) * STAGE;
 #pragma unroll
             for (int p = 0; p < A_PER; ++p) {
                 uint2 h, m, l;
                 const f4v v = ra[slot][p];
+#ifdef PF_EXP_NOSPLIT
+                h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); m = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); l = h;
+#else
                 gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+#endif
                 *reinterpret_cast<uint2*>(As + adst[p]) = h;
                 *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
                 *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
@@ -718,8 +718,8 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         };
         // row scales + bias of tile ti -> LDS (parity ti & 1); ordinary loads, completed with the vmcnt(0) below
         auto stage_tile_consts = [&](int ti) {
-            const int lt = logical(b + ti * G);
-            const int set = g.tiles[lt * 3], row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];
+            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            const int set = t.set, row0 = t.row0, nrows = t.nrows;
             float sc = 1.f;
             if (g.row_scale) sc = g.row_scale[row0 + min(ft & 127, nrows - 1)];
             float b0 = 0.f;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         stage_tile_consts(0);                                                          // (compiler-managed loads: done before the asm loads below are counted)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int d = 0; d < PF_DA; ++d) if (d < total) load_a(d, d);
+        for (int d = 0; d < PF_DA; ++d) if (d < total) load_a(d);
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]) :: "memory");
         store_a(0, 0);
         GS_BARRIER();
@@ -754,9 +754,10 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                         PF_T(gc, 1);
                         store_a(gc + 1, SL);
                         // the first chunk of the NEXT tile is about to become visible: its scales / bias must be there as well
-                        if ((gc + 1) % nchunks == 0) { stage_tile_consts((gc + 1) / nchunks); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        // (short-K launches only: the counted path above needs nchunks >= PF_DA)
+                        if (!fast_consts && sa_c == 1 && sa_ti > 0) { stage_tile_consts(sa_ti); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                     }
-                    if (gc + PF_DA < total) load_a(gc + PF_DA, u);                     // slot u held chunk gc: already split into LDS
+                    if (gc + PF_DA < total) load_a(u);                                 // slot u held chunk gc: already split into LDS
                     PF_T(gc, 2);
                     GS_BARRIER();
                     PF_T(gc, 3);
@@ -821,8 +822,8 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 PF_T(gc, 3);
             }
             // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
-            const int lt = logical(b + ti * G);
-            const int row0 = g.tiles[lt * 3 + 1], nrows = g.tiles[lt * 3 + 2];       // scalar (SMEM) loads: lgkmcnt, not vmcnt
+            const GsTile tl = gs_tile(g.tiles, logical(b + ti * G));                // scalar (SMEM) loads: lgkmcnt, not vmcnt
+            const int row0 = tl.row0, nrows = tl.nrows;
             const float* sc_t = scales + (ti & 1) * GS_BM;
             const int col = wc * 64 + ec;
             const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
@@ -859,6 +860,261 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         }
     }
 }
+
+#ifdef GS_EXPERIMENTS
+// ------------------------------------------------------------------------------------------------------------------
+// EXPERIMENT (tools/gemm_split_bench.hip mode 4): correct, but 0.99 ms against 0.97 ms for k_gemm_split_p on the 1.15 M x 256 x 256
+// product -- spreading the LDS reads under the MFMAs does not help, the kernel is not LDS-burst-bound either (profiles/r02_split_gemm_ablation2.txt).
+// k_gemm_split_r: the persistent kernel above with a THREE-stage LDS ring and ROLLING fragment reloads in the compute waves.
+// In k_gemm_split_p every compute wave reads its 12 fragments right after the chunk barrier -- all eight waves at once, ~500 cycles
+// of LDS traffic during which no MFMA runs -- and then all of them issue MFMAs (~1540 cycles) while the LDS idles (in-kernel
+// timestamps: 2200-cycle chunks).  Here the feeders run TWO chunks ahead, so the fragments of chunk c+1 are already in LDS while
+// chunk c is being multiplied: a compute wave reloads each fragment register with the next chunk's value right after the last MFMA
+// of this chunk that reads it (product order (0,0) (0,1) (0,2) (1,0) (2,0) (1,1): a_h / b_l die after the third product group,
+// b_h / a_l after the fifth, a_m / b_m after the last) -- no extra registers, the LDS reads spread under the MFMAs, and the compute
+// waves' chunk barrier needs no LDS wait (what they read in chunk c is not overwritten before the barrier after chunk c+1).
+// LDS: 3 stages x 36 KiB + 8 x 4.25 KiB staging (16-row passes) + scales/bias = 145 KiB.
+__global__ __launch_bounds__(1024) void k_gemm_split_r(SplitGemmK g) {
+    constexpr int BK = 16, BN = 256, WC = 4;
+    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
+    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;                                  // 12 + 24 KiB
+    constexpr int NST = 3;
+    constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
+    constexpr int OFF_E = NST * STAGE, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
+    constexpr int A_PER = (GS_BM * BK / 4) / 256;                                     // float4 per A-feeder lane and chunk: 2
+    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6
+    __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nchunks = g.K / BK;
+    const int G = gridDim.x, b = blockIdx.x;
+    const int nb = g.n_tiles, q8 = nb / 8, r8 = nb % 8;
+    auto logical = [&](int t) -> int { const int x = t % 8, i = t / 8; return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; };
+    const int ntb = b < nb ? (nb - b + G - 1) / G : 0;                                // tiles of this workgroup
+    const int total = ntb * nchunks;                                                  // flattened chunk count
+    const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
+    float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
+    float* biasl = reinterpret_cast<float*>(smem + OFF_BIAS);                         // [2][256]
+    if (total == 0) return;
+
+    if (wave >= 12) {
+        // ================= B feeder: chunk k -> stage k % 3, two chunks ahead of the compute waves
+        __builtin_amdgcn_s_setprio(2);
+        const int fw = wave - 12;
+        unsigned boff[B_PPW]; int bdst[B_PPW];
+#pragma unroll
+        for (int p = 0; p < B_PPW; ++p) {
+            const int piece = fw * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % 2, plane = po / 2;
+            boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + cb * 64 + lane) * 8) * 2);
+            bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+        }
+        const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
+        int ib_c = 0, ib_ti = 0, ib_st = 0;
+        uint64_t ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b)).set * g.bt_stride);
+        auto issue_b = [&]() {                                                        // the next chunk in order
+            if (ib_c == nchunks) { ib_c = 0; ++ib_ti; ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b + ib_ti * G)).set * g.bt_stride); }
+            const uint64_t base = ib_base + (uint64_t)(ib_c * b_chunk_bytes);
+            ++ib_c;
+            const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+            const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
+#pragma unroll
+            for (int p = 0; p < B_PPW; ++p) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ib_st * STAGE + bdst[p]));
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
+            }
+            ib_st = ib_st == NST - 1 ? 0 : ib_st + 1;
+        };
+        issue_b();
+        if (total > 1) issue_b();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GS_BARRIER();
+        for (int gc = 0; gc < total; ++gc) {
+            if (gc + 2 < total) issue_b();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            GS_BARRIER();
+        }
+    } else if (wave >= 8) {
+        // ================= A feeder: registers PF_DA chunks deep, chunk k -> stage k % 3, stored two chunks ahead of the compute waves
+        __builtin_amdgcn_s_setprio(3);
+        const int ft = tid - 512;                                                     // 0..255
+        const int rr[A_PER] = {ft >> 2, (ft + 256) >> 2};
+        const int c4 = (ft & 3) * 4;
+        int adst[A_PER];
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) adst[p] = (c4 >> 3) * A_OCT + rr[p] * 16 + (c4 & 7) * 2;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        f4v ra[PF_DA][A_PER];
+        const bool fast_consts = nchunks >= PF_DA;
+        int la_c = 0, la_ti = 0;
+        const float* la_src[A_PER];
+        float rc_sc = 1.f, rc_b = 0.f;
+        auto la_tile = [&](int ti, bool consts) {
+            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) la_src[p] = g.A + (int64_t)(t.row0 + min(rr[p], t.nrows - 1)) * g.lda + c4;
+            if (consts) {
+                if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & 127, t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
+                if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + ft; asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
+            }
+        };
+        la_tile(0, false);
+        auto load_a = [&](int slot) {                                                 // the next chunk in order
+            if (la_c == nchunks) { la_c = 0; ++la_ti; la_tile(la_ti, fast_consts); }
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                const float* src = la_src[p] + la_c * BK;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(src) : "memory");
+            }
+            ++la_c;
+        };
+        auto stage_tile_consts = [&](int ti) {                                        // short-K launches and the first tile: plain loads, drained by the caller
+            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            float sc = 1.f;
+            if (g.row_scale) sc = g.row_scale[t.row0 + min(ft & 127, t.nrows - 1)];
+            float b0 = 0.f;
+            if (g.bias) b0 = (g.bias + (int64_t)t.set * g.bias_stride)[ft];
+            if (ft < GS_BM) scales[(ti & 1) * GS_BM + ft] = sc;
+            biasl[(ti & 1) * BN + ft] = b0;
+        };
+        int sa_c = 0, sa_ti = 0, sa_st = 0;                                           // (tile, chunk, stage) of the next store
+        auto store_a = [&](int slot) {
+            if (sa_c == nchunks) { sa_c = 0; ++sa_ti; }
+            if (sa_c == 0 && sa_ti > 0) {
+                if (fast_consts) {                                                     // arrived with (before) this chunk's loads
+                    asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
+                    if (ft < GS_BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
+                    biasl[(sa_ti & 1) * BN + ft] = rc_b;
+                } else { stage_tile_consts(sa_ti); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            }
+            ++sa_c;
+            char* As = smem + sa_st * STAGE;
+            sa_st = sa_st == NST - 1 ? 0 : sa_st + 1;
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) {
+                uint2 h, m, l;
+                const f4v v = ra[slot][p];
+                gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+                *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+            }
+        };
+        static_assert(A_PER == 2 && PF_DA == 4, "wait macro / unrolling are written for 2 loads per chunk, 4 chunks deep");
+#define PR_WAIT_SLOT(NEWER, SLOT) \
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0]), "+v"(ra[SLOT][1]) : "n"((NEWER) * A_PER) : "memory")
+        // chunk k sits in slot k % PF_DA; when it is stored, chunks k+1 .. min(k+PF_DA-1, total-1) are the newer groups in flight
+#define PR_DO_STORE(K_, SLOT)                                                                         \
+        do {                                                                                          \
+            const int newer_ = min(PF_DA - 1, total - 1 - (K_));                                     \
+            if (newer_ >= 3) PR_WAIT_SLOT(3, SLOT); else if (newer_ == 2) PR_WAIT_SLOT(2, SLOT);      \
+            else if (newer_ == 1) PR_WAIT_SLOT(1, SLOT); else PR_WAIT_SLOT(0, SLOT);                  \
+            store_a(SLOT);                                                                            \
+            if ((K_) + PF_DA < total) load_a(SLOT);                                                   \
+        } while (0)
+        stage_tile_consts(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < PF_DA; ++d) if (d < total) load_a(d);
+        PR_DO_STORE(0, 0);
+        if (total > 1) PR_DO_STORE(1, 1);
+        GS_BARRIER();
+        for (int g0 = 0; g0 < total; g0 += PF_DA) {
+#pragma unroll
+            for (int u = 0; u < PF_DA; ++u) {
+                const int gc = g0 + u;
+                if (gc < total) {
+                    if (gc + 2 < total) PR_DO_STORE(gc + 2, (u + 2) % PF_DA);
+                    GS_BARRIER();
+                }
+            }
+        }
+#undef PR_DO_STORE
+#undef PR_WAIT_SLOT
+    } else {
+        // ================= compute
+        const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
+        const int a_lane = kh * A_OCT + (wr * 64 + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
+        const int er = lane >> 4, ec = (lane & 15) * 4;
+        GS_BARRIER();                                                                  // chunks 0 and 1 are staged
+        gm_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                af[i][p] = *reinterpret_cast<const gm_bf16x8*>(smem + a_lane + p * A_PLANE + i * 512);
+                bf[i][p] = *reinterpret_cast<const gm_bf16x8*>(smem + b_lane + p * B_PLANE + i * 512);
+            }
+        int gc = 0, nst = 1;                                                           // nst: stage of chunk gc + 1
+        for (int ti = 0; ti < ntb; ++ti) {
+            gm_f32x16 acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int c = 0; c < nchunks; ++c, ++gc) {
+                const char* Sn = smem + nst * STAGE;                                   // next chunk's stage (stale after the last chunk: read, never used)
+                nst = nst == NST - 1 ? 0 : nst + 1;
+#define PR_PROD(PA, PB)                                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+#define PR_RELOAD_A(P) _Pragma("unroll") for (int i = 0; i < 2; ++i) af[i][P] = *reinterpret_cast<const gm_bf16x8*>(Sn + a_lane + (P) * A_PLANE + i * 512);
+#define PR_RELOAD_B(P) _Pragma("unroll") for (int j = 0; j < 2; ++j) bf[j][P] = *reinterpret_cast<const gm_bf16x8*>(Sn + b_lane + (P) * B_PLANE + j * 512);
+                PR_PROD(0, 0) PR_PROD(0, 1) PR_PROD(0, 2)
+                PR_RELOAD_A(0) PR_RELOAD_B(2)
+                PR_PROD(1, 0) PR_PROD(2, 0)
+                PR_RELOAD_B(0) PR_RELOAD_A(2)
+                PR_PROD(1, 1)
+                PR_RELOAD_A(1) PR_RELOAD_B(1)
+#undef PR_PROD
+#undef PR_RELOAD_A
+#undef PR_RELOAD_B
+                __builtin_amdgcn_s_barrier();                                          // no LDS wait: see the header comment
+            }
+            // ---- epilogue of tile ti: wave-private staging in 16-row passes, stores only (no global load, no barrier)
+            const GsTile tl = gs_tile(g.tiles, logical(b + ti * G));
+            const int row0 = tl.row0, nrows = tl.nrows;
+            const float* sc_t = scales + (ti & 1) * GS_BM;
+            const int col = wc * 64 + ec;
+            const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 8 * hh; e < 8 * hh + 8; ++e) E[((e & 3) + 8 * ((e >> 2) & 1) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int rl = wr * 64 + i * 32 + hh * 16 + it * 4 + er;
+                        if (rl >= nrows) continue;
+                        const int64_t row = row0 + rl;
+                        const float sc = sc_t[rl];
+                        float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
+                        v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
+                        if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                        if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+                        if (g.nt_store) {
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+                        } else {
+                            *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+            }
+        }
+    }
+}
+
+#endif  // GS_EXPERIMENTS (k_gemm_split_r)
 
 #ifdef GS_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------------------------

@@ -37,9 +37,10 @@ int main(int argc, char** argv) {
     g.A = dA; g.lda = K; g.Bt = dBt; g.bt_stride = 0; g.C = dC; g.ldc = N; g.K = K; g.N = N; g.bias = dBias; g.relu = 0;
     unsigned long long* dDbg; CK(hipMalloc(&dDbg, 3 * 64 * 4 * 8)); CK(hipMemset(dDbg, 0, 3 * 64 * 4 * 8)); g.dbg = dDbg;
     g.tiles = dT; g.n_tiles = (int)tiles.size() / 3; g.n_col_tiles = N / (64 * WC); g.nt_store = getenv("GS_NT") ? atoi(getenv("GS_NT")) : 1;
-    const bool fc = argc > 6 && atoi(argv[6]) == 1, pers = argc > 6 && atoi(argv[6]) == 2, halfk = argc > 6 && atoi(argv[6]) == 3;
+    const bool fc = argc > 6 && atoi(argv[6]) == 1, pers = argc > 6 && atoi(argv[6]) == 2, halfk = argc > 6 && atoi(argv[6]) == 3, roll = argc > 6 && atoi(argv[6]) == 4;
     g.dephase = getenv("GS_DEPHASE") ? atoi(getenv("GS_DEPHASE")) : 2;
     auto launch = [&]() {
+        if (roll) { static const int cap = getenv("GS_GRID") ? atoi(getenv("GS_GRID")) : 256; hipLaunchKernelGGL(k_gemm_split_r, dim3(std::min(g.n_tiles, cap)), dim3(1024), 0, 0, g); return; }
         if (halfk) { hipLaunchKernelGGL(k_gemm_split_h, dim3(std::min(2 * g.n_tiles, 512)), dim3(512), 0, 0, g); return; }
         if (pers) { static const int cap = getenv("GS_GRID") ? atoi(getenv("GS_GRID")) : 256; hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(g.n_tiles, cap)), dim3(1024), 0, 0, g); return; }
         if (fc) { hipLaunchKernelGGL(k_gemm_split_fc, dim3(g.n_tiles * g.n_col_tiles), dim3(640 + 64 * FC_NB), 0, 0, g); return; }
