@@ -139,8 +139,8 @@ def cpu_baseline(db, data, cfg, config, batch, budget_s=45.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='arxiv', choices=['arxiv', 'syn0', 'tissue', 'firstmm'])
     ap.add_argument('--task_num', type=int, default=None)
     ap.add_argument('--hoist_z1', type=int, default=0)

@@ -25,6 +25,7 @@ struct AggK {
     // (hub_scratch, [parts][hub_ld]) in part order -- deterministic -- and runs the epilogue.  hub == NULL: one block per hub row.
     const int32_t* hub; float* hub_scratch; int hub_part, hub_ld;
     const float* e_w; const int32_t* x_idx;     // per-edge source scale / source row of x (see gm_agg_args)
+    int skip_lo, skip_hi;                       // rows with skip_lo <= degree <= skip_hi are left to the fused aggregate+GEMM kernel (empty range: none)
 };
 
 // edge e -> (row of x to read, its scale): from the per-edge tables when the launch has them, else through indices / s_in / x_row
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     if (lane < a.win && myrow < a.rows) {
         p0 = a.indptr[myrow]; dg = a.indptr[myrow + 1] - p0;
         if (a.s_out) so = a.s_out[myrow];
+        if (dg >= a.skip_lo && dg <= a.skip_hi) dg = -2;                   // not this launch's row
         if (dg >= 1) agg_edge(a, p0, u0, w0);
         if (dg >= 2) agg_edge(a, p0 + 1, u1, w1);
     }
@@ -469,7 +471,7 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
            g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
            g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64,
-           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx};
+           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx, g.skip_on ? g.skip_lo : 1, g.skip_on ? g.skip_hi : 0};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);

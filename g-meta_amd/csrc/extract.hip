@@ -329,6 +329,25 @@ __global__ void k_edge_tables(const int32_t* indices, const int32_t* indices_t, 
         enorm[e] = norm[u]; enorm_t[e] = norm[v]; efeat[e] = feat_row[u];
     }
 }
+// per-row source table of the fused aggregate + GEMM kernel (gm_batch::d_fuse2 / d_fuse2_feat)
+__global__ void k_fuse2(const int32_t* indptr, const int32_t* indices, int64_t rows, const float* norm, const int32_t* feat_row, int4* f2, int4* f2_feat,
+                        unsigned long long* counts) {
+    unsigned long long nr = 0, ne = 0;
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int p = indptr[r], d = indptr[r + 1] - p;
+        const int self = (int)r | GM_FUSE_SELF;
+        int4 t = make_int4(self, self, __float_as_int(1.f), 0), tf = t;
+        if (d == 0) { t = make_int4(GM_FUSE_ZERO, GM_FUSE_ZERO, __float_as_int(1.f), 0); tf = t; }
+        else if (d <= GM_FUSE_MAXDEG) {
+            const int u0 = indices[p], u1 = d >= 2 ? indices[p + 1] : u0;
+            const int w0 = __float_as_int(norm[u0]), w1 = d >= 2 ? __float_as_int(norm[u1]) : 0;
+            t = make_int4(u0, u1, w0, w1); tf = make_int4(feat_row[u0], feat_row[u1], w0, w1);
+        }
+        if (d > GM_FUSE_MAXDEG) { ++nr; ne += (unsigned long long)d; }
+        f2[r] = t; f2_feat[r] = tf;
+    }
+    if (nr) { atomicAdd(counts, nr); atomicAdd(counts + 1, ne); }
+}
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
                               int32_t* crow, float* cnorm, int32_t* cdeg) {
@@ -373,6 +392,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
     gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
+    gm_dev_free((int4*)b->d_fuse2, s); gm_dev_free((int4*)b->d_fuse2_feat, s);
     gm_dev_free(b->d_enorm[0], s); gm_dev_free(b->d_enorm[1], s); gm_dev_free(b->d_efeat, s);
     gm_dev_free(b->d_hub[0], s); gm_dev_free(b->d_hub[1], s); gm_dev_free(b->d_hub_scratch[0], s); gm_dev_free(b->d_hub_scratch[1], s);
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
@@ -447,6 +467,21 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
         hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
                            b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);
         GM_HIP(hipGetLastError());
+    }
+    if (b->rows > 0) {
+        int4 *f0 = nullptr, *ff = nullptr;
+        GM_TRY(gm_alloc(&f0, (size_t)b->rows, s)); GM_TRY(gm_alloc(&ff, (size_t)b->rows, s));
+        b->d_fuse2 = f0; b->d_fuse2_feat = ff;
+        unsigned long long* d_counts = nullptr; unsigned long long h_counts[2] = {0, 0};
+        GM_TRY(gm_alloc(&d_counts, 2, s));
+        GM_HIP(hipMemsetAsync(d_counts, 0, 16, s));
+        hipLaunchKernelGGL(k_fuse2, dim3((int)std::min<int64_t>(4096, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, b->d_norm,
+                           b->d_feat_row, f0, ff, d_counts);
+        GM_HIP(hipGetLastError());
+        GM_HIP(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
+        GM_HIP(hipStreamSynchronize(s));
+        gm_dev_free(d_counts, s);
+        b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1];
     }
     tm.lap("heavy");
     // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include "gm_internal.h"
+#include <mutex>
 #include "gemm_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -472,6 +473,20 @@ int gm_gemm_mode() {
 extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode = mode ? 1 : 0; }
 extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
 // The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
+const float* gm_zero_row(hipStream_t s) {
+    static std::mutex mu;
+    static float* rows[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!rows[dev]) {
+        float* p = nullptr;
+        if (hipMalloc(&p, 4096 * sizeof(float)) != hipSuccess) return nullptr;
+        if (hipMemsetAsync(p, 0, 4096 * sizeof(float), s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) { (void)hipFree(p); return nullptr; }
+        rows[dev] = p;
+    }
+    return rows[dev];
+}
 bool gm_gemm_split_ok(int n_tiles, int K, int N) {
     static int min_tiles = -1;        // default: from a quarter of the CUs busy upwards (measured on the 141-tile support batch of a 4-task shard: still ahead of the fp32 small-tile kernel)
     if (min_tiles < 0) { const char* e = getenv("GM_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atoi(e) : gm_num_cus() / 4; }
@@ -505,7 +520,16 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
         static int grid_cap = -1;
         if (grid_cap < 0) { const char* e = getenv("GM_GEMM_SPLIT_GRID"); grid_cap = e ? atoi(e) : 0; if (grid_cap <= 0 || grid_cap > gm_num_cus()) grid_cap = gm_num_cus(); }
-        hipLaunchKernelGGL(k_gemm_split_p, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+        if (a.fuse2) {
+            // fused aggregate + GEMM: A addresses the aggregate's input rows, rows of other degrees come finished from a.zside
+            GM_REQUIRE(a.K / 16 >= PF_DA && a.zside && (a.ldz % 4 == 0) && (((uintptr_t)a.zside & 15) == 0), GM_EINVAL, "gemm: fused aggregate needs K >= %d and an aligned side buffer", 16 * PF_DA);
+            GM_REQUIRE(a.K <= 4096, GM_EINVAL, "gemm: fused aggregate supports K <= 4096");
+            k.f2 = reinterpret_cast<const int4*>(a.fuse2); k.zside = a.zside; k.ldz = a.ldz; k.zrow = gm_zero_row(s);
+            GM_REQUIRE(k.zrow, GM_EHIP, "gemm: zero row allocation failed");
+            hipLaunchKernelGGL(k_gemm_split_p<true>, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+        } else {
+            hipLaunchKernelGGL(k_gemm_split_p<false>, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+        }
         GM_HIP(hipGetLastError());
         return GM_OK;
     }

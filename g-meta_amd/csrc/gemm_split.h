@@ -46,7 +46,12 @@ struct SplitGemmK {
     const int32_t* tiles; int n_tiles; int n_col_tiles; int nt_store;
     unsigned long long* dbg;                   // experiment: per-iteration timestamps of one workgroup (FC_TRACE)
     int dephase;                               // k_gemm_split_h: s_sleep(127) count for the second-slot workgroups
+    // k_gemm_split_p<true> (fused aggregate + GEMM): A / lda address the aggregate's INPUT rows, f2 is the per-row source table, rows
+    // flagged GM_SPLIT_FUSE_SELF read their finished aggregate from zside (row stride ldz), rows without a source read zeros
+    const int4* f2; const float* zside; int64_t ldz; const float* zrow;     // zrow: >= K zero floats (rows flagged GM_SPLIT_FUSE_ZERO)
 };
+#define GM_SPLIT_FUSE_SELF 0x40000000
+#define GM_SPLIT_FUSE_ZERO 0x20000000
 
 // x (4 floats) -> three packed bf16x4 (8 bytes each): h = trunc16(x), m = trunc16(x - h), l = x - h - m (exact in bf16)
 __device__ __forceinline__ void gs_split4(const float4 v, uint2& h, uint2& m, uint2& l) {
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(640 + 64 * FC_NB) void k_gemm_split_fc(SplitGemmK g
 #ifndef PF_DA
 #define PF_DA 4
 #endif
+template <bool GATHER>
 __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     constexpr int BK = 16, BN = 256, WC = 4;
     constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
@@ -665,36 +671,81 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) adst[p] = (c4 >> 3) * A_OCT + rr[p] * 16 + (c4 & 7) * 2;
         typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v ra[PF_DA][A_PER];
+        typedef int i4v __attribute__((ext_vector_type(4)));
+        constexpr int NJ = GATHER ? 2 : 1;                                            // loads per row and chunk (GATHER: the row's two sources)
+        f4v ra[PF_DA][A_PER][NJ];
         // Chunks are loaded in order: (tile, chunk) counters, the tile looked up once per tile through the scalar cache.  From the second
         // tile on, the tile's row scales and bias ride in the same counted queue (two loads issued right before the tile's first A loads,
         // i.e. older than them; written to LDS when that chunk is stored): no vmcnt(0) drain of the prefetch at tile boundaries.
+        // GATHER: the A tile is the aggregate itself -- row r of the tile is w0 * X[u0] + w1 * X[u1] with {u0, u1, w0, w1} from the batch's
+        // per-row source table (gm_batch::d_fuse2: rows of one or two sources; any other row reads its own, already aggregated, row of
+        // `zside` with weights 1, 0), summed in the aggregate kernel's order (fma chain from 0) before the split.  The table entries of
+        // tile t+1 are fetched when tile t's first loads are issued (same counted queue), a whole tile ahead of their use.
         const bool fast_consts = nchunks >= PF_DA;                                    // the const registers are reused every nchunks chunks
         int la_c = 0, la_ti = 0;
-        const float* la_src[A_PER];
+        const float* la_src[A_PER][NJ];
+        float w_next[A_PER][2] = {{1.f, 0.f}, {1.f, 0.f}}, w_cur[A_PER][2] = {{1.f, 0.f}, {1.f, 0.f}};
+        i4v fq[A_PER] = {};
         float rc_sc = 1.f, rc_b = 0.f;
-        auto la_tile = [&](int ti, bool consts) {
+        auto fq_prefetch = [&](int ti) {                                              // table entries of tile ti (if any) -> fq, counted loads
+            if (ti >= ntb) return;
             const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
 #pragma unroll
-            for (int p = 0; p < A_PER; ++p) la_src[p] = g.A + (int64_t)(t.row0 + min(rr[p], t.nrows - 1)) * g.lda + c4;
+            for (int p = 0; p < A_PER; ++p) {
+                const int4* q = g.f2 + t.row0 + min(rr[p], t.nrows - 1);
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(fq[p]) : "v"(q) : "memory");
+            }
+        };
+        auto la_tile = [&](int ti, bool consts) {
+            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            if constexpr (GATHER) {
+                asm volatile("" : "+v"(fq[0]), "+v"(fq[1]) :: "memory");            // fetched a tile ago; every wait since then covered them
+#pragma unroll
+                for (int p = 0; p < A_PER; ++p) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int u = j ? fq[p].y : fq[p].x;
+                        const float* base = (u & GM_SPLIT_FUSE_ZERO) ? g.zrow : (u & GM_SPLIT_FUSE_SELF) ? g.zside + (int64_t)(u & ~GM_SPLIT_FUSE_SELF) * g.ldz : g.A + (int64_t)u * g.lda;
+                        la_src[p][j] = base + c4;
+                        w_next[p][j] = __int_as_float(j ? fq[p].w : fq[p].z);
+                    }
+                }
+                fq_prefetch(ti + 1);
+            } else {
+#pragma unroll
+                for (int p = 0; p < A_PER; ++p) la_src[p][0] = g.A + (int64_t)(t.row0 + min(rr[p], t.nrows - 1)) * g.lda + c4;
+            }
             if (consts) {
                 if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & 127, t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
                 if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + ft; asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
             }
         };
+        if constexpr (GATHER) { fq_prefetch(0); asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0]), "+v"(fq[1]) :: "memory"); }
         la_tile(0, false);
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int p = 0; p < A_PER; ++p) { w_cur[p][0] = w_next[p][0]; w_cur[p][1] = w_next[p][1]; }
+        }
         auto load_a = [&](int slot) {                                                 // the next chunk in order
             if (la_c == nchunks) { la_c = 0; ++la_ti; la_tile(la_ti, fast_consts); }
 #pragma unroll
-            for (int p = 0; p < A_PER; ++p) {
-                const float* src = la_src[p] + la_c * BK;
-                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p]) : "v"(src) : "memory");
-            }
+            for (int p = 0; p < A_PER; ++p)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float* src = la_src[p][j] + la_c * BK;
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ra[slot][p][j]) : "v"(src) : "memory");
+                }
             ++la_c;
         };
         int sa_c = 0, sa_ti = 0;                                                      // (tile, chunk) of the next store_a
         auto store_a = [&](int gc, int slot) {
-            if (sa_c == nchunks) { sa_c = 0; ++sa_ti; }
+            if (sa_c == nchunks) {
+                sa_c = 0; ++sa_ti;
+                if constexpr (GATHER) {                                                // the loads of this tile were issued with w_next's table entries
+#pragma unroll
+                    for (int p = 0; p < A_PER; ++p) { w_cur[p][0] = w_next[p][0]; w_cur[p][1] = w_next[p][1]; }
+                }
+            }
             if (sa_c == 0 && sa_ti > 0 && fast_consts) {                               // first chunk of a later tile: its consts arrived with (before) this chunk's loads
                 asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
                 if (ft < GS_BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
@@ -705,7 +756,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
             for (int p = 0; p < A_PER; ++p) {
                 uint2 h, m, l;
-                const f4v v = ra[slot][p];
+                f4v v = ra[slot][p][0];
+                if constexpr (GATHER) {
+                    const f4v v1 = ra[slot][p][NJ - 1];
+                    const float w0 = w_cur[p][0], w1 = w_cur[p][1];
+                    v.x = __fmaf_rn(v1.x, w1, __fmaf_rn(v.x, w0, 0.f)); v.y = __fmaf_rn(v1.y, w1, __fmaf_rn(v.y, w0, 0.f));
+                    v.z = __fmaf_rn(v1.z, w1, __fmaf_rn(v.z, w0, 0.f)); v.w = __fmaf_rn(v1.w, w1, __fmaf_rn(v.w, w0, 0.f));
+                }
 #ifdef PF_EXP_NOSPLIT
                 h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); m = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); l = h;
 #else
@@ -727,14 +784,17 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             if (ft < GS_BM) scales[(ti & 1) * GS_BM + ft] = sc;
             biasl[(ti & 1) * BN + ft] = b0;
         };
-        static_assert(A_PER == 2 && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 2 loads per chunk");
-#define PF_WAIT_SLOT(NEWER, SLOT) \
-        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0]), "+v"(ra[SLOT][1]) : "n"((NEWER) * A_PER) : "memory")
+        static_assert(A_PER == 2 && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 2 rows per lane and chunk");
+#define PF_WAIT_SLOT(NEWER, SLOT)                                                                                                              \
+        do {                                                                                                                                   \
+            if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][1][0]), "+v"(ra[SLOT][0][NJ - 1]), "+v"(ra[SLOT][1][NJ - 1]) : "n"((NEWER) * 4) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][1][0]) : "n"((NEWER) * 2) : "memory");             \
+        } while (0)
         stage_tile_consts(0);                                                          // (compiler-managed loads: done before the asm loads below are counted)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int d = 0; d < PF_DA; ++d) if (d < total) load_a(d);
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ra[0][0]), "+v"(ra[0][1]) :: "memory");
+        PF_WAIT_SLOT(0, 0);
         store_a(0, 0);
         GS_BARRIER();
         for (int g0 = 0; g0 < total; g0 += PF_DA) {

@@ -112,6 +112,11 @@ struct gm_batch {
     // per-edge tables (gm_batch_finalize): the source's norm for both CSR orientations (enorm[o][e] = norm[indices_o[e]]) and the source's
     // feature row (efeat[e] = feat_row[indices[e]]): what the aggregate would otherwise fetch with a dependent 4-byte gather per edge
     float* d_enorm[2] = {nullptr, nullptr}; int32_t* d_efeat = nullptr;
+    // fused aggregate + GEMM (forward passes nobody differentiates): per row {u0, u1, bits(w0), bits(w1)} -- the row's one or two sources
+    // (batch rows in d_fuse2, feature rows in d_fuse2_feat) and their norms; rows without a source carry {GM_FUSE_ZERO, same, 1, 0}, rows of any other degree {row | GM_FUSE_SELF, same, 1, 0}:
+    // their aggregate is written by the ordinary kernel (gm_agg_args::skip_lo/hi) and picked up as is
+    void* d_fuse2 = nullptr; void* d_fuse2_feat = nullptr;
+    int64_t unfused_rows = 0, unfused_edges = 0;     // rows (and their in-edges) the ordinary aggregate still writes in a fused pass
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
@@ -177,6 +182,7 @@ struct gm_agg_args {
     const int32_t* x_row;      // optional indirection applied to the column index (feature gather)
     const float* e_w;          // optional per-edge source scale (= s_in[indices[e]]; gm_batch::d_enorm): replaces the s_in gather
     const int32_t* x_idx;      // optional per-edge source row of x (= x_row[indices[e]]; gm_batch::d_efeat): replaces the x_row gather
+    int skip_on, skip_lo, skip_hi;   // window kernel only, with skip_on: leave rows with skip_lo <= degree <= skip_hi unwritten (the fused aggregate + GEMM forms them)
     int64_t ldx;
     const float* s_in;         // optional per-source scale
     const float* s_out;        // optional per-destination scale
@@ -198,6 +204,10 @@ struct gm_agg_args {
     int sched_len, sched_win;
     const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
 };
+#define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
+#define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row
+const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)
+#define GM_FUSE_MAXDEG 2
 #define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
 struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; };
 template <class A, class B> inline void gm_agg_hub(A& a, const B* b, int o) { a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o]; }
@@ -225,6 +235,9 @@ struct gm_gemm_args {
     const uint8_t* mask_b;              // same mask packed, byte (row*ldc + col)/4 = bits of 4 consecutive columns (needs vector stores)
     uint8_t* relu_bits;                 // optional output: packed relu' bits of C (with relu; N % 4 == 0, ldc == N)
     const uint16_t* Bsplit; int64_t bsplit_stride;   // optional: B_t as three bf16 planes (gm_split_weights) -> the split-bf16 kernel (gemm_split.h)
+    // with Bsplit: fused aggregate + GEMM.  fuse2 = gm_batch::d_fuse2 / d_fuse2_feat; A / lda then address the aggregate's INPUT rows
+    // (previous layer's output or the feature table) and rows the table flags GM_FUSE_SELF read their finished aggregate from zside
+    const void* fuse2; const float* zside; int64_t ldz;
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
     int64_t rows;                       // total rows covered by the tiles (profiling: flops = 2*rows*K*N)

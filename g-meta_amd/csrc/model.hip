@@ -436,7 +436,20 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
 static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const float* dlogits, float* dparams, int64_t dstride, hipStream_t st, int skip_head);
 
 // skip_head: the head (centre gather + linear) is evaluated by the fused k_head_loss launch that follows
-static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head = 0) {
+// fwd_only: nobody differentiates this pass (query evaluations of the inner steps, finetunning's query passes): aggregate-first layers
+// whose update runs on the split-bf16 kernel take the FUSED aggregate + GEMM -- the aggregate of a row with one or two sources is formed
+// in the GEMM's A feeders (same fma order), only rows of other degrees go through the aggregate kernel and HBM; Z_l of the other
+// rows and the relu' bits are never written.  Same floats as the unfused pass, bit for bit.
+static int gm_fuse_agg() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("GM_FUSE_AGG"); v = e ? atoi(e) : 1; }
+    return v;
+}
+static int g_fuse_agg_override = -1;
+extern "C" void gm_set_fuse_agg(int32_t on) { g_fuse_agg_override = on < 0 ? -1 : (on ? 1 : 0); }
+extern "C" int32_t gm_get_fuse_agg(void) { return g_fuse_agg_override >= 0 ? g_fuse_agg_override : gm_fuse_agg(); }
+
+static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head = 0, int fwd_only = 0) {
     if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1, skip_head);
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     GM_REQUIRE(L.dims[0] == b->store->feat_dim || L.dims[0] == b->store->feat_ld || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
@@ -458,27 +471,47 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
+            const bool split_ok = c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0;
+            const bool fuse = fwd_only && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
+                              (!gather || (b->store->feat_ld % 4 == 0 && b->store->feat_ld >= fi));
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
-                gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
-                {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
-                    int64_t strict = gm_aggregate_bytes(b, fi);
-                    if (gather) strict += 4 * b->rows - 4 * b->rows * (int64_t)fi + std::min<int64_t>(4 * b->rows * (int64_t)fi, 4 * b->store->total_nodes * (int64_t)fi);
-                    gm_prof_note(GM_PROF_AGG_STRICT, strict);
+                if (fuse) {
+                    // only the rows the fused kernel does not form itself (more than GM_FUSE_MAXDEG sources): a partial launch
+                    a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
+                    // SURVEY 8(d)'s B_agg restricted to what this launch touches: every indptr entry, the indices / norms of the rows it writes,
+                    // those rows (written once) and their sources (read once: the high-degree rows of a subgraph reach ~all of its rows)
+                    const int64_t pb = 4 * (b->rows + 1) + 4 * b->unfused_edges + 4 * b->unfused_rows + 4 * b->unfused_rows * (int64_t)fi +
+                                       4 * std::min<int64_t>(b->unfused_edges, gather ? std::min<int64_t>(b->rows, b->store->total_nodes) : b->rows) * (int64_t)fi;
+                    gm_prof_agg_begin(st, pb); gm_prof_note(GM_PROF_AGG_STRICT, pb);
+                    GM_TRY(gm_launch_aggregate(a, st));
+                    gm_prof_agg_end(st);
+                } else {
+                    gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
+                    {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
+                        int64_t strict = gm_aggregate_bytes(b, fi);
+                        if (gather) strict += 4 * b->rows - 4 * b->rows * (int64_t)fi + std::min<int64_t>(4 * b->rows * (int64_t)fi, 4 * b->store->total_nodes * (int64_t)fi);
+                        gm_prof_note(GM_PROF_AGG_STRICT, strict);
+                    }
+                    GM_TRY(gm_launch_aggregate(a, st));
+                    gm_prof_agg_end(st);
+                    if (l == 0) c.z1_valid = 1;
                 }
-                GM_TRY(gm_launch_aggregate(a, st));
-                gm_prof_agg_end(st);
-                if (l == 0) c.z1_valid = 1;
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
-            g.relu_bits = c.M[l];
-            if (c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0) {
+            g.relu_bits = fwd_only ? nullptr : c.M[l];
+            if (split_ok) {
                 uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 0) : nullptr;      // left by the reduction that wrote these weights
                 if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
                 g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+            }
+            if (fuse) {
+                g.zside = c.Z[l]; g.ldz = fi;
+                if (gather) { g.A = b->store->d_feat; g.lda = b->store->feat_ld; g.fuse2 = b->d_fuse2_feat; }
+                else { g.A = xin; g.lda = fi; g.fuse2 = b->d_fuse2; }
             }
             GM_TRY(gm_launch_gemm_nn(g, st));
         }
@@ -1114,7 +1147,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     };
     // One query evaluation (meta.py:129-141,152-154): forward on sq, then head + proto_loss_qry (+ head backward when the
     // meta-gradient is wanted) once the prototypes / weights it needs are ready.
-    auto qry_fwd = [&](const float* w, int64_t wstride) -> int { return gcn_forward(p.Q, w, wstride, p.logit_q, sq, hoist, 1); };
+    auto qry_fwd = [&](const float* w, int64_t wstride, int fwd_only) -> int { return gcn_forward(p.Q, w, wstride, p.logit_q, sq, hoist, 1, fwd_only); };
     auto qry_loss = [&](const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
         ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
         return head_loss(p.Q, w, wstride, p.logit_q, pk, grad ? 1 : 0, p.gq, Pp, sparse, sq);
@@ -1124,11 +1157,11 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     hipEvent_t e_proto0 = signal(st);
     GM_TRY(spt_step_bwd(theta, 0));
     hipEvent_t e_fw = signal(st);                          // fw_1 ready
-    GM_TRY(qry_fwd(theta, 0));
+    GM_TRY(qry_fwd(theta, 0, 1));
     wait(sq, e_proto0);
     GM_TRY(qry_loss(theta, 0, 0, 0, false));
     wait(sq, e_fw);
-    GM_TRY(qry_fwd(fw(1), Pp));
+    GM_TRY(qry_fwd(fw(1), Pp, 1));
     GM_TRY(qry_loss(fw(1), Pp, 1, 0, false));
     bool have_grad = false;
     for (int k = 1; k < K; ++k) {            // meta.py:143-157
@@ -1136,8 +1169,8 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         GM_TRY(spt_step_bwd(fw(k), Pp));
         e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
         wait(sq, e_fw);
-        GM_TRY(qry_fwd(fw(k + 1), Pp));
         const bool last = hp->need_meta_grad && k == K - 1;
+        GM_TRY(qry_fwd(fw(k + 1), Pp, last ? 0 : 1));                     // only the last evaluation is differentiated
         GM_TRY(qry_loss(fw(k + 1), Pp, k + 1, k, last));
         if (last) {
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the

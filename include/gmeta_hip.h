@@ -207,6 +207,13 @@ int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float*
 void gm_set_gemm_mode(int32_t mode);
 int32_t gm_get_gemm_mode(void);
 
+/* Fused aggregate + update for forward passes nobody differentiates (the query evaluations of the inner steps in gm_meta_step,
+ * i.e. meta.py:129-141,152-154 before the last step, and every query pass of finetunning): rows with one or two sources are
+ * aggregated inside the GEMM's operand feeders, in the aggregate kernel's own fma order -- same floats, bit for bit -- and their
+ * Z rows never travel through HBM.  on = 1 / 0, -1 = back to the environment variable GM_FUSE_AGG (default 1). */
+void gm_set_fuse_agg(int32_t on);
+int32_t gm_get_fuse_agg(void);
+
 /* Profiling aid for bench.py: HIP-event time (ms) of the aggregate launches of the last
  * gm_meta_step on this thread, their count and their summed algorithmic bytes.  Events are only
  * recorded when gm_profile_enable(1) was called (they add a few microseconds per launch). */

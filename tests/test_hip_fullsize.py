@@ -265,3 +265,25 @@ def test_split_bf16_gemm_equals_exact_fp32_gemm(world):
     np.testing.assert_allclose(l1, l0, atol=2e-6, rtol=2e-6)
     d = float((g1 - g0).abs().max()); scale = float(g0.abs().max())
     assert d <= 2e-5 and d <= 2e-3 * scale, (d, scale)
+
+
+def test_fused_aggregate_gemm_is_bitwise_the_unfused_pass(world):
+    """Forward passes nobody differentiates (the inner steps' query evaluations, finetunning's query passes) form the aggregate of rows
+    with one or two sources inside the GEMM's operand feeders (k_gemm_split_p<true>) instead of writing Z through HBM: same fma order,
+    so the whole meta-step -- accuracies, every loss, the meta-gradient -- and the finetunning accuracies are BITWISE those of the
+    unfused pass (learner.py:41-47 either way)."""
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    b = world['batch']
+    try:
+        lib.gm_set_fuse_agg(0)
+        m0 = _meta(world); a0, g0 = _step(m0, b); l0 = np.asarray(m0.last_stats['losses_q']).copy()
+        f0 = np.asarray(m0.finetunning_batch(b[0], b[1], b[2], b[3]))
+        lib.gm_set_fuse_agg(1)
+        assert lib.gm_get_fuse_agg() == 1
+        m1 = _meta(world); a1, g1 = _step(m1, b); l1 = np.asarray(m1.last_stats['losses_q']).copy()
+        f1 = np.asarray(m1.finetunning_batch(b[0], b[1], b[2], b[3]))
+    finally:
+        lib.gm_set_fuse_agg(-1)
+    assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and torch.equal(g0, g1)
+    assert np.array_equal(f0, f1)
