@@ -442,7 +442,7 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     static int unr = -1;
     if (unr < 0) { const char* e = getenv("GM_AGG_UNR"); unr = e ? atoi(e) : 24; }
 #define GM_AGG_CASE(U_, M_) if (unr == U_ * 10 + M_) { hipLaunchKernelGGL((k_agg_win<LPR, NCH, U_, M_>), dim3(grid), dim3(AGG_BLOCK), 0, s, a); return; }
-    GM_AGG_CASE(1, 2) GM_AGG_CASE(1, 4) GM_AGG_CASE(2, 2) GM_AGG_CASE(2, 4) GM_AGG_CASE(4, 2) GM_AGG_CASE(4, 4) GM_AGG_CASE(3, 4) GM_AGG_CASE(2, 6)
+    GM_AGG_CASE(1, 2) GM_AGG_CASE(1, 4) GM_AGG_CASE(2, 2) GM_AGG_CASE(2, 4) GM_AGG_CASE(4, 2) GM_AGG_CASE(4, 4) GM_AGG_CASE(3, 4) GM_AGG_CASE(2, 6) GM_AGG_CASE(2, 8) GM_AGG_CASE(1, 8)
 #undef GM_AGG_CASE
     hipLaunchKernelGGL((k_agg_win<LPR, NCH, 2, 4>), dim3(grid), dim3(AGG_BLOCK), 0, s, a);
 }

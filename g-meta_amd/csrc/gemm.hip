@@ -515,7 +515,7 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         SplitGemmK k{};
         k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
         k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
-        k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1;
+        k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;
         // persistent: one workgroup per CU (it fills the CU's register file, so nothing else co-resides).  GM_GEMM_SPLIT_GRID caps the
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
         static int grid_cap = -1;

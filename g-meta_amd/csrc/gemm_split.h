@@ -48,6 +48,7 @@ struct SplitGemmK {
     int dephase;                               // k_gemm_split_h: s_sleep(127) count for the second-slot workgroups
     // k_gemm_split_p<true> (fused aggregate + GEMM): A / lda address the aggregate's INPUT rows, f2 is the per-row source table, rows
     // flagged GM_SPLIT_FUSE_SELF read their finished aggregate from zside (row stride ldz), rows without a source read zeros
+    float* zero_out;                           // optional [rows, ldc]: the epilogue also zero-fills this buffer's tile (dQ of the backward pass that follows)
     const int4* f2; const float* zside; int64_t ldz; const float* zrow;     // zrow: >= K zero floats (rows flagged GM_SPLIT_FUSE_ZERO)
 };
 #define GM_SPLIT_FUSE_SELF 0x40000000
@@ -914,6 +915,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     } else {
                         *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
                     }
+                    if (g.zero_out) *reinterpret_cast<float4*>(g.zero_out + row * g.ldc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }

@@ -354,6 +354,7 @@ struct PlaneDir {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     PlaneDir* pd;                // non-NULL inside gm_meta_step
+    int dq_zeroed = 0;           // the last forward GEMM already zero-filled bufA (= dQ) for the head/loss launch that follows
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
     uint16_t* Wsplit;            // per-task weights of the GEMM being launched as three bf16 planes (split-bf16 kernel, gemm_split.h)
     float* WTl[GM_MAX_GCN];      // per-task transposed weights of layer l >= 1, [set][fo][fi]: B of the dZ GEMM (dense backward)
@@ -472,7 +473,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
             const bool split_ok = c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0;
-            const bool fuse = fwd_only && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
+            const bool fuse = fwd_only == 1 && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
                               (!gather || (b->store->feat_ld % 4 == 0 && b->store->feat_ld >= fi));
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
@@ -483,9 +484,12 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                     a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
                     // SURVEY 8(d)'s B_agg restricted to what this launch touches: every indptr entry, the indices / norms of the rows it writes,
                     // those rows (written once) and their sources (read once: the high-degree rows of a subgraph reach ~all of its rows)
-                    const int64_t pb = 4 * (b->rows + 1) + 4 * b->unfused_edges + 4 * b->unfused_rows + 4 * b->unfused_rows * (int64_t)fi +
-                                       4 * std::min<int64_t>(b->unfused_edges, gather ? std::min<int64_t>(b->rows, b->store->total_nodes) : b->rows) * (int64_t)fi;
-                    gm_prof_agg_begin(st, pb); gm_prof_note(GM_PROF_AGG_STRICT, pb);
+                    const int64_t pb0 = 4 * (b->rows + 1) + 4 * b->unfused_edges + 4 * b->unfused_rows + 4 * b->unfused_rows * (int64_t)fi;
+                    const int64_t src = std::min<int64_t>(b->unfused_edges, b->rows);
+                    const int64_t pb = pb0 + 4 * src * (int64_t)fi;
+                    // strict HBM pricing as for the full launches: a gather launch reads at most the whole (cache-resident) feature table
+                    const int64_t pbs = pb0 + 4 * (gather ? std::min<int64_t>(src, b->store->total_nodes) : src) * (int64_t)fi;
+                    gm_prof_agg_begin(st, pb); gm_prof_note(GM_PROF_AGG_STRICT, pbs);
                     GM_TRY(gm_launch_aggregate(a, st));
                     gm_prof_agg_end(st);
                 } else {
@@ -502,12 +506,14 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
-            g.relu_bits = fwd_only ? nullptr : c.M[l];
+            g.relu_bits = fwd_only == 1 ? nullptr : c.M[l];
             if (split_ok) {
                 uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 0) : nullptr;      // left by the reduction that wrote these weights
                 if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
                 g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
             }
+            // fwd_only == 2: the head + loss + backward follow (gm_meta_step): the last layer's GEMM zero-fills dQ on its way out instead of a memset launch
+            if (fwd_only == 2 && l == L.n_gcn - 1 && g.Bsplit && fo == L.dims[L.n_gcn]) { g.zero_out = c.bufA; c.dq_zeroed = 1; }
             if (fuse) {
                 g.zside = c.Z[l]; g.ldz = fi;
                 if (gather) { g.A = b->store->d_feat; g.lda = b->store->feat_ld; g.fuse2 = b->d_fuse2_feat; }
@@ -895,7 +901,8 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
         else if (sparse && sparse_bwd_ok(L)) Gc = c.cG2;
         else {
             dQ = c.bufA;
-            GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[L.n_gcn], st));
+            if (c.dq_zeroed) c.dq_zeroed = 0;
+            else GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[L.n_gcn], st));
         }
     }
     HeadK hk = make_head(c, params, pstride);
@@ -1134,7 +1141,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     // One support step (meta.py:122-126,145-151): forward -> [head + proto_loss_spt + head backward, one launch] -> backward,
     // with the SGD step w_next = w - lr * grad written by the kernels that produce each gradient.
     auto spt_step = [&](int k, const float* w, int64_t wstride, float* w_next) -> int {
-        GM_TRY(gcn_forward(p.S, w, wstride, p.logit_s, st, hoist, 1));
+        GM_TRY(gcn_forward(p.S, w, wstride, p.logit_s, st, hoist, 1, (sparse && sparse_bwd_ok(p.L)) ? 0 : 2));
         p.S.sgd = SgdK{w, wstride, w_next, Pp, hp->update_lr};
         ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr, 0, p.tab_s};
         GM_TRY(head_loss(p.S, w, wstride, p.logit_s, pk, 1, p.g, Pp, sparse, st));
@@ -1170,7 +1177,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
         wait(sq, e_fw);
         const bool last = hp->need_meta_grad && k == K - 1;
-        GM_TRY(qry_fwd(fw(k + 1), Pp, last ? 0 : 1));                     // only the last evaluation is differentiated
+        GM_TRY(qry_fwd(fw(k + 1), Pp, last ? ((sparse && sparse_bwd_ok(p.L)) ? 0 : 2) : 1));       // only the last evaluation is differentiated
         GM_TRY(qry_loss(fw(k + 1), Pp, k + 1, k, last));
         if (last) {
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
