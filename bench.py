@@ -370,6 +370,7 @@ def main():
         gemm_mode = ('split-bf16: large N=256 launches on v_mfma_f32_32x32x16_bf16 with every fp32 operand split exactly into three bf16 pieces, six '
                      'products, fp32 accumulation (error vs fp64 <= the fp32 fmaf chain\'s; DESIGN.md section 4); other launches exact fp32'
                      if lib.gm_get_gemm_mode() == 1 else 'exact fp32 (v_mfma_f32_32x32x2_f32) everywhere')
+        fused = lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1 and not (a.cone or a.hoist_z1)
         out = {
             'metric': 'meta-tasks/sec (inner-loop fwd+bwd) at task_num=%d' % T, 'value': round(T / (ms_per_step * 1e-3), 3),
             'unit': 'meta-tasks/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
@@ -385,6 +386,7 @@ def main():
                        'schedule': ('hoist_z1 ' if a.hoist_z1 else '') + ('cone (receptive-field rows only, forward and backward)' if a.cone else
                                     'sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
                                     'full (reference-equivalent: every forward/backward dense over all subgraph rows)'),
+                       'fused_aggregate_gemm': bool(fused),
                        'streams': 1 if a.serialize else 2,
                        'readback': 'deferred by one step (Meta.forward_deferred)' if a.defer else 'every step (Meta.forward returns the accuracies)',
                        'parallelism': 'tasks sharded over %d rank(s) (rank 0: %d of %d), one all-reduce of the meta-gradient per step' % (world, hi - lo, T),
@@ -401,7 +403,12 @@ def main():
                          'algorithmic_bytes_per_launch': agg_bytes // max(agg_n, 1),
                          'measured': 'HIP events on the launch stream over %s' % ('the timed region (serialize=1)' if a.serialize else
                                      '%d serialised steps run right after the timed region' % a.roofline_steps),
-                         'achieved_while_overlapped': round(ov_bytes / (ov_ms * 1e-3) / 1e9, 1) if ov_ms > 0 else None},
+                         'achieved_while_overlapped': round(ov_bytes / (ov_ms * 1e-3) / 1e9, 1) if ov_ms > 0 else None,
+                         'launch_mix': ('full launches (support chain, the differentiated query pass) AND the partial launches of the forward-only query passes, '
+                                        'whose 0..2-source rows are aggregated inside the fused aggregate+GEMM kernel: those launches are priced with B_agg '
+                                        'restricted to what they touch (every indptr entry; indices, norms and output rows of the >=3-source rows; their '
+                                        'sources read once = min(edges, rows) rows).  GM_FUSE_AGG=0 gives the all-full-launch sample of the earlier rounds.')
+                                       if fused else 'full launches only (fused aggregate+GEMM off or not applicable to this schedule)'},
         }
         if mm[1][0] > 0:
             def tf(c):

@@ -915,7 +915,12 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     } else {
                         *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
                     }
-                    if (g.zero_out) *reinterpret_cast<float4*>(g.zero_out + row * g.ldc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (g.zero_out) {                       // zeros made here: a loop-invariant zero quad gets hoisted and, at 128 VGPRs, spilled
+                        typedef float f4z __attribute__((ext_vector_type(4)));
+                        f4z z;
+                        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z.x), "=v"(z.y), "=v"(z.z), "=v"(z.w));
+                        *reinterpret_cast<f4z*>(g.zero_out + row * g.ldc + col) = z;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
