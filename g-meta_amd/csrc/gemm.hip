@@ -526,9 +526,13 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             GM_REQUIRE(a.K <= 4096, GM_EINVAL, "gemm: fused aggregate supports K <= 4096");
             k.f2 = reinterpret_cast<const int4*>(a.fuse2); k.zside = a.zside; k.ldz = a.ldz; k.zrow = gm_zero_row(s);
             GM_REQUIRE(k.zrow, GM_EHIP, "gemm: zero row allocation failed");
-            hipLaunchKernelGGL(k_gemm_split_p<true>, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+            hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
         } else {
-            hipLaunchKernelGGL(k_gemm_split_p<false>, dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+            // a launch that would leave more than half of the CUs without a tile walks 64-row half tiles: half the MFMA chain per workgroup
+            static int half_on = -1;
+            if (half_on < 0) { const char* e = getenv("GM_GEMM_HALF_TILES"); half_on = e ? atoi(e) : 1; }
+            if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
+            else hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
         }
         GM_HIP(hipGetLastError());
         return GM_OK;

@@ -589,23 +589,30 @@ __global__ __launch_bounds__(640 + 64 * FC_NB) void k_gemm_split_fc(SplitGemmK g
 #ifndef PF_DA
 #define PF_DA 4
 #endif
-template <bool GATHER>
+template <bool GATHER, int MI>
 __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
-    constexpr int BK = 16, BN = 256, WC = 4;
-    constexpr int A_OCT = GS_BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
+    // MI = 2: 128-row tiles (each compute wave a 64 x 64 block); MI = 1: 64-row HALF tiles (32 x 64 per wave) for launches that would
+    // leave more than half of the CUs without a tile -- a small batch is bound by one tile's MFMA chain, not by throughput
+    constexpr int BK = 16, BN = 256, WC = 4, BM = 64 * MI;
+    constexpr int A_OCT = BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
     constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;                                  // 12 + 24 KiB
     constexpr int EP_LD = 68, E_WAVE = 32 * EP_LD * 4;                                // 8704 B per compute wave
     constexpr int OFF_E = 2 * STAGE, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
-    constexpr int A_PER = (GS_BM * BK / 4) / 256;                                     // float4 per A-feeder lane and chunk: 2 (four feeder waves)
+    constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
     constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6
     __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = g.K / BK;
     const int G = gridDim.x, b = blockIdx.x;
     // XCD-contiguous tile order over this launch: hardware id t -> logical tile
-    const int nb = g.n_tiles, q8 = nb / 8, r8 = nb % 8;
+    const int nb = g.n_tiles * (2 / MI), q8 = nb / 8, r8 = nb % 8;
     auto logical = [&](int t) -> int { const int x = t % 8, i = t / 8; return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; };
     const int ntb = b < nb ? (nb - b + G - 1) / G : 0;                                // tiles of this workgroup
+    auto tile_of = [&](int w) -> GsTile {                                             // hardware work id -> {set, row0, nrows} of its (half) tile
+        const int lt = logical(w);
+        if constexpr (MI == 2) return gs_tile(g.tiles, lt);
+        else { GsTile t = gs_tile(g.tiles, lt >> 1); const int h = (lt & 1) * 64; t.row0 += h; t.nrows = max(0, min(64, t.nrows - h)); return t; }
+    };
     const int total = ntb * nchunks;                                                  // flattened chunk count
     const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
     float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
@@ -633,9 +640,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
         // chunks are issued in order: (tile, chunk) counters instead of a division per chunk, the tile's set looked up once per tile
         int ib_c = 0, ib_ti = 0;
-        uint64_t ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b)).set * g.bt_stride);
+        uint64_t ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)tile_of(b).set * g.bt_stride);
         auto issue_b = [&](int gc) {                                                  // global chunk gc (= the next in order) -> stage gc & 1
-            if (ib_c == nchunks) { ib_c = 0; ++ib_ti; ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)gs_tile(g.tiles, logical(b + ib_ti * G)).set * g.bt_stride); }
+            if (ib_c == nchunks) { ib_c = 0; ++ib_ti; ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)tile_of(b + ib_ti * G).set * g.bt_stride); }
             const uint64_t base = ib_base + (uint64_t)(ib_c * b_chunk_bytes);
             ++ib_c;
             const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
@@ -666,7 +673,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         // ================= A feeder
         __builtin_amdgcn_s_setprio(3);
         const int ft = tid - 512;                                                     // 0..255
-        const int rr[A_PER] = {ft >> 2, (ft + 256) >> 2};
+        int rr[A_PER];
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) rr[p] = (ft + p * 256) >> 2;
         const int c4 = (ft & 3) * 4;
         int adst[A_PER];
 #pragma unroll
@@ -685,12 +694,14 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const bool fast_consts = nchunks >= PF_DA;                                    // the const registers are reused every nchunks chunks
         int la_c = 0, la_ti = 0;
         const float* la_src[A_PER][NJ];
-        float w_next[A_PER][2] = {{1.f, 0.f}, {1.f, 0.f}}, w_cur[A_PER][2] = {{1.f, 0.f}, {1.f, 0.f}};
-        i4v fq[A_PER] = {};
+        float w_next[A_PER][2], w_cur[A_PER][2];
+        i4v fq[A_PER];
+#pragma unroll
+        for (int p = 0; p < A_PER; ++p) { w_next[p][0] = w_cur[p][0] = 1.f; w_next[p][1] = w_cur[p][1] = 0.f; fq[p] = i4v{0, 0, 0, 0}; }
         float rc_sc = 1.f, rc_b = 0.f;
         auto fq_prefetch = [&](int ti) {                                              // table entries of tile ti (if any) -> fq, counted loads
             if (ti >= ntb) return;
-            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            const GsTile t = tile_of(b + ti * G);
 #pragma unroll
             for (int p = 0; p < A_PER; ++p) {
                 const int4* q = g.f2 + t.row0 + min(rr[p], t.nrows - 1);
@@ -698,9 +709,10 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             }
         };
         auto la_tile = [&](int ti, bool consts) {
-            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            const GsTile t = tile_of(b + ti * G);
             if constexpr (GATHER) {
-                asm volatile("" : "+v"(fq[0]), "+v"(fq[1]) :: "memory");            // fetched a tile ago; every wait since then covered them
+                if constexpr (A_PER == 2) asm volatile("" : "+v"(fq[0]), "+v"(fq[A_PER - 1]) :: "memory");   // fetched a tile ago; every wait since then covered them
+                else asm volatile("" : "+v"(fq[0]) :: "memory");
 #pragma unroll
                 for (int p = 0; p < A_PER; ++p) {
 #pragma unroll
@@ -717,11 +729,15 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 for (int p = 0; p < A_PER; ++p) la_src[p][0] = g.A + (int64_t)(t.row0 + min(rr[p], t.nrows - 1)) * g.lda + c4;
             }
             if (consts) {
-                if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & 127, t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
+                if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & (BM - 1), t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
                 if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + ft; asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
             }
         };
-        if constexpr (GATHER) { fq_prefetch(0); asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0]), "+v"(fq[1]) :: "memory"); }
+        if constexpr (GATHER) {
+            fq_prefetch(0);
+            if constexpr (A_PER == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0]), "+v"(fq[A_PER - 1]) :: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0]) :: "memory");
+        }
         la_tile(0, false);
         if constexpr (GATHER) {
 #pragma unroll
@@ -749,7 +765,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             }
             if (sa_c == 0 && sa_ti > 0 && fast_consts) {                               // first chunk of a later tile: its consts arrived with (before) this chunk's loads
                 asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
-                if (ft < GS_BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
+                if (ft < BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
                 biasl[(sa_ti & 1) * BN + ft] = rc_b;
             }
             ++sa_c;
@@ -776,20 +792,22 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         };
         // row scales + bias of tile ti -> LDS (parity ti & 1); ordinary loads, completed with the vmcnt(0) below
         auto stage_tile_consts = [&](int ti) {
-            const GsTile t = gs_tile(g.tiles, logical(b + ti * G));
+            const GsTile t = tile_of(b + ti * G);
             const int set = t.set, row0 = t.row0, nrows = t.nrows;
             float sc = 1.f;
-            if (g.row_scale) sc = g.row_scale[row0 + min(ft & 127, nrows - 1)];
+            if (g.row_scale) sc = g.row_scale[row0 + min(ft & (BM - 1), nrows - 1)];
             float b0 = 0.f;
             if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[ft];
-            if (ft < GS_BM) scales[(ti & 1) * GS_BM + ft] = sc;
+            if (ft < BM) scales[(ti & 1) * GS_BM + ft] = sc;
             biasl[(ti & 1) * BN + ft] = b0;
         };
-        static_assert(A_PER == 2 && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 2 rows per lane and chunk");
+        static_assert((A_PER == 1 || A_PER == 2) && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 1 or 2 rows per lane and chunk");
 #define PF_WAIT_SLOT(NEWER, SLOT)                                                                                                              \
         do {                                                                                                                                   \
-            if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][1][0]), "+v"(ra[SLOT][0][NJ - 1]), "+v"(ra[SLOT][1][NJ - 1]) : "n"((NEWER) * 4) : "memory"); \
-            else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][1][0]) : "n"((NEWER) * 2) : "memory");             \
+            if constexpr (GATHER && A_PER == 2) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][A_PER - 1][0]), "+v"(ra[SLOT][0][NJ - 1]), "+v"(ra[SLOT][A_PER - 1][NJ - 1]) : "n"((NEWER) * 4) : "memory"); \
+            else if constexpr (GATHER) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][0][NJ - 1]) : "n"((NEWER) * 2) : "memory"); \
+            else if constexpr (A_PER == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(ra[SLOT][0][0]), "+v"(ra[SLOT][A_PER - 1][0]) : "n"((NEWER) * 2) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ra[SLOT][0][0]) : "n"((NEWER) * 1) : "memory");                                 \
         } while (0)
         stage_tile_consts(0);                                                          // (compiler-managed loads: done before the asm loads below are counted)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -829,7 +847,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     } else {
         // ================= compute
         const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
-        const int a_lane = kh * A_OCT + (wr * 64 + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        const int a_lane = kh * A_OCT + (wr * 32 * MI + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
         float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
         const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
@@ -842,9 +860,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             for (int p = 0; p < 3; ++p) bfx[j][p] = *reinterpret_cast<const gm_bf16x8*>(smem + b_lane + p * B_PLANE + j * 512);
 #endif
         for (int ti = 0; ti < ntb; ++ti) {
-            gm_f32x16 acc[2][2];
+            gm_f32x16 acc[MI][2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -853,7 +871,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 PF_T(gc, 0);
                 const char* S = smem + (gc & 1) * STAGE;
 #ifdef PF_EXP_NOBLDS
-                gm_bf16x8 af[2][3];
+                gm_bf16x8 af[MI][3];
                 static_assert(true, "");
                 gm_bf16x8 bf[2][3];
 #pragma unroll
@@ -861,10 +879,10 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bf[j][p] = bfx[j][p];
 #else
-                gm_bf16x8 af[2][3], bf[2][3];
+                gm_bf16x8 af[MI][3], bf[2][3];
 #endif
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
 #ifndef PF_EXP_NOBLDS
@@ -874,7 +892,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
 #endif
 #define PF_PROD(PA, PB)                                                                                                  \
-                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)               \
+                _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
                 PF_PROD(2, 0) PF_PROD(0, 2) PF_PROD(1, 1) PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)
 #undef PF_PROD
@@ -883,13 +901,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 PF_T(gc, 3);
             }
             // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
-            const GsTile tl = gs_tile(g.tiles, logical(b + ti * G));                // scalar (SMEM) loads: lgkmcnt, not vmcnt
+            const GsTile tl = tile_of(b + ti * G);                // scalar (SMEM) loads: lgkmcnt, not vmcnt
             const int row0 = tl.row0, nrows = tl.nrows;
             const float* sc_t = scales + (ti & 1) * GS_BM;
             const int col = wc * 64 + ec;
             const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -897,7 +915,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    const int rl = wr * 64 + i * 32 + it * 4 + er;
+                    const int rl = wr * 32 * MI + i * 32 + it * 4 + er;
                     if (rl >= nrows) continue;
                     const int64_t row = row0 + rl;
                     const float sc = sc_t[rl];

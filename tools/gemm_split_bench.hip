@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
     auto launch = [&]() {
         if (roll) { static const int cap = getenv("GS_GRID") ? atoi(getenv("GS_GRID")) : 256; hipLaunchKernelGGL(k_gemm_split_r, dim3(std::min(g.n_tiles, cap)), dim3(1024), 0, 0, g); return; }
         if (halfk) { hipLaunchKernelGGL(k_gemm_split_h, dim3(std::min(2 * g.n_tiles, 512)), dim3(512), 0, 0, g); return; }
-        if (pers) { static const int cap = getenv("GS_GRID") ? atoi(getenv("GS_GRID")) : 256; hipLaunchKernelGGL(k_gemm_split_p<false>, dim3(std::min(g.n_tiles, cap)), dim3(1024), 0, 0, g); return; }
+        if (pers) { static const int cap = getenv("GS_GRID") ? atoi(getenv("GS_GRID")) : 256; if (getenv("GS_HALF")) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(std::min(2 * g.n_tiles, cap)), dim3(1024), 0, 0, g); else hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(g.n_tiles, cap)), dim3(1024), 0, 0, g); return; }
         if (fc) { hipLaunchKernelGGL(k_gemm_split_fc, dim3(g.n_tiles * g.n_col_tiles), dim3(640 + 64 * FC_NB), 0, 0, g); return; }
         if (BK == 32) { printf("BK=32 removed\n"); exit(1); }
         else { if (WC == 4) run<4, 16>(g, 0); else if (WC == 2) run<2, 16>(g, 0); else run<1, 16>(g, 0); }
