@@ -287,3 +287,23 @@ def test_fused_aggregate_gemm_is_bitwise_the_unfused_pass(world):
         lib.gm_set_fuse_agg(-1)
     assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and torch.equal(g0, g1)
     assert np.array_equal(f0, f1)
+
+
+@pytest.mark.parametrize('tasks', [1, 3])
+def test_fused_aggregate_gemm_bitwise_on_small_task_counts(world, tasks):
+    """Same as above on 1- and 3-task batches (36k / 107k query rows: workgroups of the persistent kernel get one or two tiles, sets end
+    in partial tiles) and through the one-stream path: the counted prefetch queues of the fused feeders at their boundary cases."""
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    b = world['db'].get_batch(list(range(tasks)))
+    out = []
+    try:
+        for fuse in (0, 1):
+            lib.gm_set_fuse_agg(fuse)
+            m = _meta(world, serialize=1 if tasks == 1 else 0)
+            a, g = _step(m, b)
+            out.append((a, g, np.asarray(m.last_stats['losses_q']).copy(), np.asarray(m.finetunning_batch(b[0], b[1], b[2], b[3]))))
+    finally:
+        lib.gm_set_fuse_agg(-1)
+    (a0, g0, l0, f0), (a1, g1, l1, f1) = out
+    assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and torch.equal(g0, g1) and np.array_equal(f0, f1)
