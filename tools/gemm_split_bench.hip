@@ -6,8 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
-#define GS_EXPERIMENTS
-#include "../g-meta_amd/csrc/gemm_split.h"
+#include "gemm_split_experiments.h"     // includes g-meta_amd/csrc/gemm_split.h + the prototype kernels
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s failed: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
