@@ -314,6 +314,37 @@ def main():
             extra['exact_f32_mfma_gemm'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
                                             'what': 'default schedule with GM_GEMM_MODE=f32: every update GEMM on v_mfma_f32_32x32x2_f32'}
             lib.gm_set_gemm_mode(1)
+        if lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1:
+            # the same schedule with every pass writing Z (fused aggregate + GEMM off): step time, and the aggregate's roofline over an
+            # all-full-launch sample -- the figure of the earlier rounds (the large query launches are aggregate launches again)
+            lib.gm_set_fuse_agg(0)
+            step(0); drain()
+            torch.cuda.synchronize(); te = time.perf_counter()
+            for k in range(a.extra_steps):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
+            extra['unfused_aggregate'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
+                                          'what': 'default schedule with GM_FUSE_AGG=0: every forward pass writes Z_l and runs the plain GEMM'}
+            if a.roofline_steps > 0:
+                lib.gm_profile_enable(1)
+                maml.serialize = 1
+                step(0); drain()
+                u_ms, u_n, u_by = 0.0, 0, 0
+                for k in range(a.roofline_steps):
+                    step(k); drain()
+                    ms, n, by = prof_read()
+                    u_ms += ms; u_n += n; u_by += by
+                maml.serialize = 0
+                lib.gm_profile_enable(0)
+                if u_ms > 0:
+                    u_ach = u_by / (u_ms * 1e-3) / 1e9
+                    extra['unfused_aggregate']['roofline'] = {'kernel': 'k_agg, full launches only', 'achieved': round(u_ach, 1), 'unit': 'GB/s',
+                                                              'frac': round(u_ach / HBM_PEAK_GBS, 4), 'launches_measured': u_n,
+                                                              'avg_launch_ms': round(u_ms / max(u_n, 1), 4),
+                                                              'algorithmic_bytes_per_launch': u_by // max(u_n, 1)}
+            lib.gm_set_fuse_agg(-1)
         lv = {}
         for side, x in (('spt', batches[0][0][0].view_of), ('qry', batches[0][2][0].view_of)):      # what the cone schedule touches
             ok = C.c_int32(); nr = (C.c_int64 * (cfg['h'] + 1))(); ne = (C.c_int64 * (cfg['h'] + 1))()
