@@ -1032,6 +1032,67 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
     }
 }
 
+// The same reduction for the fast-weight chains of gm_meta_step, where the updated weights also leave as split-bf16 operand planes
+// (K % 8 == 0, N % 32 == 0): a block owns an 8 (k) x 32 (n) patch of W, so that a k-octet of one column (forward planes [k/8][n][8])
+// and an n-octet of one row (dZ planes [n/8][k][8]) are each ONE 16-byte store instead of eight scattered 2-byte ones -- the
+// element-per-thread version spent more time on those stores than on the partial sums.  Blocks past the patches reduce db.
+__global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, const int32_t* set_chunk_off, int K, int N, float* dW, int64_t dw_stride,
+                                                          float* db, int64_t db_stride, WgradSgd u) {
+    __shared__ uint16_t pl[3][8][40];                       // [plane][k in patch][n in patch], rows padded to 80 B
+    const int set = blockIdx.y, tid = threadIdx.x;
+    const int c0 = set_chunk_off[set], c1 = set_chunk_off[set + 1];
+    const int KN = K * N, tot = KN + N, npn = N / 32, n_patch = (K / 8) * npn;
+    auto sum_of = [&](int j) -> float {
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int c = c0;
+        for (; c + 8 <= c1; c += 8) {
+#pragma unroll
+            for (int u_ = 0; u_ < 8; ++u_) s8[u_] += partial[(int64_t)(c + u_) * tot + j];
+        }
+        for (int u_ = 0; c < c1; ++c, ++u_) s8[u_] += partial[(int64_t)c * tot + j];
+        return ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));      // same order as k_wgrad_reduce
+    };
+    if ((int)blockIdx.x >= n_patch) {                       // db (and the bias step)
+        const int n = ((int)blockIdx.x - n_patch) * 256 + tid;
+        if (n < N && db) {
+            const float s = sum_of(KN + n);
+            db[(int64_t)set * db_stride + n] = s;
+            if (u.next) u.next[(int64_t)set * u.next_stride + u.b_off + n] = u.cur[(int64_t)set * u.cur_stride + u.b_off + n] - u.lr * s;
+        }
+        return;
+    }
+    const int kb = blockIdx.x / npn, nb = blockIdx.x - kb * npn, tk = tid >> 5, tn = tid & 31;
+    const int k = kb * 8 + tk, n = nb * 32 + tn, j = k * N + n;
+    const float s = sum_of(j);
+    dW[(int64_t)set * dw_stride + j] = s;
+    if (!u.next) return;                                    // (uniform)
+    const float wn = u.cur[(int64_t)set * u.cur_stride + u.w_off + j] - u.lr * s;
+    u.next[(int64_t)set * u.next_stride + u.w_off + j] = wn;
+    if (u.wt) u.wt[(int64_t)set * KN + (int64_t)n * K + k] = wn;
+    if (!(u.pl_fwd || u.pl_dz)) return;                     // (uniform)
+    const uint32_t bx = __float_as_uint(wn), bh = bx & 0xffff0000u;
+    const float r1 = wn - __uint_as_float(bh);
+    const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
+    const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
+    pl[0][tk][tn] = (uint16_t)(bh >> 16); pl[1][tk][tn] = (uint16_t)(bm >> 16); pl[2][tk][tn] = (uint16_t)(bl >> 16);
+    __syncthreads();
+    if (tid < 96 && u.pl_fwd) {                             // forward planes: unit (plane, n) = the patch's 8 k of column n
+        const int p = tid >> 5, c = tid & 31;
+        uint16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = pl[p][q][c];
+        uint4 w4 = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
+        *reinterpret_cast<uint4*>(u.pl_fwd + (int64_t)set * 3 * KN + (int64_t)p * KN + ((int64_t)kb * N + nb * 32 + c) * 8) = w4;
+    } else if (tid >= 128 && tid < 224 && u.pl_dz) {        // dZ planes: unit (plane, k, n-octet) = 8 consecutive n of row k
+        const int t = tid - 128, p = t >> 5, r = t & 31, kk = r >> 2, no = r & 3;
+        uint16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = pl[p][kk][no * 8 + q];
+        uint4 w4 = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
+        *reinterpret_cast<uint4*>(u.pl_dz + (int64_t)set * 3 * KN + (int64_t)p * KN + (((int64_t)(nb * 4 + no)) * K + kb * 8 + kk) * 8) = w4;
+    }
+}
+
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     gm_prof_begin(GM_PROF_WGRAD, s, 2 * a.rows * a.K * a.N);
@@ -1074,8 +1135,13 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     if (launched) {
         GM_HIP(hipGetLastError());
         const int tot = (a.K + 1) * a.N;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
-                           a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
+        if ((sgd.pl_fwd || sgd.pl_dz) && a.K % 8 == 0 && a.N % 32 == 0) {
+            hipLaunchKernelGGL(k_wgrad_reduce_pl, dim3((a.K / 8) * (a.N / 32) + (a.N + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+                               a.K, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
+        } else {
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
+                               a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
+        }
         GM_HIP(hipGetLastError());
         return GM_OK;
     }
