@@ -346,7 +346,10 @@ __global__ void k_fuse2(const int32_t* indptr, const int32_t* indices, int64_t r
         if (d > GM_FUSE_MAXDEG) { ++nr; ne += (unsigned long long)d; }
         f2[r] = t; f2_feat[r] = tf;
     }
-    if (nr) { atomicAdd(counts, nr); atomicAdd(counts + 1, ne); }
+    // one pair of atomics per wave, not per thread (92k contended atomics took longer than the table itself)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { nr += __shfl_down(nr, off, 64); ne += __shfl_down(ne, off, 64); }
+    if ((threadIdx.x & 63) == 0 && nr) { atomicAdd(counts, nr); atomicAdd(counts + 1, ne); }
 }
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
@@ -475,7 +478,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
         unsigned long long* d_counts = nullptr; unsigned long long h_counts[2] = {0, 0};
         GM_TRY(gm_alloc(&d_counts, 2, s));
         GM_HIP(hipMemsetAsync(d_counts, 0, 16, s));
-        hipLaunchKernelGGL(k_fuse2, dim3((int)std::min<int64_t>(4096, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, b->d_norm,
+        hipLaunchKernelGGL(k_fuse2, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, b->d_norm,
                            b->d_feat_row, f0, ff, d_counts);
         GM_HIP(hipGetLastError());
         GM_HIP(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
