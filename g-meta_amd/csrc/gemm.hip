@@ -526,13 +526,24 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             GM_REQUIRE(a.K <= 4096, GM_EINVAL, "gemm: fused aggregate supports K <= 4096");
             k.f2 = reinterpret_cast<const int4*>(a.fuse2); k.zside = a.zside; k.ldz = a.ldz; k.zrow = gm_zero_row(s);
             GM_REQUIRE(k.zrow, GM_EHIP, "gemm: zero row allocation failed");
-            hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+            // Workgroup lifetime: a strictly persistent grid (one workgroup per CU for the whole launch) holds every CU for ~0.65 ms on the
+            // large query launches, and nothing co-resides with it (it fills the register file) -- the support chain's small kernels then wait
+            // a whole GEMM for a CU (head/loss: 26 us of work, 680 us in the two-stream timeline).  `mult` workgroups per CU, each walking
+            // 1/mult of the tiles, give the dispatcher a yield point every ~0.65/mult ms (default 4: 27.7 -> 27.4 ms at task_num 32, 5.12 -> 4.86 ms
+            // for the 4-task shard, where the support chain is the critical path; 8 and more lose to the per-workgroup prologue).
+            static int mult_f = -1;
+            if (mult_f < 0) { const char* e = getenv("GM_GEMM_FUSED_ROUNDS"); mult_f = e ? atoi(e) : 4; if (mult_f < 1) mult_f = 1; }
+            hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
         } else {
             // a launch that would leave more than half of the CUs without a tile walks 64-row half tiles: half the MFMA chain per workgroup
             static int half_on = -1;
             if (half_on < 0) { const char* e = getenv("GM_GEMM_HALF_TILES"); half_on = e ? atoi(e) : 1; }
             if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
-            else hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, grid_cap)), dim3(1024), 0, s, k);
+            else {
+                static int mult_p = -1;
+                if (mult_p < 0) { const char* e = getenv("GM_GEMM_PLAIN_ROUNDS"); mult_p = e ? atoi(e) : 1; if (mult_p < 1) mult_p = 1; }
+                hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, mult_p * grid_cap)), dim3(1024), 0, s, k);
+            }
         }
         GM_HIP(hipGetLastError());
         return GM_OK;
