@@ -174,3 +174,22 @@ def test_nominal_size_configs_match_oracle(name):
         o = orc.finetune(w['og'], w['data']['feats'], w['ob']['spt'][t], w['ob']['qry'][t], np.asarray(b[1][t]), np.asarray(b[3][t]), theta1, w['config'],
                          w['args'].k_spt, w['args'].update_lr, K)
         np.testing.assert_allclose(ft[t], o, atol=1e-6)
+
+
+def test_arxiv_finetunning_matches_oracle(arxiv):
+    """Meta.finetunning_batch at the arxiv shape (every query pass is forward-only: the fused aggregate + GEMM kernel carries all of
+    them) against the oracle's per-task finetunning loop (meta.py:175-234) on the task holding the largest sampled subgraph and one more."""
+    import gmeta_amd
+    w = arxiv
+    torch.manual_seed(11)
+    m = gmeta_amd.Meta(w['args'], w['config']).to('cuda')
+    theta = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+    b = w['batch']
+    ft = m.finetunning_batch(b[0], b[1], b[2], b[3])
+    sizes = np.diff(w['Q'].sub_off)
+    so = w['Q'].set_sub_off
+    t_hub = int(np.searchsorted(so, int(np.argmax(sizes)), side='right') - 1)
+    for t in sorted({t_hub, (t_hub + 5) % w['T']}):
+        o = orc.finetune(w['og'], w['data']['feats'], w['ob']['spt'][t], w['ob']['qry'][t], np.asarray(b[1][t]), np.asarray(b[3][t]), theta, w['config'],
+                         w['args'].k_spt, w['args'].update_lr, K)
+        np.testing.assert_allclose(ft[t], o, atol=1e-6)
