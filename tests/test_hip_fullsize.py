@@ -1,8 +1,8 @@
 """GPU (-m gpu): the HIP path at BASELINE.json's full sizes (arxiv shape: 169,343-node graph, F0=128, h=2, hidden 256,
-3-way 3-shot 24-query, sample_nodes=1000), checked through size-independent properties -- the oracle is far too slow
-here (seconds per task), so: extraction invariants + CSR transpose consistency (bit-exact integer work), aggregate
-linearity / degree identity / adjointness <A x, y> = <x, A^T y>, batched == per-task, stream-mode and run-to-run
-determinism, hoisted == full schedule."""
+3-way 3-shot 24-query, sample_nodes=1000), checked through size-independent properties (the floats of the same
+shapes are compared with the oracle in test_hip_fullsize_oracle.py, the headline T=32 / K=10 configuration included):
+extraction invariants + CSR transpose consistency (bit-exact integer work), aggregate linearity / degree identity /
+adjointness <A x, y> = <x, A^T y>, batched == per-task, stream-mode and run-to-run determinism, hoisted == full schedule."""
 import ctypes as C
 
 import numpy as np

@@ -1,12 +1,13 @@
 """GPU (-m gpu): HIP vs the oracle's FLOATS at the headline shapes, so that the kernel instantiations the bench runs are the
-ones compared -- BASELINE configs[1] (arxiv shape, T=8: the 286k-row query batch selects the 256-wide DMA GEMM, the
-8x8 / 4x8 weight-gradient tiles, the 64-row window aggregate + the hub-row kernel on sampled ~1000-node hub subgraphs)
+ones compared -- BASELINE configs[1] (arxiv shape: once EXACTLY as benched, T=32 / K=10, all 32 tasks against the oracle; and at
+T=8 / K=3 for the per-kernel tests: the 286k-row query batch selects the split-bf16 / 256-wide DMA GEMMs, the
+8x8 / 4x8 weight-gradient tiles, the 64-row window aggregate + the hub-row parts on sampled ~1000-node hub subgraphs)
 and the nominal sizes of configs[3] (Tissue shape: 24 x 2,100 nodes, in-degree ~50, F0=50, H=128, every subgraph sampled,
 in-degree ~24 inside a subgraph) and configs[4] (FirstMM shape: 41 directed graphs x 1,400 nodes, F0=5, pair centres, head
 [2, 2H]).  learner.py:25-56,134-175 / meta.py:101-173 against oracle/gmeta_oracle.py, tolerance 1e-4 (north star).
 
 The oracle walks the SAME node sets (replayed from the HIP extraction, which the other tests pin bit-exactly; a sample of
-subgraphs is re-derived here with the oracle's own k-hop + keyed sampler) because its Python extraction of 600+ sampled
+subgraphs is re-derived here with the oracle's own k-hop + keyed sampler) because its Python extraction of 600-2,600 sampled
 subgraphs would take minutes; everything after the node sets -- induced CSR, degrees, features, every float -- is its own."""
 import argparse
 import ctypes as C
@@ -23,7 +24,7 @@ TOL = 1e-4
 K = 3
 
 
-def _world(name, T):
+def _world(name, T, K=K):
     import gmeta_amd
     from gmeta_amd import synth
     np.random.seed(222); random.seed(222); torch.manual_seed(222)
@@ -43,7 +44,7 @@ def _world(name, T):
         for t in range(T):
             seeds = [tuple(int(v) for v in s) for s in db._task_arrays(t)[col]]
             ob[tag].append(orc.Batch(og, seeds, [par[off[k]:off[k + 1]] for k in range(so[t], so[t + 1])]))
-    return dict(args=args, cfg=cfg, data=data, store=store, db=db, batch=batch, config=config, og=og, S=S, Q=Q, ob=ob, T=T, link=bool(cfg.get('link')))
+    return dict(args=args, cfg=cfg, data=data, store=store, db=db, batch=batch, config=config, og=og, S=S, Q=Q, ob=ob, T=T, K=K, link=bool(cfg.get('link')))
 
 
 @pytest.fixture(scope='module')
@@ -68,6 +69,7 @@ def _check_extraction_sample(w, stride):
 
 def _meta_vs_oracle(w, tol_grad=TOL):
     import gmeta_amd
+    K = w['K']
     torch.manual_seed(11)
     m = gmeta_amd.Meta(w['args'], w['config']).to('cuda')
     theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
@@ -104,6 +106,19 @@ def test_arxiv_meta_step_floats_match_oracle(arxiv):
     sizes = np.diff(arxiv['Q'].sub_off)
     assert (sizes >= 1000).any(), 'no sampled hub subgraph in this batch'
     _meta_vs_oracle(arxiv)
+
+
+def test_arxiv_headline_config_matches_oracle():
+    """BASELINE configs[1] EXACTLY as bench.py times it -- synth.make_args('arxiv') untouched: task_num=32, update_step=10 (ten chained
+    fast-weight updates, meta.py:143-157), the 1.14 M-row query batch -- against the oracle's task_inner_loop on ALL 32 tasks
+    (~25 s of CPU): accuracies of every step <= 1e-6, losses_q of every step and theta.grad <= 1e-4 (meta.py:101-173, learner.py:25-56)."""
+    from gmeta_amd import synth
+    cfg = synth.CONFIGS['arxiv']
+    assert cfg['task_num'] == 32 and cfg['update_step'] == 10
+    w = _world('arxiv', cfg['task_num'], K=cfg['update_step'])
+    assert w['args'].task_num == 32 and w['args'].update_step == 10
+    assert w['Q'].rows > 1_000_000
+    _meta_vs_oracle(w)
 
 
 def test_arxiv_forward_backward_per_task_weights_match_oracle(arxiv):
@@ -172,7 +187,7 @@ def test_nominal_size_configs_match_oracle(name):
     ft = m.finetunning_batch(b[0], b[1], b[2], b[3])
     for t in (0, w['T'] - 1):
         o = orc.finetune(w['og'], w['data']['feats'], w['ob']['spt'][t], w['ob']['qry'][t], np.asarray(b[1][t]), np.asarray(b[3][t]), theta1, w['config'],
-                         w['args'].k_spt, w['args'].update_lr, K)
+                         w['args'].k_spt, w['args'].update_lr, w['K'])
         np.testing.assert_allclose(ft[t], o, atol=1e-6)
 
 
@@ -191,5 +206,5 @@ def test_arxiv_finetunning_matches_oracle(arxiv):
     t_hub = int(np.searchsorted(so, int(np.argmax(sizes)), side='right') - 1)
     for t in sorted({t_hub, (t_hub + 5) % w['T']}):
         o = orc.finetune(w['og'], w['data']['feats'], w['ob']['spt'][t], w['ob']['qry'][t], np.asarray(b[1][t]), np.asarray(b[3][t]), theta, w['config'],
-                         w['args'].k_spt, w['args'].update_lr, K)
+                         w['args'].k_spt, w['args'].update_lr, w['K'])
         np.testing.assert_allclose(ft[t], o, atol=1e-6)
