@@ -238,7 +238,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ov_ms, ov_n, ov_bytes = 0.0, 0, 0
-    ov_mm = {1: [0.0, 0, 0], 2: [0.0, 0, 0]}
+    MM_CATS = (1, 2, 4, 5)      # exact-fp32 GEMM / weight gradient, split-bf16 GEMM / weight gradient (gm_profile_read categories)
+    ov_mm = {c: [0.0, 0, 0] for c in MM_CATS}
     strict_bytes = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
@@ -247,7 +248,7 @@ def main():
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
         strict_bytes += prof_read(3)[2]
-        for cat in (1, 2):
+        for cat in MM_CATS:
             ms, n, fl = prof_read(cat)
             ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
     if a.defer:
@@ -265,7 +266,7 @@ def main():
     # the GPU on two streams, which stretches every kernel; the kernel-alone duration is measured on extra steps with
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
-    mm = ov_mm if a.serialize else {1: [0.0, 0, 0], 2: [0.0, 0, 0]}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
+    mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         lib.gm_profile_enable(1)
@@ -279,7 +280,7 @@ def main():
             ms, n, by = prof_read()
             agg_ms += ms; agg_n += n; agg_bytes += by
             strict_bytes += prof_read(3)[2]
-            for cat in (1, 2):
+            for cat in MM_CATS:
                 ms, n, fl = prof_read(cat)
                 mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
         maml.serialize = 0
@@ -441,25 +442,41 @@ def main():
                                         'sources read once = min(edges, rows) rows).  GM_FUSE_AGG=0 gives the all-full-launch sample of the earlier rounds.')
                                        if fused else 'full launches only (fused aggregate+GEMM off or not applicable to this schedule)'},
         }
-        if mm[1][0] > 0:
-            def tf(c):
-                return round(mm[c][2] / (mm[c][0] * 1e-3) / 1e12, 1)
-            out['mfma'] = {'note': 'update GEMMs, HIP events around every launch of the same serialised steps as the roofline; flops counted as '
-                                   '2*rows*K*N of the fp32 product (whatever MFMA passes implement it); frac = achieved / 157.3 TFLOP/s dense fp32 matrix peak',
-                           'peak_tflops': MFMA_F32_PEAK_TFLOPS, 'gemm_mode': gemm_mode,
-                           'gemm': {'achieved_tflops': tf(1), 'frac': round(tf(1) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[1][1],
-                                    'what': 'forward X@W and backward dZ = dQ@W^T'},
-                           'wgrad': {'achieved_tflops': tf(2), 'frac': round(tf(2) / MFMA_F32_PEAK_TFLOPS, 4), 'launches': mm[2][1],
-                                     'what': 'dW = (norm*Z)^T dQ, db, incl. the partial reduction'}}
+        if mm[1][0] + mm[4][0] > 0:
+            # Every launch is priced on the matrix pipe it ran on: the exact-fp32 kernels (v_mfma_f32_32x32x2_f32) against the 157.3 TFLOP/s dense
+            # fp32 matrix peak, the split-bf16 kernels -- which issue SIX bf16 MFMA flops per flop of the fp32 product -- against 2.5 PFLOP/s bf16.
+            def pipe(exact, split):
+                ms = mm[exact][0] + mm[split][0]; fl = mm[exact][2] + mm[split][2]
+                t_pk = mm[exact][2] / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3 + 6.0 * mm[split][2] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3   # ms at the peak of the pipe used
+                d = {'fp32_equivalent_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, 'launches': mm[exact][1] + mm[split][1],
+                     'frac': round(t_pk / ms, 4) if ms > 0 else None}
+                if mm[split][0] > 0:
+                    tfs = mm[split][2] / (mm[split][0] * 1e-3) / 1e12
+                    d['split_bf16'] = {'launches': mm[split][1], 'fp32_equivalent_tflops': round(tfs, 1), 'bf16_mfma_tflops': round(6 * tfs, 1),
+                                       'frac_of_bf16_peak': round(6 * tfs / MFMA_BF16_PEAK_TFLOPS, 4), 'ms_per_step': round(mm[split][0] / max(ser_steps, 1), 3)}
+                if mm[exact][0] > 0:
+                    tfe = mm[exact][2] / (mm[exact][0] * 1e-3) / 1e12
+                    d['exact_f32'] = {'launches': mm[exact][1], 'tflops': round(tfe, 1), 'frac_of_f32_peak': round(tfe / MFMA_F32_PEAK_TFLOPS, 4),
+                                      'ms_per_step': round(mm[exact][0] / max(ser_steps, 1), 3)}
+                return d, t_pk
+            g_d, g_pk = pipe(1, 4); w_d, w_pk = pipe(2, 5)
+            g_d['what'] = 'forward X@W and backward dZ = dQ@W^T'; w_d['what'] = 'dW = (norm*Z)^T dQ, db, incl. the partial reduction'
+            out['mfma'] = {'note': 'update GEMMs, HIP events around every launch of the same serialised steps as the roofline; flops counted as 2*rows*K*N of the '
+                                   'fp32 product; `frac` = time those launches would take at the dense peak of the pipe each one ran on (fp32 MFMA 157.3 TFLOP/s for '
+                                   'the exact kernels; bf16 MFMA 2.5 PFLOP/s at 6 bf16 flops per fp32 flop for the split-bf16 kernels) / measured time',
+                           'peak_tflops': {'f32': MFMA_F32_PEAK_TFLOPS, 'bf16': MFMA_BF16_PEAK_TFLOPS}, 'gemm_mode': gemm_mode, 'gemm': g_d, 'wgrad': w_d}
             if ser_steps > 0:
-                # composite bound of the whole step: all update flops at the fp32 matrix peak + all aggregate bytes at the HBM peak
-                fl = (mm[1][2] + mm[2][2]) / ser_steps; by = agg_bytes / ser_steps
-                t_mfma, t_hbm = fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3, by / (HBM_PEAK_GBS * 1e9) * 1e3
+                # composite bound of the whole step: every update launch at the peak of its own pipe + all aggregate bytes at the HBM peak
+                fl = sum(mm[c][2] for c in MM_CATS) / ser_steps; by = agg_bytes / ser_steps
+                t_mfma, t_hbm = (g_pk + w_pk) / ser_steps, by / (HBM_PEAK_GBS * 1e9) * 1e3
+                t_f32 = fl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
                 out['step_bound'] = {'update_gflop_per_step': round(fl / 1e9, 1), 'aggregate_gb_per_step': round(by / 1e9, 2),
-                                     'ms_at_fp32_mfma_peak': round(t_mfma, 2), 'ms_at_hbm_peak': round(t_hbm, 2),
+                                     'ms_at_mfma_peak_of_pipe_used': round(t_mfma, 2), 'ms_at_hbm_peak': round(t_hbm, 2),
                                      'frac_of_serial_bound': round((t_mfma + t_hbm) / ms_per_step, 3),
                                      'frac_of_overlapped_bound': round(max(t_mfma, t_hbm) / ms_per_step, 3),
-                                     'note': 'bounds priced with the exact-fp32 MFMA peak (157.3 TF); the split-bf16 GEMM kernel does 6 bf16 MFMA flops per fp32 flop on a 2.5 PF pipe, so it can beat the fp32 bound'}
+                                     'labelled_extra_ms_if_all_flops_ran_at_fp32_mfma_peak': round(t_f32, 2),
+                                     'note': 'split-bf16 launches priced at 6 bf16 MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
+                                             'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
         if e2e:
             out['end_to_end'] = e2e
         if extra:

@@ -30,7 +30,8 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, 'gm_internal.h'), os.path.join(HERE, '..', 'include', 'gmeta_hip.h')]
+    # every header a translation unit can include: editing any of them (gemm_split.h is only included by gemm.hip) rebuilds the objects
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'gmeta_hip.h')]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)

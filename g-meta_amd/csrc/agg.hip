@@ -360,10 +360,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
 }
 
 int gm_agg_window(int64_t rows) {
-    static int min_waves = -1;
-    if (min_waves < 0) { const char* e = getenv("GM_AGG_MIN_WAVES"); min_waves = e ? atoi(e) : 65536; }
-    static int min_win = -1;
-    if (min_win < 0) { const char* e = getenv("GM_AGG_MIN_WIN"); min_win = e ? atoi(e) : 2; if (min_win < 1) min_win = 1; }
+    const int min_waves = gm_knob().agg_min_waves, min_win = gm_knob().agg_min_win;
     int win = 64;
     while (win > min_win && rows / win < min_waves) win >>= 1;
     return win;
@@ -371,9 +368,7 @@ int gm_agg_window(int64_t rows) {
 
 int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s) {
     *out = gm_agg_sched{};
-    static int on = -1, part_env = -1;
-    if (on < 0) { const char* e = getenv("GM_AGG_SCHED"); on = e ? atoi(e) : 1; }
-    if (part_env < 0) { const char* e = getenv("GM_AGG_HUB_PART"); part_env = e ? atoi(e) : 128; }      // 0: one block per hub row
+    const int on = gm_knob().agg_sched, part_env = gm_knob().agg_hub_part;      // part_env 0: one block per hub row
     if (!on || n_heavy <= 0 || rows <= 0) return GM_OK;                  // no hub rows: the plain window launch
     // edges per hub part: a multiple of 16, at most 32 parts for the widest row
     int hub_part = 0;
@@ -439,8 +434,7 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     int grid = a.nblocks;
     if (a.sched) grid = GM_NXCD * a.sched_len;
     else if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
-    static int unr = -1;
-    if (unr < 0) { const char* e = getenv("GM_AGG_UNR"); unr = e ? atoi(e) : 24; }
+    const int unr = gm_knob().agg_unr;
 #define GM_AGG_CASE(U_, M_) if (unr == U_ * 10 + M_) { hipLaunchKernelGGL((k_agg_win<LPR, NCH, U_, M_>), dim3(grid), dim3(AGG_BLOCK), 0, s, a); return; }
     GM_AGG_CASE(1, 2) GM_AGG_CASE(1, 4) GM_AGG_CASE(2, 2) GM_AGG_CASE(2, 4) GM_AGG_CASE(4, 2) GM_AGG_CASE(4, 4) GM_AGG_CASE(3, 4) GM_AGG_CASE(2, 6) GM_AGG_CASE(2, 8) GM_AGG_CASE(1, 8)
 #undef GM_AGG_CASE
@@ -455,16 +449,8 @@ static void launch_one(const AggK& a0, hipStream_t s) {
     hipLaunchKernelGGL((k_agg<VEC, LPR>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
-static int agg_nt() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GM_AGG_NT"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static int agg_variant() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GM_AGG_VARIANT"); v = e ? atoi(e) : 0; }   // 1 = force the generic row-per-group kernel (debug)
-    return v;
-}
+static int agg_nt() { return gm_knob().agg_nt; }
+static int agg_variant() { return gm_knob().agg_variant; }
 
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
@@ -524,7 +510,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     if (s_in && s_in == b->d_norm) a.e_w = b->d_enorm[transposed ? 1 : 0];
     a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
-    a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, transposed ? 1 : 0);
+    a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, transposed ? 1 : 0, (hipStream_t)stream);
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

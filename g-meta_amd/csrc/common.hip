@@ -138,11 +138,47 @@ extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t
     return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);
 }
 
-int gm_heavy_deg() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GM_HEAVY_DEG"); v = e ? atoi(e) : 64; if (v < 2) v = 2; }
-    return v;
+const gm_knobs& gm_knob() {
+    static gm_knobs k;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+        k.agg_min_waves = env("GM_AGG_MIN_WAVES", 65536);
+        k.agg_min_win = std::max(1, env("GM_AGG_MIN_WIN", 2));
+        k.agg_sched = env("GM_AGG_SCHED", 1);
+        k.agg_hub_part = env("GM_AGG_HUB_PART", 128);                  // 0: one block per hub row
+        k.agg_unr = env("GM_AGG_UNR", 24);
+        k.agg_nt = env("GM_AGG_NT", 1);
+        k.agg_variant = env("GM_AGG_VARIANT", 0);                      // 1 = force the generic row-per-group kernel (debug)
+        k.agg_edge_tables = env("GM_AGG_EDGE_TABLES", 1);
+        k.heavy_deg = std::max(2, env("GM_HEAVY_DEG", 64));
+        k.extract_global_bitmap = env("GM_EXTRACT_GLOBAL_BITMAP", 0);
+        k.feat_pad = env("GM_FEAT_PAD", 1);
+        k.timing = env("GM_TIMING", 0);
+        const char* gm = getenv("GM_GEMM_MODE");
+        k.gemm_mode = (gm && (!strcmp(gm, "split") || !strcmp(gm, "1"))) ? 1 : (gm && (!strcmp(gm, "f32") || !strcmp(gm, "0"))) ? 0 : -1;
+        k.gemm_split_min_tiles = env("GM_GEMM_SPLIT_MIN_TILES", -1);
+        k.gemm_split_grid = env("GM_GEMM_SPLIT_GRID", 0);
+        k.gemm_fused_rounds = std::max(1, env("GM_GEMM_FUSED_ROUNDS", 4));
+        k.gemm_plain_rounds = std::max(1, env("GM_GEMM_PLAIN_ROUNDS", 1));
+        k.gemm_half_tiles = env("GM_GEMM_HALF_TILES", 1);
+        k.gemm_bn = env("GM_GEMM_BN", 256);
+        k.gemm_mid_tiles = env("GM_GEMM_MID_TILES", 1536);
+        k.gemm_glds = env("GM_GEMM_GLDS", 1);
+        k.gemm_nt = env("GM_GEMM_NT", 1);
+        k.gemm_small = env("GM_GEMM_SMALL", 1);
+        k.wgrad_split = env("GM_WGRAD_SPLIT", 1);
+        k.dz_glds = env("GM_DZ_GLDS", 1);
+        k.fuse_agg = env("GM_FUSE_AGG", 1);
+        k.head_stage = env("GM_HEAD_STAGE", 1);
+        k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
+        k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
+        k.head_blocks = env("GM_HEAD_BLOCKS", 1);
+    });
+    return k;
 }
+
+int gm_heavy_deg() { return gm_knob().heavy_deg; }
 
 // ---------------------------------------------------------------- per-device facts (one process may drive several GPUs)
 static std::mutex g_dev_mu;

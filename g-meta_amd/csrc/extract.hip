@@ -5,6 +5,7 @@
 // local ids are prefix popcounts.  Edge lists are read from HBM coalesced (wave per frontier node).
 #include <algorithm>
 #include <stdlib.h>
+#include <mutex>
 #include "gm_internal.h"
 
 #define EX_BLOCK 512
@@ -384,8 +385,23 @@ void gm_batch_mark_use(const gm_batch* b, hipStream_t st) {
     if (hipEventRecord(b->used_ev, st) != hipSuccess) (void)hipGetLastError();
 }
 
+// Hub-part counters / partial rows of orientation o are about to be used by a launch on `s`: if the previous such launch went to ANOTHER
+// stream, order this one behind everything queued there so far (which includes that launch).  Costs nothing while a batch stays on one stream.
+int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (b->hub_used[o] && b->hub_stream[o] != s) {
+        if (!b->hub_ev[o]) GM_HIP(hipEventCreateWithFlags(&b->hub_ev[o], hipEventDisableTiming));
+        GM_HIP(hipEventRecord(b->hub_ev[o], b->hub_stream[o]));
+        GM_HIP(hipStreamWaitEvent(s, b->hub_ev[o], 0));
+    }
+    b->hub_used[o] = true; b->hub_stream[o] = s;
+    return GM_OK;
+}
+
 static void batch_free(gm_batch* b) {
     hipStream_t s = b->stream;
+    for (int o = 0; o < 2; ++o) if (b->hub_ev[o]) { (void)hipEventDestroy(b->hub_ev[o]); b->hub_ev[o] = nullptr; }
     if (b->used_ev) {
         if (hipStreamWaitEvent(s, b->used_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b->used_ev); }
         (void)hipEventDestroy(b->used_ev); b->used_ev = nullptr;
@@ -463,8 +479,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
         }
     }
-    static int edge_tables = -1;
-    if (edge_tables < 0) { const char* e = getenv("GM_AGG_EDGE_TABLES"); edge_tables = e ? atoi(e) : 1; }
+    const int edge_tables = gm_knob().agg_edge_tables;
     if (b->edges > 0 && edge_tables) {
         GM_TRY(gm_alloc(&b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_efeat, (size_t)b->edges, s));
         hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
@@ -589,8 +604,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     if (!given) cap = std::min<int64_t>(store->max_nodes, (int64_t)sample_nodes + 2);
     const int Wmax = (int)((store->max_nodes + 31) >> 5);
     size_t lds_a = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 256 + 16);
-    static int force_global = -1;
-    if (force_global < 0) { const char* ev = getenv("GM_EXTRACT_GLOBAL_BITMAP"); force_global = ev ? atoi(ev) : 0; }
+    const int force_global = gm_knob().extract_global_bitmap;
     // parent graphs beyond ~650k nodes do not fit the LDS bitmap pair: fall back to a per-workgroup slab in HBM
     const bool gpath = force_global || lds_a > 160 * 1024;
     if (gpath) lds_a = sizeof(uint32_t) * (EX_BLOCK + 256 + 16);

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include "gm_internal.h"
+#include <atomic>
 #include <mutex>
 #include "gemm_split.h"
 
@@ -465,12 +466,14 @@ __global__ __launch_bounds__(512) void k_gemm_glds_small(GemmK g) {
 }
 
 // ---- split-bf16 path (gemm_split.h): mode switch, eligibility, weight planes
-static int g_gemm_mode = -1;
+static std::atomic<int> g_gemm_mode{-1};        // gm_set_gemm_mode override (-1: the environment / library default)
 int gm_gemm_mode() {
-    if (g_gemm_mode < 0) { const char* e = getenv("GM_GEMM_MODE"); g_gemm_mode = (e && (!strcmp(e, "split") || !strcmp(e, "1"))) ? 1 : (e && (!strcmp(e, "f32") || !strcmp(e, "0"))) ? 0 : GM_GEMM_MODE_DEFAULT; }
-    return g_gemm_mode;
+    const int o = g_gemm_mode.load(std::memory_order_relaxed);
+    if (o >= 0) return o;
+    const int e = gm_knob().gemm_mode;
+    return e >= 0 ? e : GM_GEMM_MODE_DEFAULT;
 }
-extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode = mode ? 1 : 0; }
+extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode.store(mode ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
 // The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
 const float* gm_zero_row(hipStream_t s) {
@@ -488,8 +491,8 @@ const float* gm_zero_row(hipStream_t s) {
     return rows[dev];
 }
 bool gm_gemm_split_ok(int n_tiles, int K, int N) {
-    static int min_tiles = -1;        // default: from a quarter of the CUs busy upwards (measured on the 141-tile support batch of a 4-task shard: still ahead of the fp32 small-tile kernel)
-    if (min_tiles < 0) { const char* e = getenv("GM_GEMM_SPLIT_MIN_TILES"); min_tiles = e ? atoi(e) : gm_num_cus() / 4; }
+    // default: from a quarter of the (current device's) CUs busy upwards (measured on the 141-tile support batch of a 4-task shard: still ahead of the fp32 small-tile kernel)
+    const int min_tiles = gm_knob().gemm_split_min_tiles >= 0 ? gm_knob().gemm_split_min_tiles : gm_num_cus() / 4;
     return gm_gemm_mode() == 1 && N == 256 && K % 16 == 0 && K >= 32 && n_tiles >= min_tiles;
 }
 int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s) {
@@ -501,9 +504,10 @@ int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K,
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
-    gm_prof_begin(GM_PROF_GEMM, s, 2 * a.rows * a.K * a.N);
+    const int cat = a.Bsplit ? GM_PROF_GEMM_SPLIT : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
+    gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
     const int rc = launch_gemm_nn(a, s);
-    gm_prof_end(GM_PROF_GEMM, s);
+    gm_prof_end(cat, s);
     return rc;
 }
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
@@ -518,8 +522,8 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;
         // persistent: one workgroup per CU (it fills the CU's register file, so nothing else co-resides).  GM_GEMM_SPLIT_GRID caps the
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
-        static int grid_cap = -1;
-        if (grid_cap < 0) { const char* e = getenv("GM_GEMM_SPLIT_GRID"); grid_cap = e ? atoi(e) : 0; if (grid_cap <= 0 || grid_cap > gm_num_cus()) grid_cap = gm_num_cus(); }
+        int grid_cap = gm_knob().gemm_split_grid;
+        if (grid_cap <= 0 || grid_cap > gm_num_cus()) grid_cap = gm_num_cus();
         if (a.fuse2) {
             // fused aggregate + GEMM: A addresses the aggregate's input rows, rows of other degrees come finished from a.zside
             GM_REQUIRE(a.K / 16 >= PF_DA && a.zside && (a.ldz % 4 == 0) && (((uintptr_t)a.zside & 15) == 0), GM_EINVAL, "gemm: fused aggregate needs K >= %d and an aligned side buffer", 16 * PF_DA);
@@ -531,17 +535,14 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             // a whole GEMM for a CU (head/loss: 26 us of work, 680 us in the two-stream timeline).  `mult` workgroups per CU, each walking
             // 1/mult of the tiles, give the dispatcher a yield point every ~0.65/mult ms (default 4: 27.7 -> 27.4 ms at task_num 32, 5.12 -> 4.86 ms
             // for the 4-task shard, where the support chain is the critical path; 8 and more lose to the per-workgroup prologue).
-            static int mult_f = -1;
-            if (mult_f < 0) { const char* e = getenv("GM_GEMM_FUSED_ROUNDS"); mult_f = e ? atoi(e) : 4; if (mult_f < 1) mult_f = 1; }
+            const int mult_f = gm_knob().gemm_fused_rounds;
             hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
         } else {
             // a launch that would leave more than half of the CUs without a tile walks 64-row half tiles: half the MFMA chain per workgroup
-            static int half_on = -1;
-            if (half_on < 0) { const char* e = getenv("GM_GEMM_HALF_TILES"); half_on = e ? atoi(e) : 1; }
+            const int half_on = gm_knob().gemm_half_tiles;
             if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
             else {
-                static int mult_p = -1;
-                if (mult_p < 0) { const char* e = getenv("GM_GEMM_PLAIN_ROUNDS"); mult_p = e ? atoi(e) : 1; if (mult_p < 1) mult_p = 1; }
+                const int mult_p = gm_knob().gemm_plain_rounds;
                 hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, mult_p * grid_cap)), dim3(1024), 0, s, k);
             }
         }
@@ -565,28 +566,22 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     } while (0)
     // column-tile width: the widest (A read once) unless that leaves CUs idle -- small batches are latency-bound, so
     // trade A re-reads (L2 hits, same XCD) for parallelism
-    static int bn_cap = -1;
-    if (bn_cap < 0) { const char* e = getenv("GM_GEMM_BN"); bn_cap = e ? atoi(e) : 256; }
+    const int bn_cap = gm_knob().gemm_bn;
     int bn = a.N > 128 ? 256 : a.N > 64 ? 128 : 64;
     if (bn > bn_cap) bn = bn_cap;
     while (bn > 64 && (int64_t)a.n_tiles * ((a.N + bn - 1) / bn) < 512) bn >>= 1;
-    static int mid_tiles = -1;           // below this many row tiles a 256-wide tile grid is only a few rounds deep: halve the tile (shorter tail)
-    if (mid_tiles < 0) { const char* e = getenv("GM_GEMM_MID_TILES"); mid_tiles = e ? atoi(e) : 1536; }
+    const int mid_tiles = gm_knob().gemm_mid_tiles;           // below this many row tiles a 256-wide tile grid is only a few rounds deep: halve the tile (shorter tail)
     if (bn == 256 && a.n_tiles < mid_tiles) bn = 128;
     g.n_col_tiles = (a.N + bn - 1) / bn;
-    static int use_glds = -1;
-    if (use_glds < 0) { const char* e = getenv("GM_GEMM_GLDS"); use_glds = e ? atoi(e) : 1; }
+    const int use_glds = gm_knob().gemm_glds;
     const bool bias_al = !a.bias || ((((uintptr_t)a.bias & 15) == 0) && (a.bias_stride % 4 == 0));
-    static int nts = -1;
-    if (nts < 0) { const char* e = getenv("GM_GEMM_NT"); nts = e ? atoi(e) : 1; }
-    g.nt_store = nts;
+    g.nt_store = gm_knob().gemm_nt;
     if (use_glds && vec && !a.transB && !a.mask_b && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
         const dim3 grid(g.n_tiles * g.n_col_tiles);
         if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);
         else if (bn == 128) hipLaunchKernelGGL((k_gemm_glds<2>), grid, dim3(256), 0, s, g);
         else {
-            static int small = -1;            // 1 (default): 8 x (32 x 32) waves per 128 x 64 tile when the launch leaves CUs mostly empty
-            if (small < 0) { const char* e = getenv("GM_GEMM_SMALL"); small = e ? atoi(e) : 1; }
+            const int small = gm_knob().gemm_small;            // 1 (default): 8 x (32 x 32) waves per 128 x 64 tile when the launch leaves CUs mostly empty
             if (small && (int64_t)g.n_tiles * g.n_col_tiles <= 4 * gm_num_cus()) hipLaunchKernelGGL(k_gemm_glds_small, grid, dim3(512), 0, s, g);
             else hipLaunchKernelGGL((k_gemm_glds<1>), grid, dim3(128), 0, s, g);
         }
@@ -1105,10 +1100,20 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, c
 }
 
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
+static bool wgrad_fast_ok(const gm_wgrad_args& a) {
+    return (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
+           (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
+}
+// exact 3-way bf16 split of both operands, fp32 accumulation (k_wgrad_split): the same arithmetic as the split GEMM
+static bool wgrad_takes_split(const gm_wgrad_args& a) {
+    const int wsplit = gm_knob().wgrad_split;
+    return a.n_chunks > 0 && wgrad_fast_ok(a) && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= gm_num_cus() / 4 && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256);
+}
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
-    gm_prof_begin(GM_PROF_WGRAD, s, 2 * a.rows * a.K * a.N);
+    const int cat = wgrad_takes_split(a) ? GM_PROF_WGRAD_SPLIT : GM_PROF_WGRAD;
+    gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
     const int rc = launch_wgrad(a, s);
-    gm_prof_end(GM_PROF_WGRAD, s);
+    gm_prof_end(cat, s);
     return rc;
 }
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
@@ -1125,12 +1130,8 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
     w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
     bool launched = false;
-    const bool fast_ok = (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
-                         (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
-    static int wsplit = -1;
-    if (wsplit < 0) { const char* e = getenv("GM_WGRAD_SPLIT"); wsplit = e ? atoi(e) : 1; }
-    if (fast_ok && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= gm_num_cus() / 4 && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256)) {
-        // exact 3-way bf16 split of both operands, fp32 accumulation (see k_wgrad_split): the same arithmetic as the split GEMM
+    const bool fast_ok = wgrad_fast_ok(a);
+    if (wgrad_takes_split(a)) {
         if (a.K == 256 && a.N == 256) GM_TRY((launch_wgrad_split<2, 2>(w, s)));
         else if (a.K == 128 && a.N == 256) GM_TRY((launch_wgrad_split<1, 2>(w, s)));
         else if (a.K == 256 && a.N == 128) GM_TRY((launch_wgrad_split<2, 1>(w, s)));

@@ -150,14 +150,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
     float* biasl = reinterpret_cast<float*>(smem + OFF_BIAS);                         // [2][256]
     if (total == 0) return;
-#ifdef PF_TRACE
-    const bool tr = (blockIdx.x == 77) && lane == 0 && (wave == 0 || wave == 8 || wave == 12);
-    const int trole = wave == 0 ? 0 : wave == 8 ? 1 : 2;
-#define PF_T(C, WHICH) do { if (tr && (C) < 64) g.dbg[((trole * 64 + (C)) * 4) + (WHICH)] = clock64(); } while (0)
-#else
-#define PF_T(C, WHICH) do {} while (0)
-#endif
-
     if (wave >= 12) {
         // ================= B feeder
         __builtin_amdgcn_s_setprio(2);            // feeders ahead of the MFMA-heavy compute waves in VALU / LDS arbitration
@@ -191,15 +183,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GS_BARRIER();
         for (int gc = 0; gc < total; ++gc) {
-            PF_T(gc, 0);
-#ifndef PF_EXP_NOBDMA
             if (gc + 1 < total) issue_b(gc + 1);
-#endif
-            PF_T(gc, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            PF_T(gc, 2);
             GS_BARRIER();
-            PF_T(gc, 3);
         }
     } else if (wave >= 8) {
         // ================= A feeder
@@ -312,11 +298,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     v.x = __fmaf_rn(v1.x, w1, __fmaf_rn(v.x, w0, 0.f)); v.y = __fmaf_rn(v1.y, w1, __fmaf_rn(v.y, w0, 0.f));
                     v.z = __fmaf_rn(v1.z, w1, __fmaf_rn(v.z, w0, 0.f)); v.w = __fmaf_rn(v1.w, w1, __fmaf_rn(v.w, w0, 0.f));
                 }
-#ifdef PF_EXP_NOSPLIT
-                h = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y)); m = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w)); l = h;
-#else
                 gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
-#endif
                 *reinterpret_cast<uint2*>(As + adst[p]) = h;
                 *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
                 *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
@@ -353,7 +335,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             for (int u = 0; u < PF_DA; ++u) {
                 const int gc = g0 + u;
                 if (gc < total) {
-                    PF_T(gc, 0);
                     if (gc + 1 < total) {
                         // chunk gc+1 sits in slot (u+1) % PF_DA; newer groups in flight: chunks gc+2 .. min(gc+PF_DA-1, total-1)
                         const int newer = min(PF_DA - 2, total - 2 - gc);
@@ -362,16 +343,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                         else if (newer == 1 && PF_DA > 3) PF_WAIT_SLOT(1, SL);
                         else if (newer == 2 && PF_DA > 4) PF_WAIT_SLOT(2, SL);
                         else PF_WAIT_SLOT(0, SL);
-                        PF_T(gc, 1);
                         store_a(gc + 1, SL);
                         // the first chunk of the NEXT tile is about to become visible: its scales / bias must be there as well
                         // (short-K launches only: the counted path above needs nchunks >= PF_DA)
                         if (!fast_consts && sa_c == 1 && sa_ti > 0) { stage_tile_consts(sa_ti); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                     }
                     if (gc + PF_DA < total) load_a(u);                                 // slot u held chunk gc: already split into LDS
-                    PF_T(gc, 2);
                     GS_BARRIER();
-                    PF_T(gc, 3);
                 }
             }
         }
@@ -384,13 +362,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
         int gc = 0;
-#ifdef PF_EXP_NOBLDS
-        gm_bf16x8 bfx[2][3];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) bfx[j][p] = *reinterpret_cast<const gm_bf16x8*>(smem + b_lane + p * B_PLANE + j * 512);
-#endif
         for (int ti = 0; ti < ntb; ++ti) {
             gm_f32x16 acc[MI][2];
 #pragma unroll
@@ -400,37 +371,22 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
             for (int c = 0; c < nchunks; ++c, ++gc) {
-                PF_T(gc, 0);
                 const char* S = smem + (gc & 1) * STAGE;
-#ifdef PF_EXP_NOBLDS
-                gm_bf16x8 af[MI][3];
-                static_assert(true, "");
-                gm_bf16x8 bf[2][3];
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[j][p] = bfx[j][p];
-#else
                 gm_bf16x8 af[MI][3], bf[2][3];
-#endif
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
-#ifndef PF_EXP_NOBLDS
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
-#endif
 #define PF_PROD(PA, PB)                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
                 PF_PROD(2, 0) PF_PROD(0, 2) PF_PROD(1, 1) PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)
 #undef PF_PROD
-                PF_T(gc, 2);
                 GS_BARRIER();
-                PF_T(gc, 3);
             }
             // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
             const GsTile tl = tile_of(b + ti * G);                // scalar (SMEM) loads: lgkmcnt, not vmcnt
@@ -455,9 +411,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
                     if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
                     if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
-#ifdef PF_EXP_NOSTORE
-                    if (v.x != 123.456f) continue;
-#endif
                     if (g.nt_store) {
                         typedef float f4v __attribute__((ext_vector_type(4)));
                         f4v vv = {v.x, v.y, v.z, v.w};

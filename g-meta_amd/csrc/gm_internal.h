@@ -109,6 +109,10 @@ struct gm_batch {
     // hub rows split into parts of hub_part edges, one block each (gm_agg_schedule): part table + arrival counters, and the partial
     // rows.  One aggregate launch per orientation at a time (a batch's launches are stream-ordered: they share the layer buffers too).
     int32_t* d_hub[2] = {nullptr, nullptr}; float* d_hub_scratch[2] = {nullptr, nullptr}; int32_t hub_part[2] = {0, 0};
+    // The arrival counters / partial rows belong to ONE launch at a time.  Launches of a batch are stream-ordered in gm_meta_step; a caller
+    // that moves an orientation's launches to another stream (public gm_aggregate / gm_gcn_* API) is ordered behind the previous stream's
+    // launch by gm_batch_hub_order (an event wait, only when the stream changes).  Host-side bookkeeping, guarded by hub_mu.
+    mutable hipStream_t hub_stream[2] = {nullptr, nullptr}; mutable bool hub_used[2] = {false, false}; mutable hipEvent_t hub_ev[2] = {nullptr, nullptr};
     // per-edge tables (gm_batch_finalize): the source's norm for both CSR orientations (enorm[o][e] = norm[indices_o[e]]) and the source's
     // feature row (efeat[e] = feat_row[indices[e]]): what the aggregate would otherwise fetch with a dependent 4-byte gather per edge
     float* d_enorm[2] = {nullptr, nullptr}; int32_t* d_efeat = nullptr;
@@ -137,14 +141,27 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s);
 // that work instead of relying on the host having synchronised (deferred read-back, prefetch threads).
 void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
 
+// ---- tuning / debug knobs: every GM_* environment variable is read ONCE, under std::call_once, into this
+// struct (the prefetch thread and the training thread both enter the library); per-device quantities are derived at the call site.
+struct gm_knobs {
+    int agg_min_waves, agg_min_win, agg_sched, agg_hub_part, agg_unr, agg_nt, agg_variant, agg_edge_tables, heavy_deg;
+    int extract_global_bitmap, feat_pad, timing;
+    int gemm_mode;                 // 0 exact fp32, 1 split-bf16, -1 not set (library default)
+    int gemm_split_min_tiles;      // -1: a quarter of the current device's CUs
+    int gemm_split_grid;           // 0: the current device's CU count
+    int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
+    int fuse_agg, head_stage, side_stream_priority;
+    int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
+    int head_blocks;               // workgroups per task of the head/loss kernel's gather phase
+};
+const gm_knobs& gm_knob();
+
 // ---- host phase timing for the setup paths (env GM_TIMING=1 prints to stderr)
 #include <chrono>
 struct gm_phase_timer {
     const char* what; bool on; std::chrono::steady_clock::time_point t0, t;
     explicit gm_phase_timer(const char* w) : what(w) {
-        static int en = -1;
-        if (en < 0) { const char* e = getenv("GM_TIMING"); en = e ? atoi(e) : 0; }
-        on = en != 0; t0 = t = std::chrono::steady_clock::now();
+        on = gm_knob().timing != 0; t0 = t = std::chrono::steady_clock::now();
     }
     void lap(const char* phase) {
         if (!on) return;
@@ -210,7 +227,11 @@ const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current de
 #define GM_FUSE_MAXDEG 2
 #define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
 struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; };
-template <class A, class B> inline void gm_agg_hub(A& a, const B* b, int o) { a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o]; }
+int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s);
+template <class A> inline void gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s) {
+    a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o];
+    if (a.hub) (void)gm_batch_hub_order(b, o, s);
+}
 // Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
 int gm_agg_window(int64_t rows);
 // Block schedule for the window aggregate over `rows` rows with the given (ascending, host) hub-row list: 8 per-XCD lists of
@@ -311,7 +332,9 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_GEMM 1
 #define GM_PROF_WGRAD 2
 #define GM_PROF_AGG_STRICT 3   // work-only shadow of GM_PROF_AGG: compulsory HBM bytes (a layer-1 gather reads at most the feature table)
-#define GM_PROF_CATS 4
+#define GM_PROF_GEMM_SPLIT 4   // grouped GEMM launches that ran on the split-bf16 kernel (6 bf16 MFMA flops per fp32 flop; work = fp32 flops)
+#define GM_PROF_WGRAD_SPLIT 5  // weight gradients on the split-bf16 kernel
+#define GM_PROF_CATS 6
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
 void gm_prof_reset();

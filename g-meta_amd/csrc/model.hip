@@ -3,6 +3,7 @@
 // at once.  Each task (set) owns its fast weights; the K-loop runs here so that one FFI call is one
 // meta-step and nothing returns to the host until the accuracies are read back.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <stdlib.h>
 #include "gm_internal.h"
@@ -441,14 +442,9 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
 // whose update runs on the split-bf16 kernel take the FUSED aggregate + GEMM -- the aggregate of a row with one or two sources is formed
 // in the GEMM's A feeders (same fma order), only rows of other degrees go through the aggregate kernel and HBM; Z_l of the other
 // rows and the relu' bits are never written.  Same floats as the unfused pass, bit for bit.
-static int gm_fuse_agg() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("GM_FUSE_AGG"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static int g_fuse_agg_override = -1;
-extern "C" void gm_set_fuse_agg(int32_t on) { g_fuse_agg_override = on < 0 ? -1 : (on ? 1 : 0); }
-extern "C" int32_t gm_get_fuse_agg(void) { return g_fuse_agg_override >= 0 ? g_fuse_agg_override : gm_fuse_agg(); }
+static std::atomic<int> g_fuse_agg_override{-1};
+extern "C" void gm_set_fuse_agg(int32_t on) { g_fuse_agg_override.store(on < 0 ? -1 : (on ? 1 : 0), std::memory_order_relaxed); }
+extern "C" int32_t gm_get_fuse_agg(void) { const int o = g_fuse_agg_override.load(std::memory_order_relaxed); return o >= 0 ? o : gm_knob().fuse_agg; }
 
 static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* logits, hipStream_t st, int reuse_z1, int skip_head = 0, int fwd_only = 0) {
     if (c.cone) return cone_forward(c, params, pstride, logits, st, reuse_z1, skip_head);
@@ -465,7 +461,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
-            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0, st); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
@@ -476,7 +472,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             const bool fuse = fwd_only == 1 && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
                               (!gather || (b->store->feat_ld % 4 == 0 && b->store->feat_ld >= fi));
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0, st); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 if (fuse) {
@@ -559,7 +555,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         wgrad_sgd(w, c, l);
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1, st); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -578,8 +574,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             if (l > 0) {
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
-                static int dz_glds = -1;
-                if (dz_glds < 0) { const char* e = getenv("GM_DZ_GLDS"); dz_glds = e ? atoi(e) : 1; }
+                const int dz_glds = gm_knob().dz_glds;
                 const bool use_split = c.Wsplit && gm_gemm_split_ok(b->n_tiles, fo, fi);
                 const bool use_wt = !use_split && dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
                 if (use_split) {
@@ -608,7 +603,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             if (kn) { c.pd->valid[kn][l][0] = w.pl_fwd != nullptr; c.pd->valid[kn][l][1] = w.pl_dz != nullptr; }
             if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
             if (l > 0) {
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1, st); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
@@ -875,7 +870,10 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
     hipStream_t st = (hipStream_t)stream;
     ClassTables ct;
     GM_TRY(class_tables(b, y, 0, ct));
-    GM_REQUIRE(ct.Ct == c_task, GM_EINVAL, "proto_loss_qry: %d query classes but %d prototypes", ct.Ct, c_task);
+    // prototypes are indexed by sorted-class position with stride c_task: EVERY set must carry exactly c_task query classes (a set with
+    // fewer would be scored against another class's prototype); gm_meta_step checks support vs query class counts per task itself
+    for (int t = 0; t < b->sets; ++t)
+        GM_REQUIRE(ct.tab[t * 3 + 1] == c_task, GM_EINVAL, "proto_loss_qry: set %d has %d query classes but the prototypes hold %d per set", t, ct.tab[t * 3 + 1], c_task);
     int32_t* d_rows = nullptr;
     GM_TRY(upload_tables(ct, &d_rows, st));
     int rc = GM_OK;
@@ -911,8 +909,7 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     for (int t = 0; t < b->sets; ++t) max_subs = std::max(max_subs, b->h_set_sub_off[t + 1] - b->h_set_sub_off[t]);
     const size_t hs_bytes = sizeof(float) * ((size_t)max_subs * b->centres * L.dims[L.n_gcn] + (size_t)L.n_out * (L.hc + 1) + 2 * (size_t)max_subs * L.n_out +
                                              (size_t)max_subs * b->centres);      // + the centre-row scratch
-    static int stage_on = -1;
-    if (stage_on < 0) { const char* e = getenv("GM_HEAD_STAGE"); stage_on = e ? atoi(e) : 1; }
+    const int stage_on = gm_knob().head_stage;
     const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
     const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
     GM_TRY(gm_func_full_lds((const void*)k_head_loss));
@@ -952,8 +949,7 @@ struct MetaStreams {
             // (GPU_MAX_HW_QUEUES, default 4), and once RCCL/torch have created their streams an ordinary stream created
             // here was observed to alias the caller's queue, silently serialising the whole step.
             int lo = 0, hi = 0;
-            static int use_prio = -1;
-            if (use_prio < 0) { const char* e = getenv("GM_SIDE_STREAM_PRIORITY"); use_prio = e ? atoi(e) : 1; }
+            const int use_prio = gm_knob().side_stream_priority;
             if (use_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
                 GM_HIP(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo));      // `lo` = least priority
             } else {

@@ -65,8 +65,7 @@ extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const i
     UP(s->d_out_idx, out_idx, int32_t)
 #undef UP
     {
-        static int pad_on = -1;
-        if (pad_on < 0) { const char* e = getenv("GM_FEAT_PAD"); pad_on = e ? atoi(e) : 1; }
+        const int pad_on = gm_knob().feat_pad;
         // 1 (default): pad only widths the vector kernels cannot take as they are (not a multiple of 4: 50, 5, ...); 2: always; 0: never.
         // Aligned widths keep their native stride: padding is exact (zeros) but changes which kernels run, i.e. the fp summation order.
         s->feat_ld = (pad_on == 2 || (pad_on == 1 && feat_dim % 4 != 0)) ? gm_pad_feat(feat_dim) : feat_dim;

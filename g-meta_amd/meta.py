@@ -189,7 +189,12 @@ class Meta(nn.Module):
             self.meta_optim.grad_scale = None
             self.meta_optim.step()
             return _Deferred(self, head[P:], K1, applied=True)
-        return _Deferred(self, head, K1, applied=False, P=P)
+        # Non-fused Adam (optim.Adam(fused=True) unavailable) or CPU tensors: the NaN guard needs the loss on the host, so the update is
+        # applied HERE -- every meta-batch steps the optimiser like meta.py:163-169, whether or not the caller ever reads the
+        # accuracies (train.py only reads them on report steps); only the handle's bookkeeping is left for .accs()
+        d = _Deferred(self, head, K1, applied=False, P=P)
+        d.accs()
+        return d
 
     def forward_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
         return self.forward_deferred(x_spt, y_spt, x_qry, y_qry).accs()

@@ -303,9 +303,24 @@ class Subgraphs(Dataset):
             selected_cls = np.arange(len(data)); np.random.shuffle(selected_cls)
             support_x, query_x = [], []
             for cls in selected_cls:
-                if len(data[cls]) < self.k_shot + self.k_query:
-                    raise ValueError('each class in a graph must have at least k_shot + k_query entities (sdp.py:218-240 fallback was "not used in practice")')
-                s, q = self._pick(data[cls], self.k_shot, self.k_query)
+                pool = data[cls]
+                if len(pool) >= self.k_shot + self.k_query:
+                    s, q = self._pick(pool, self.k_shot, self.k_query)
+                elif len(pool) >= self.k_shot:
+                    # the reference's short-class branch (sdp.py:218-238, "not used in practice"): every entity of the class is used, the first
+                    # k_shot of a shuffle as support, and the query list is topped up with k_shot + k_query - len + 1 entities (`count <=
+                    # num_more`) of randomly chosen classes of the same graph, drawn with the same global-RNG calls.  Such a task carries
+                    # k_query + 1 query entries with mixed labels: the query loss then raises on unequal class counts, in the reference
+                    # (torch.stack, meta.py:65) and here (gm_meta_step) alike.
+                    idx = np.arange(len(pool)); np.random.shuffle(idx)
+                    arr = np.array(pool)
+                    s, q = arr[idx[:self.k_shot]].tolist(), arr[idx[self.k_shot:]].tolist()
+                    for _ in range(self.k_shot + self.k_query - len(pool) + 1):
+                        sub_cls = np.random.choice(selected_cls, 1)[0]
+                        q.append(str(np.array(data[sub_cls])[np.random.choice(len(data[sub_cls]), 1)[0]]))
+                else:
+                    print('each class in a graph must have larger than k_shot entities in the current model')      # sdp.py:240: class skipped
+                    continue
                 support_x.append(s); query_x.append(q)
             random.shuffle(support_x); random.shuffle(query_x)
             self.support_x_batch.append(support_x); self.query_x_batch.append(query_x)
@@ -490,7 +505,7 @@ class Subgraphs(Dataset):
                         if stop.is_set():
                             break
                         b = self.get_batch(idx)
-                        if cone_layers:
+                        if cone_layers and b[0]:        # (an empty task shard has nothing to prepare)
                             for x in (b[0][0], b[2][0]):
                                 root = x.view_of if x.view_of is not None else x
                                 _lib.check(_lib.lib().gm_batch_prepare_cone(root.handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone')

@@ -222,7 +222,9 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
 /* Same for one launch category: 0 = aggregate (work = algorithmic bytes), 1 = grouped GEMM (forward and dZ; work =
  * flops 2*rows*K*N), 2 = weight gradient incl. its reduction (work = flops), 3 = the aggregate launches of category 0
  * priced at their COMPULSORY HBM bytes (a layer-1 launch that gathers from the store's feature table reads at most the
- * whole table, not rows*width; total_ms is 0 for this category -- use category 0's). */
+ * whole table, not rows*width; total_ms is 0 for this category -- use category 0's), 4 / 5 = the grouped GEMMs / weight
+ * gradients that ran on the split-bf16 kernels (work = flops of the fp32 product; the kernels issue 6 bf16 MFMA flops per
+ * fp32 flop) -- categories 1 / 2 then hold only the launches on the exact-fp32 MFMA kernels. */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 
 #ifdef __cplusplus

@@ -98,8 +98,44 @@ def link_replay(name, sample_nodes, T, seed):
     dump(name, graphs, info, {'train.csv': csv_all, 'train_spt.csv': csv_spt, 'train_qry.csv': csv_qry}, args, T)
 
 
+def shared_short_class(name, T, seed):
+    """Shared setup with one class smaller than k_shot + k_query in one graph: the reference's top-up branch (sdp.py:218-238).
+    Only the task lists are recorded (ragged -> JSON): such a task cannot pass proto_loss_qry (meta.py:65) in the reference either."""
+    rng = np.random.default_rng(seed)
+    graphs, names, labels, info = [], [], [], {}
+    for g, (n, short) in enumerate(((90, 0), (110, 5))):            # graph 1: class 2 has only 5 members (k_shot 3 + k_query 4 = 7)
+        e = mg.pa_edges(n, 3, rng)
+        graphs.append((n, np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]])))
+        lab = rng.integers(0, 2, size=n)
+        if short:
+            lab[rng.permutation(n)[:short]] = 2
+        else:
+            lab[rng.permutation(n)[:30]] = 2
+        for v in range(n):
+            nm = '%d_%d' % (g, v); names.append(nm); labels.append(str(int(lab[v]))); info[nm] = int(lab[v])
+    args = mg.ns(task_setup='Shared', n_way=3, k_spt=3, k_qry=4, task_num=T, h=1)
+    torch.manual_seed(222); np.random.seed(222); random.seed(222)
+    root = tempfile.mkdtemp(prefix='gmeta_replay_') + '/'
+    mg.write_csv(root + 'train.csv', names, labels)
+    G = [mg.make_graph(*g) for g in graphs]
+    db = sdp.Subgraphs(root, 'train', info, n_way=args.n_way, k_shot=args.k_spt, k_query=args.k_qry, batchsz=T, args=args, adjs=G, h=args.h)
+    spt = [[[str(x) for x in sub] for sub in db.support_x_batch[t]] for t in range(T)]
+    qry = [[[str(x) for x in sub] for sub in db.query_x_batch[t]] for t in range(T)]
+    n_short = sum(1 for t in qry for sub in t if len(sub) != args.k_qry)
+    assert n_short > 0, 'no task drew the short class'
+    out = {'case': name, 'T': T, 'n_graphs': len(graphs), 'args': json.dumps(vars(args)), 'csv_files': json.dumps(['train.csv']),
+           'csv_train.csv_names': np.array(names), 'csv_train.csv_labels': np.array(labels),
+           'info_names': np.array(list(info)), 'info_labels': np.array([info[k] for k in info], np.int64),
+           'spt_json': json.dumps(spt), 'qry_json': json.dumps(qry), 'rng_after': np.random.get_state()[1].copy()}
+    for k, (n, s, d) in enumerate(graphs):
+        out['g%d_n' % k] = n; out['g%d_src' % k] = np.asarray(s, np.int32); out['g%d_dst' % k] = np.asarray(d, np.int32)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **out)
+    print('%-20s T=%d tasks, %d query lists topped up (k_query + 1 entries)  %.1f KB' % (name, T, n_short, os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024))
+
+
 if __name__ == '__main__':
     node_replay('r0_replay_h2', 500, 4, 6, 2, 40, 5, 11)
     node_replay('r1_replay_h3', 300, 3, 5, 3, 60, 3, 12)
     node_replay('r2_replay_h1', 400, 6, 5, 1, 12, 4, 13)
     link_replay('r3_replay_link', 20, 4, 14)
+    shared_short_class('r4_shared_short_class', 8, 15)

@@ -1,0 +1,131 @@
+"""GPU (-m gpu): regressions for the round-3 fixes.
+
+* Meta.forward_deferred without the fused Adam: every meta-batch must step the optimiser (meta.py:163-169), whether or not
+  the caller reads the accuracies (train.py reads them on report steps only).
+* A Shared-setup task topped up by the reference's short-class branch (sdp.py:218-238) is rejected by the query loss
+  (unequal class counts: torch.stack at meta.py:65 in the reference, gm_meta_step here).
+* The standalone gm_proto_loss_qry rejects a set whose class count differs from the prototypes'.
+* Aggregate launches of one batch from two streams: the hub-part counters / partial rows are ordered (gm_batch_hub_order)."""
+import argparse
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Fixture
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _step_inputs(fx):
+    from hip_util import fixture_batches, make_store
+    store = make_store(fx)
+    S, Q = fixture_batches(fx, store, True)
+    ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]
+    yq = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_qry']]
+    return store, S, Q, (S.views(), ys, Q.views(), yq)
+
+
+def test_unfused_adam_steps_on_every_meta_batch_without_reading_accs():
+    from hip_util import fixture_meta
+    fx = Fixture('g2_shared')
+    store, S, Q, inp = _step_inputs(fx)
+    fused = fixture_meta(fx)
+    if not fused._adam_fused:
+        pytest.skip('this torch build has no fused Adam: nothing to compare with')
+    for _ in range(3):
+        fused.forward_deferred(*inp).accs()
+    plain = fixture_meta(fx)
+    plain.meta_optim = torch.optim.Adam(plain.net.parameters(), lr=plain.meta_lr)
+    plain._adam_fused = False
+    handles = [plain.forward_deferred(*inp) for _ in range(3)]          # .accs() never called before the comparison
+    for a, b in zip(fused.net.parameters(), plain.net.parameters()):
+        np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=2e-6, rtol=0)
+    steps = {int(s['step']) for s in plain.meta_optim.state.values()}
+    assert steps == {3}
+    assert handles[-1].accs().shape == (fx.K + 1,)
+
+
+def test_topped_up_shared_task_is_rejected_by_the_query_loss():
+    import gmeta_amd
+    from gmeta_amd import synth
+    z = np.load(os.path.join(GOLD, 'r4_shared_short_class.npz'), allow_pickle=False)
+    args = argparse.Namespace(**json.loads(str(z['args'])))
+    graphs = [(int(z['g%d_n' % k]), z['g%d_src' % k], z['g%d_dst' % k]) for k in range(int(z['n_graphs']))]
+    tables = {'train': ([str(x) for x in z['csv_train.csv_names']], [str(x) for x in z['csv_train.csv_labels']])}
+    info = {str(k): int(v) for k, v in zip(z['info_names'], z['info_labels'])}
+    rng = np.random.default_rng(0)
+    feats = [rng.standard_normal((n, 8)).astype(np.float32) for n, _, _ in graphs]
+    store = gmeta_amd.GraphStore(graphs, feats)
+    torch.manual_seed(222); np.random.seed(222); random.seed(222)
+    db = gmeta_amd.Subgraphs(None, 'train', info, n_way=args.n_way, k_shot=args.k_spt, k_query=args.k_qry, batchsz=int(z['T']), args=args,
+                             adjs=store, h=args.h, tables=tables, verbose=False)
+    qry = json.loads(str(z['qry_json']))
+    bad = [t for t in range(int(z['T'])) if any(len(sub) != args.k_qry for sub in qry[t])]
+    good = [t for t in range(int(z['T'])) if t not in bad]
+    assert bad and good
+    m = gmeta_amd.Meta(args, synth.make_config(8, 16, args.h, 3)).to('cuda')
+    accs = m(*db.get_batch(good[:1]), feats)                             # an ordinary task of the same dataset trains
+    assert accs.shape == (args.update_step + 1,)
+    with pytest.raises(RuntimeError, match='unequal row counts'):
+        m(*db.get_batch(bad[:1]), feats)
+
+
+def test_proto_loss_qry_rejects_a_set_with_a_different_class_count():
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    fx = Fixture('g2_shared')
+    store, S, Q, inp = _step_inputs(fx)
+    C_out = 2
+    yq = np.concatenate([np.asarray(y).reshape(-1) for y in fx.z['y_qry']]).astype(np.int32)
+    ct = len(np.unique(yq[:Q.set_sub_off[1]]))
+    logits = torch.randn(Q.subs, C_out, device='cuda')
+    protos = torch.randn(Q.sets, ct, C_out, device='cuda')
+    loss = torch.zeros(Q.sets, device='cuda'); acc = torch.zeros(Q.sets, device='cuda')
+    rc = lib.gm_proto_loss_qry(Q.handle, _lib.ptr(logits), C_out, _lib.ptr(yq), _lib.ptr(protos), ct, _lib.ptr(loss), _lib.ptr(acc), None, None, _lib.stream_ptr())
+    assert rc == 0
+    y_bad = yq.copy()
+    s0, s1 = Q.set_sub_off[Q.sets - 1], Q.set_sub_off[Q.sets]
+    y_bad[s0:s1] = y_bad[s0]                                             # the last set collapses to ONE class (still equal counts per class)
+    rc = lib.gm_proto_loss_qry(Q.handle, _lib.ptr(logits), C_out, _lib.ptr(y_bad), _lib.ptr(protos), ct, _lib.ptr(loss), _lib.ptr(acc), None, None, _lib.stream_ptr())
+    assert rc != 0 and b'query classes' in lib.gm_last_error()
+
+
+def test_aggregate_of_one_batch_from_two_streams_is_ordered():
+    """gm_aggregate on a batch with split hub rows, alternating between two streams without any host synchronisation in between:
+    every result equals the single-stream one (the launches share arrival counters and partial-row scratch)."""
+    import gmeta_amd
+    from gmeta_amd import _lib, synth
+    lib = _lib.lib()
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=2)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=2, args=args,
+                             adjs=store, h=cfg['h'], tables=data['tables'], verbose=False)
+    b = db.get_batch([0, 1])
+    Q = b[2][0].view_of
+    F = 256
+    xs = [torch.randn(Q.rows, F, device='cuda') for _ in range(2)]
+    want = []
+    for x in xs:
+        o = torch.empty(Q.rows, F, device='cuda')
+        _lib.check(lib.gm_aggregate(Q.handle, 0, 0, _lib.ptr(x), F, None, None, _lib.ptr(o), _lib.stream_ptr()))
+        want.append(o)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = []
+    for rep in range(6):
+        k = rep % 2
+        o = torch.empty(Q.rows, F, device='cuda')
+        with torch.cuda.stream(streams[k]):
+            _lib.check(lib.gm_aggregate(Q.handle, 0, 0, _lib.ptr(xs[k]), F, None, None, _lib.ptr(o), _lib.stream_ptr()))
+        outs.append((k, o))
+    torch.cuda.synchronize()
+    for k, o in outs:
+        assert torch.equal(o, want[k])

@@ -117,3 +117,17 @@ def test_reference_mode_batches_hold_the_reference_node_sets(case):
     # the batched path visits tasks in the same order and reuses the memo
     b = db.get_batch(list(range(T)))
     assert len(b[0]) == T and sum(len(x) for x in b[6]) + sum(len(x) for x in b[7]) == (len(off) - 1) // int(z['passes'])
+
+
+def test_shared_short_class_top_up_follows_the_reference(monkeypatch):
+    """sdp.py:218-238: a Shared-setup class smaller than k_shot + k_query is topped up from random classes of the same graph (the
+    reference's bare `except:` branch).  With the reference's seeds the host mirror draws the same (ragged) task lists, consumes the
+    global RNG identically, and the topped-up task carries k_query + 1 query entries exactly like the reference's."""
+    import json as _json
+    z, args, graphs, tables, info = _load('r4_shared_short_class')
+    db = _db(z, args, tables, info, _HostStore(graphs), monkeypatch)
+    spt, qry = _json.loads(str(z['spt_json'])), _json.loads(str(z['qry_json']))
+    assert [[list(map(str, sub)) for sub in t] for t in db.support_x_batch] == spt
+    assert [[list(map(str, sub)) for sub in t] for t in db.query_x_batch] == qry
+    assert any(len(sub) == args.k_qry + 1 for t in qry for sub in t)
+    assert np.array_equal(np.random.get_state()[1], z['rng_after'])

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     const double fl = 2.0 * M * K * N;
     printf("split-bf16 GEMM: %.3f ms  %.1f TFLOP/s (fp32-equivalent)  %.1f TFLOP/s of bf16 MFMA work  %.2f TB/s of A+C traffic\n", ms, fl / ms / 1e9,
            6 * fl / ms / 1e9, ((double)M * K * 4 + (double)M * N * 4) / ms / 1e9);
-#if defined(FC_TRACE) || defined(PF_TRACE)
+#if defined(FC_TRACE)
     {
         std::vector<unsigned long long> d(3 * 64 * 4);
         CK(hipMemcpy(d.data(), dDbg, d.size() * 8, hipMemcpyDeviceToHost));
