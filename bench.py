@@ -128,12 +128,81 @@ def cpu_baseline(db, data, cfg, config, batch, budget_s=45.0):
         variants[name] = {'value': round(1.0 / med, 4), 'median_s_per_task': round(med, 3), 'tasks_timed': len(times), 'threads': best_nt,
                           'min_s': round(min(times), 3), 'max_s': round(max(times), 3), 'thread_probe_s_at_K2': probe}
     best = max(variants, key=lambda k: variants[k]['value'])
+    # ---- the same restatement with the tasks of the meta-batch run SIDE BY SIDE (they are independent, meta.py:118-161): W worker
+    # processes x the tuned thread count, all T tasks of the meta-batch, wall time from a common start to the last worker's end
+    par = None
+    try:
+        par = cpu_baseline_task_parallel(db, data, cfg, config, batch, theta, variants['numpy-omp']['threads'], host_cores)
+    except Exception as e:       # a reported extra, never the product path
+        par = {'value': None, 'error': repr(e)}
     return {'value': variants[best]['value'], 'unit': 'meta-tasks/s', 'cores': variants[best]['threads'], 'host_cores': host_cores, 'kind': 'port',
-            'variant': best, 'cpu_model': cpu_model(), 'variants': variants,
+            'variant': best, 'cpu_model': cpu_model(), 'variants': variants, 'task_parallel': par,
             'sample': 'whole tasks of the first meta-batch of the same config (K=%d inner steps incl. the meta-gradient), one task at a '
                       'time like the reference loop (meta.py:118), subgraphs pre-extracted on both sides; per variant: thread count tuned on '
                       'a K=2 probe of one task (full-width pools are slower on these op sizes), then up to 2 warm-up tasks and the median of '
                       '>= 5 timed tasks (fewer only if the time budget runs out); `cores` = threads the best variant used' % K}
+
+
+def cpu_baseline_task_parallel(db, data, cfg, config, batch, theta, threads, host_cores, max_workers=32):
+    """All tasks of the first meta-batch on the host cores at once: oracle/cpu_task_worker.py processes (fresh interpreters: no fork of
+    a process that holds a HIP context), `threads` BLAS/OpenMP threads each, as many workers as fit the cores (at most one per task)."""
+    import subprocess
+    import tempfile
+    S, Q = batch[0][0].view_of or batch[0][0], batch[2][0].view_of or batch[2][0]
+    T = len(batch[0])
+    workers = max(1, min(T, max_workers, host_cores // max(threads, 1)))
+    arrs = {'hp': json.dumps({'k_spt': cfg['k_spt'], 'update_lr': cfg['update_lr'], 'K': cfg['update_step']}),
+            'config': json.dumps([[n, list(p)] for n, p in config]), 'n_graphs': len(data['graphs']), 'n_theta': len(theta)}
+    for g, (n, src, dst) in enumerate(data['graphs']):
+        arrs['g%d_n' % g] = n; arrs['g%d_src' % g] = np.asarray(src); arrs['g%d_dst' % g] = np.asarray(dst); arrs['feat%d' % g] = data['feats'][g]
+    for k, v in enumerate(theta):
+        arrs['theta%d' % k] = v
+    for t in range(T):
+        for side, B, seeds in (('s', S, db._task_arrays(t)[0]), ('q', Q, db._task_arrays(t)[1])):
+            so, par, off = B.set_sub_off, B.parent(), B.sub_off
+            lists = [par[off[k]:off[k + 1]] for k in range(so[t], so[t + 1])]
+            arrs['t%d_%s_seeds' % (t, side)] = np.asarray(seeds, np.int64)
+            arrs['t%d_%s_nodes' % (t, side)] = np.concatenate(lists).astype(np.int64)
+            arrs['t%d_%s_off' % (t, side)] = np.cumsum([0] + [len(x) for x in lists]).astype(np.int64)
+        arrs['t%d_ys' % t] = np.asarray(batch[1][t]); arrs['t%d_yq' % t] = np.asarray(batch[3][t])
+    tmp = tempfile.mkdtemp(prefix='gmeta_cpu_')
+    path = os.path.join(tmp, 'inputs.npz')
+    np.savez(path, **arrs)
+    env = dict(os.environ)
+    for k in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        env[k] = str(threads)
+    env['CUDA_VISIBLE_DEVICES'] = ''; env['HIP_VISIBLE_DEVICES'] = ''
+    procs = []
+    try:
+        for w in range(workers):
+            ids = ','.join(str(t) for t in range(w, T, workers))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'oracle', 'cpu_task_worker.py'), path, ids], stdin=subprocess.PIPE,
+                                          stdout=subprocess.PIPE, text=True, env=env))
+        for p in procs:                                    # inputs built, warm-up done
+            line = p.stdout.readline()
+            if line.strip() != 'READY':
+                raise RuntimeError('cpu worker failed to start: %r' % line)
+        t0 = time.perf_counter()
+        for p in procs:
+            p.stdin.write('go\n'); p.stdin.flush()
+        per_task = []
+        for p in procs:
+            per_task += json.loads(p.stdout.readline())['seconds']
+        wall = time.perf_counter() - t0
+    finally:
+        for p in procs:
+            try:
+                p.stdin.close(); p.wait(timeout=30)
+            except Exception:
+                p.kill()
+        try:
+            os.remove(path); os.rmdir(tmp)
+        except OSError:
+            pass
+    return {'value': round(T / wall, 3), 'unit': 'meta-tasks/s', 'wall_s': round(wall, 3), 'tasks': T, 'workers': workers, 'threads_per_worker': threads,
+            'cores': workers * threads, 'host_cores': host_cores, 'median_s_per_task': round(float(np.median(per_task)), 3),
+            'what': 'numpy-omp variant, all %d tasks of the meta-batch run side by side by %d worker processes x %d threads (the tasks are independent, '
+                    'meta.py:118-161; the reference itself loops them serially), wall time from a common start to the last worker' % (T, workers, threads)}
 
 
 def main():

@@ -196,6 +196,17 @@ int gm_num_cus() {
     return n;
 }
 
+static std::map<hipStream_t, int> g_stream_cus;
+int gm_stream_cus(hipStream_t s) {
+    {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        auto it = g_stream_cus.find(s);
+        if (it != g_stream_cus.end()) return it->second;
+    }
+    return gm_num_cus();
+}
+void gm_stream_set_cus(hipStream_t s, int cus) { std::lock_guard<std::mutex> lk(g_dev_mu); g_stream_cus[s] = cus; }
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize = 160 KiB) once per (device, kernel)
 int gm_func_full_lds(const void* fn) {
     static std::set<std::pair<int, const void*>> done;

@@ -522,8 +522,9 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;
         // persistent: one workgroup per CU (it fills the CU's register file, so nothing else co-resides).  GM_GEMM_SPLIT_GRID caps the
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
+        const int cus = gm_stream_cus(s);                                 // the stream's CU mask, if it has one
         int grid_cap = gm_knob().gemm_split_grid;
-        if (grid_cap <= 0 || grid_cap > gm_num_cus()) grid_cap = gm_num_cus();
+        if (grid_cap <= 0 || grid_cap > cus) grid_cap = cus;
         if (a.fuse2) {
             // fused aggregate + GEMM: A addresses the aggregate's input rows, rows of other degrees come finished from a.zside
             GM_REQUIRE(a.K / 16 >= PF_DA && a.zside && (a.ldz % 4 == 0) && (((uintptr_t)a.zside & 15) == 0), GM_EINVAL, "gemm: fused aggregate needs K >= %d and an aligned side buffer", 16 * PF_DA);

@@ -306,6 +306,10 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 // 280 chunks cost two rounds for the work of 1.1 -- and be small: every chunk adds a partial to write and re-read.
 // Chunks never straddle two sets (per-task weights).  Returns a multiple of 32.
 int gm_num_cus();                         // compute units of the current device (cached per device)
+// CUs a stream may use: the device's, unless the stream was created with a CU mask (gm_meta_step's CU-partitioned streams register theirs).
+// Persistent kernels size their grid with this.
+int gm_stream_cus(hipStream_t s);
+void gm_stream_set_cus(hipStream_t s, int cus);
 int gm_func_full_lds(const void* fn);     // allow 160 KiB of dynamic LDS for a kernel, once per (device, kernel)
 static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n_cu = gm_num_cus()) {
     const int sets = (int)set_off.size() - 1;

@@ -940,8 +940,22 @@ static gm_model_t internal_model(const gm_model_t* m, const gm_store* store, int
 
 struct MetaStreams {
     hipStream_t side = nullptr;
+    hipStream_t main = nullptr;      // CU-partitioned mode only (GM_CU_MASK_SUPPORT): the support chain's own stream, masked to its CUs
     std::vector<hipEvent_t> ev;
     int ensure(int n) {
+        const int per_xcd = gm_knob().cu_mask_support;
+        if (!side && per_xcd > 0 && per_xcd * GM_NXCD < gm_num_cus()) {
+            // CU-partitioned streams: the support chain owns `per_xcd` CUs of every XCD, the query evaluations the rest, so that kernels of
+            // the two chains CO-RESIDE on the chip instead of time-slicing it (a persistent 1024-thread GEMM workgroup needs a completely
+            // empty CU, which it never gets while the other queue keeps feeding small workgroups).  Mask bit i = CU i / 8 of XCD i % 8
+            // (the driver deals queue mask bits round-robin over the XCDs), so [0, 8 s) is s CUs on each XCD.
+            const int cus = gm_num_cus(), ns = per_xcd * GM_NXCD, words = (cus + 31) / 32;
+            std::vector<uint32_t> ms(words, 0u), mq(words, 0u);
+            for (int i = 0; i < cus; ++i) (i < ns ? ms : mq)[i >> 5] |= 1u << (i & 31);
+            GM_HIP(hipExtStreamCreateWithCUMask(&main, (uint32_t)words, ms.data()));
+            GM_HIP(hipExtStreamCreateWithCUMask(&side, (uint32_t)words, mq.data()));
+            gm_stream_set_cus(main, ns); gm_stream_set_cus(side, cus - ns);
+        }
         if (!side) {
             // The query stream carries bulk, throughput-bound work; the caller's stream carries the latency-critical
             // support chain.  A lower priority (a) lets support kernels win CUs when both have work and (b) gives this
@@ -1123,12 +1137,18 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the
     // prototypes of step k-1.  The small latency-bound support kernels thus overlap the throughput-bound query work.
     MetaStreams& ms = meta_streams();
-    GM_TRY(ms.ensure(2 * K + 8));
+    GM_TRY(ms.ensure(2 * K + 10));
     hipStream_t sq = hp->serialize ? st : ms.side;
+    hipStream_t const st0 = st;                            // the caller's stream: inputs arrive on it, the output leaves on it
+    if (!hp->serialize && ms.main) st = ms.main;           // CU-partitioned mode: the support chain runs on its own masked stream
     int ev = 0;
     auto signal = [&](hipStream_t from) -> hipEvent_t { hipEvent_t e = ms.ev[ev++]; (void)hipEventRecord(e, from); return e; };
     auto wait = [&](hipStream_t who, hipEvent_t e) { (void)hipStreamWaitEvent(who, e, 0); };
-    wait(sq, signal(st));                                  // inputs (theta, class tables, batches) are ready
+    {
+        hipEvent_t e_in = signal(st0);                     // inputs (theta, class tables, batches) are ready
+        wait(sq, e_in);
+        if (st != st0) wait(st, e_in);
+    }
 
     auto fw = [&](int k) -> float* { return p.fw + (int64_t)(k - 1) * p.TP; };       // fw_k, k = 1..K
     auto protos = [&](int k) -> float* { return p.protos + (int64_t)k * p.proto_sz; };   // prototypes of support step k
@@ -1187,7 +1207,9 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
             have_grad = true;
         }
     }
-    wait(st, signal(sq));                                  // join
+    wait(st0, signal(sq));                                 // join
+    if (st != st0) wait(st0, signal(st));
+    st = st0;
     const int64_t tot = Lu.P + 2 * K1 + 1 + (int64_t)T * K1;
     hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
                        have_grad ? p.gq : nullptr, p.gp, Pp, Lu.P, T, p.lq, p.aq, K1, out, cut, shift);

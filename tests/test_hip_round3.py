@@ -44,8 +44,13 @@ def test_unfused_adam_steps_on_every_meta_batch_without_reading_accs():
     plain.meta_optim = torch.optim.Adam(plain.net.parameters(), lr=plain.meta_lr)
     plain._adam_fused = False
     handles = [plain.forward_deferred(*inp) for _ in range(3)]          # .accs() never called before the comparison
-    for a, b in zip(fused.net.parameters(), plain.net.parameters()):
+    # (the head's bias is left out: its gradient is identically zero up to fp noise -- prototype distances are shift invariant -- so
+    # Adam moves it by sign(noise) * lr and the fused / foreach kernels may disagree on that sign)
+    pf, pp = list(fused.net.parameters()), list(plain.net.parameters())
+    for a, b in zip(pf[:-1], pp[:-1]):
         np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=2e-6, rtol=0)
+    moved = max(float((a.detach() - torch.from_numpy(v).to(a.device)).abs().max()) for a, v in zip(pp[:-1], fx.vars0[:-1]))
+    assert moved > 1e-4                                                    # three Adam steps really happened
     steps = {int(s['step']) for s in plain.meta_optim.state.values()}
     assert steps == {3}
     assert handles[-1].accs().shape == (fx.K + 1,)
@@ -72,7 +77,7 @@ def test_topped_up_shared_task_is_rejected_by_the_query_loss():
     m = gmeta_amd.Meta(args, synth.make_config(8, 16, args.h, 3)).to('cuda')
     accs = m(*db.get_batch(good[:1]), feats)                             # an ordinary task of the same dataset trains
     assert accs.shape == (args.update_step + 1,)
-    with pytest.raises(RuntimeError, match='unequal row counts'):
+    with pytest.raises(ValueError, match='unequal row counts'):        # GM_EINVAL -> ValueError (torch.stack raises in the reference)
         m(*db.get_batch(bad[:1]), feats)
 
 
