@@ -869,23 +869,33 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
 // The MFMA k dimension is the ROW index, so an operand lane needs 8 consecutive rows of one column: the staged planes are
 // [row octet][column][8 rows] bf16 -- a fragment read is a contiguous ds_read_b128 run (conflict-free) and a thread that loads
 // one column of 8 rows (8 dword loads, lanes on consecutive columns: 256-B coalesced rows) writes one 16-byte unit per plane.
-// Stage = 16 rows (one MFMA k step): 2 octets x (K + N) columns = 1024 or 768 (octet, column) items over 1024 threads;
-// loads of stage s+1 fly under the MFMAs of stage s, split + LDS store follow (double-buffered planes, one barrier per stage).
-// 16 waves in a 4 x 4 grid, wave (wy, wx) owns tiles tk in [wy*NTK, +NTK) x tn in [wx*NTN, +NTN).  db = column sums of G from
-// the loader registers.  Output: the same per-chunk partial [(K+1) x N] as k_wgrad_fast (reduced by k_wgrad_reduce).
-template <int NTK, int NTN>
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad_split(WgradK w) {
-    constexpr int K = NTK * 128, N = NTN * 128, COLS = K + N;
+// Stage = 16 rows (one MFMA k step): 2 octets x (K + N) columns = 1024 or 768 (octet, column) items, two per thread.
+//
+// Round 3: EIGHT waves (512 threads) in a 4 x 2 grid instead of sixteen in 4 x 4.  One 16-row stage is ~1.5 us of MFMA work and a global
+// round trip under load is 2-3 us; the 16-wave kernel had 128 registers per wave -- 64 of them accumulators -- and room for ONE stage of
+// loader registers, so every stage waited for its rows (the kernel ran at the memory latency: 851 us on the 1.14 M-row batch for 430 us
+// of MFMA work).  With 256 registers per wave the rows of TWO stages are in flight (inline-asm loads, hand-counted vmcnt: the compiler
+// collapses a deeper register prefetch at the loop back-edge) and a wave owns 2 x 4 (K = 256: NTK x NTN) tiles, i.e. 18 instead of 36
+// fragment reads per 48 MFMAs.  Accumulation order per output element is unchanged (stages in row order, the six products in the same
+// order), so the partials are bit-identical to the 16-wave kernel's.  Row scales: rows are wave-uniform, so lane j & 7 fetches row j's
+// scale with ONE load per item and stage, read back with v_readlane.  db = column sums of G from the loader registers.
+// Output: the same per-chunk partial [(K+1) x N] as k_wgrad_fast (reduced by k_wgrad_reduce).
+#define WGS_THREADS 512
+__device__ const float gm_wgs_ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // the row "scales" of an unscaled operand
+template <int KT, int NT>
+__global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
+    constexpr int K = KT * 128, N = NT * 128, COLS = K + N;
+    constexpr int NTK = KT, NTN = 2 * NT;                                           // 32 x 32 tiles per wave: (K / 32) / 4 x (N / 32) / 2
     constexpr int A_PLANE = 2 * K * 16, G_PLANE = 2 * N * 16;                       // bytes: [2 octets][cols][8 rows] bf16
     constexpr int STAGE = 3 * A_PLANE + 3 * G_PLANE;                                // 96 * (K + N) bytes: 48 KiB at 256 + 256
-    constexpr int ITEMS = 2 * COLS, IPT = (ITEMS + WG_THREADS - 1) / WG_THREADS;    // (octet, column) items per thread: 1
-    static_assert(IPT == 1, "one (octet, column) item per thread");
+    constexpr int ITEMS = 2 * COLS;                                                 // (octet, column) items per stage: 512 .. 1024
+    static_assert(2 * K <= WGS_THREADS && 2 * N <= WGS_THREADS && K % 64 == 0 && N % 64 == 0, "one wave-uniform item per operand and thread");
     extern __shared__ __attribute__((aligned(16))) float sm_f[];
     char* sm = reinterpret_cast<char*>(sm_f);
     const int chunk = blockIdx.x;
     const int row0 = w.chunks[chunk * 3 + 1], nrows = w.chunks[chunk * 3 + 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, kh = lane >> 5;
-    const int wy = wave >> 2, wx = wave & 3;
+    const int wy = wave >> 1, wx = wave & 1;
     gm_f32x16 acc[NTK][NTN];
 #pragma unroll
     for (int a = 0; a < NTK; ++a)
@@ -893,80 +903,129 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_split(WgradK w) {
         for (int b = 0; b < NTN; ++b)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    // ---- loader item of this thread: octet `oct` of the stage, column `col` of [A | G]
-    const bool active = tid < ITEMS;
-    const int oct = tid / COLS, col = tid - oct * COLS;
-    const bool isA = col < K;
-    const float* src = isA ? w.A + col : w.G + (col - K);
-    const int64_t ld = isA ? w.lda : w.ldg;
-    const int dst = (isA ? 0 : 3 * A_PLANE) + oct * (isA ? K : N) * 16 + (isA ? col : col - K) * 16;
-    const int plane = isA ? A_PLANE : G_PLANE;
-    float pf[8], ps[8];
-    float bsum = 0.f;
-    const bool scaled = isA && w.a_scale;
-    auto load_stage = [&](int r0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = min(r0 + oct * 8 + j, nrows - 1);                         // clamped; validity applied at split time
-            pf[j] = active ? src[(int64_t)(row0 + r) * ld] : 0.f;
-            ps[j] = scaled ? w.a_scale[row0 + r] : 1.f;                             // prefetched with the data (wave-uniform address)
-        }
+    // ---- the two loader items of this thread: item 0 = (octet, column) of A, item 1 = (octet, column) of G; the octet is wave-uniform
+    // (K, N are multiples of 64).  K or N = 128: only the first 256 threads have an item of that operand; the others shadow item
+    // (0, 0) -- they load (uniform vmcnt) but never store.
+    auto uni64 = [](const void* q) -> uint64_t {
+        const uint64_t v = (uint64_t)(uintptr_t)q;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return ((uint64_t)hi << 32) | lo;                                           // (unsigned: the builtin returns int, which would sign-extend)
     };
-    auto store_stage = [&](int r0, char* S) {
-        if (!active) return;
-        uint32_t h[8], m[8], l[8];
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    bool valid[2]; int oct8[2], dst[2], gcol;
+    unsigned ld_b[2], col_b[2]; uint64_t sbase[2];
+    constexpr bool isA[2] = {true, false};
+    constexpr int plane[2] = {A_PLANE, G_PLANE};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = r0 + oct * 8 + j;
-            float x = r < nrows ? pf[j] * ps[j] : 0.f;                              // rows past the chunk end contribute zeros
-            if (!isA) bsum += x;
-            const uint32_t bx = __float_as_uint(x);
-            h[j] = bx & 0xffff0000u;
-            const float r1 = x - __uint_as_float(h[j]);
-            m[j] = __float_as_uint(r1) & 0xffff0000u;
-            l[j] = __float_as_uint(r1 - __uint_as_float(m[j]));
-        }
-        uint4 vh, vm, vl;
-        vh.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); vh.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
-        vh.z = __builtin_amdgcn_perm(h[5], h[4], 0x07060302u); vh.w = __builtin_amdgcn_perm(h[7], h[6], 0x07060302u);
-        vm.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); vm.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
-        vm.z = __builtin_amdgcn_perm(m[5], m[4], 0x07060302u); vm.w = __builtin_amdgcn_perm(m[7], m[6], 0x07060302u);
-        vl.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); vl.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
-        vl.z = __builtin_amdgcn_perm(l[5], l[4], 0x07060302u); vl.w = __builtin_amdgcn_perm(l[7], l[6], 0x07060302u);
-        *reinterpret_cast<uint4*>(S + dst) = vh;
-        *reinterpret_cast<uint4*>(S + dst + plane) = vm;
-        *reinterpret_cast<uint4*>(S + dst + 2 * plane) = vl;
-    };
-    const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = 3 * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
-    load_stage(0);
-    store_stage(0, sm);
-    __syncthreads();
-    int cur = 0;
-    for (int r0 = 0; r0 < nrows; r0 += 16, cur ^= 1) {
-        const bool more = r0 + 16 < nrows;
-        const char* S = sm + cur * STAGE;
-        if (more) load_stage(r0 + 16);
-#pragma unroll
-        for (int a = 0; a < NTK; ++a) {
-            gm_bf16x8 af[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + a * 512);
-#pragma unroll
-            for (int b = 0; b < NTN; ++b) {
-                gm_bf16x8 gf[3];
-#pragma unroll
-                for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>(S + g_lane + p * G_PLANE + b * 512);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], gf[0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[2], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], gf[0], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[1], acc[a][b], 0, 0, 0);
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], gf[0], acc[a][b], 0, 0, 0);
-            }
-        }
-        if (more) store_stage(r0 + 16, sm + (cur ^ 1) * STAGE);        // the other buffer was last read before the previous barrier
-        __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+        constexpr int dummy = 0; (void)dummy;
+        const int W = it == 0 ? K : N;                                              // columns of this operand
+        valid[it] = wave_u * 64 < 2 * W;                                            // (wave-uniform)
+        const int oct = valid[it] ? (wave_u * 64) / W : 0, c = valid[it] ? tid - oct * W : 0;
+        oct8[it] = oct * 8;
+        dst[it] = (it == 0 ? 0 : 3 * A_PLANE) + oct * W * 16 + c * 16;
+        if (it == 1) gcol = oct * N + c;
+        const int64_t ld = it == 0 ? w.lda : w.ldg;
+        // addresses: a wave-uniform 64-bit base (the operand at the chunk's first row / the scale vector) in SGPRs + ONE 32-bit byte
+        // offset per load (row * ld + column; a chunk spans far less than 4 GiB)
+        const float* base = (it == 0 ? w.A : w.G) + (int64_t)row0 * ld;
+        sbase[it] = uni64(base);
+        ld_b[it] = (unsigned)ld * 4u; col_b[it] = (unsigned)c * 4u;
     }
+    // A's row scales (G has none): lane j & 7 of the wave fetches row j's scale; an unscaled A reads a vector of ones (branch-free)
+    const bool scaled = w.a_scale != nullptr;
+    const uint64_t sscale = uni64(scaled ? (const void*)(w.a_scale + row0) : (const void*)gm_wgs_ones);
+    float pf[2][2][8], ps[2];                                                       // [slot = stage parity][item][row], [slot]
+    float bsum = 0.f;
+    // Stage R0 / 16 -> slot SL: 17 loads per thread, ALWAYS issued (rows are clamped to the chunk, so a stage past the end re-reads the
+    // last row and is never stored): every wait is the same vmcnt(17) and the loop body has no control flow around the asm
+#define WGS_ISSUE(R0, SL)                                                                                                  \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                 \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+                const unsigned off = (unsigned)min((R0) + oct8[it] + j, nrows - 1) * ld_b[it] + col_b[it];                 \
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(pf[SL][it][j]) : "v"(off), "s"(sbase[it]) : "memory"); \
+            }                                                                                                              \
+        }                                                                                                                  \
+        const unsigned offs = scaled ? (unsigned)min((R0) + oct8[0] + (lane & 7), nrows - 1) * 4u : (unsigned)(lane & 7) * 4u; \
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(ps[SL]) : "v"(offs), "s"(sscale) : "memory");                  \
+    } while (0)
+#define WGS_TIE(SL, IT) "+v"(pf[SL][IT][0]), "+v"(pf[SL][IT][1]), "+v"(pf[SL][IT][2]), "+v"(pf[SL][IT][3]), "+v"(pf[SL][IT][4]), "+v"(pf[SL][IT][5]), "+v"(pf[SL][IT][6]), "+v"(pf[SL][IT][7])
+    // slot SL has landed once at most the 17 loads of the stage issued after it are outstanding
+#define WGS_WAIT(SL) asm volatile("s_waitcnt vmcnt(17)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
+#define WGS_DRAIN(SL) asm volatile("s_waitcnt vmcnt(0)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
+    // split + store, one plane at a time with the residual kept in place (x <- x - hi16(x), exact)
+#define WGS_STORE(R0, SL, S_)                                                                                              \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                 \
+            if (!valid[it]) continue;                                                                                      \
+            float x[8];                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+                const int r = (R0) + oct8[it] + j;                                                                         \
+                float v_ = pf[SL][it][j];                                                                                  \
+                if (it == 0) v_ *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ps[SL]), j));                   \
+                x[j] = r < nrows ? v_ : 0.f;                                        /* rows past the chunk end contribute zeros */ \
+                if (it == 1) bsum += x[j];                                                                                 \
+            }                                                                                                              \
+            _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                                                          \
+                uint4 v;                                                            /* hi16 of eight values, packed pairwise */ \
+                v.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);                    \
+                v.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);                    \
+                v.z = __builtin_amdgcn_perm(__float_as_uint(x[5]), __float_as_uint(x[4]), 0x07060302u);                    \
+                v.w = __builtin_amdgcn_perm(__float_as_uint(x[7]), __float_as_uint(x[6]), 0x07060302u);                    \
+                *reinterpret_cast<uint4*>((S_) + dst[it] + pl_ * plane[it]) = v;                                           \
+                if (pl_ < 2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] = x[j] - __uint_as_float(__float_as_uint(x[j]) & 0xffff0000u); } \
+            }                                                                                                              \
+        }                                                                                                                  \
+    } while (0)
+    const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = 3 * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
+    auto mfma_stage = [&](const char* S) {
+        gm_bf16x8 af[NTK][3];                           // the A fragments of the wave's tile rows stay resident, the G fragments stream by
+#pragma unroll
+        for (int a = 0; a < NTK; ++a)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + a * 512);
+#pragma unroll
+        for (int b = 0; b < NTN; ++b) {
+            gm_bf16x8 gf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>(S + g_lane + p * G_PLANE + b * 512);
+            // product by product over the tile rows: independent accumulators back to back (per tile the order of the six products is
+            // the 16-wave kernel's: l*h, h*l, m*m, m*h, h*m, h*h)
+#define WGS_PROD(PA, PB) _Pragma("unroll") for (int a = 0; a < NTK; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], gf[PB], acc[a][b], 0, 0, 0);
+            WGS_PROD(2, 0) WGS_PROD(0, 2) WGS_PROD(1, 1) WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0)
+#undef WGS_PROD
+        }
+    };
+    // Stage s lives in LDS buffer s & 1 and came through register slot s & 1.  Half-iteration of stage s: issue stage s + 2 (its slot was
+    // emptied into LDS one half-iteration ago), MFMAs of stage s, then split stage s + 1 into the other LDS buffer (last read before the
+    // previous barrier).  Two half-iterations per loop trip so that the slots are compile-time registers.
+    const int nst = (nrows + 15) >> 4;
+    char* const S0 = sm; char* const S1 = sm + STAGE;
+    WGS_ISSUE(0, 0);
+    WGS_ISSUE(16, 1);
+    WGS_WAIT(0);
+    WGS_STORE(0, 0, S0);
+    GS_BARRIER();
+#pragma unroll 1
+    for (int st = 0; st < nst; st += 2) {
+        WGS_ISSUE((st + 2) * 16, 0);
+        mfma_stage(S0);
+        WGS_WAIT(1);
+        if (st + 1 < nst) WGS_STORE((st + 1) * 16, 1, S1);
+        GS_BARRIER();
+        WGS_ISSUE((st + 3) * 16, 1);
+        if (st + 1 < nst) mfma_stage(S1);
+        WGS_WAIT(0);
+        if (st + 2 < nst) WGS_STORE((st + 2) * 16, 0, S0);
+        GS_BARRIER();
+    }
+    WGS_DRAIN(1);                                       // the last (never used) issue: nothing may land in a register after this point
+#undef WGS_ISSUE
+#undef WGS_TIE
+#undef WGS_WAIT
+#undef WGS_DRAIN
+#undef WGS_STORE
     float* out = w.partial + (int64_t)chunk * (K + 1) * N;
 #pragma unroll
     for (int a = 0; a < NTK; ++a)
@@ -978,17 +1037,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_split(WgradK w) {
         }
     // db: the two octet threads of a G column add up through LDS (fixed order)
     float* red = reinterpret_cast<float*>(sm);
-    if (active && !isA) red[oct * N + (col - K)] = bsum;
+    if (valid[1]) red[gcol] = bsum;
     __syncthreads();
     if (tid < N) out[(int64_t)K * N + tid] = red[tid] + red[N + tid];
 }
 
-template <int NTK, int NTN>
+template <int KT, int NT>
 static int launch_wgrad_split(const WgradK& w, hipStream_t s) {
-    constexpr int K = NTK * 128, N = NTN * 128;
+    constexpr int K = KT * 128, N = NT * 128;
     const size_t lds = 2 * 96 * (size_t)(K + N);
-    GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<NTK, NTN>));
-    hipLaunchKernelGGL((k_wgrad_split<NTK, NTN>), dim3(w.n_chunks), dim3(WG_THREADS), lds, s, w);
+    GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT>));
+    hipLaunchKernelGGL((k_wgrad_split<KT, NT>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
     return GM_OK;
 }
 
