@@ -173,7 +173,6 @@ const gm_knobs& gm_knob() {
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
-        k.head_blocks = env("GM_HEAD_BLOCKS", 1);
     });
     return k;
 }

@@ -954,11 +954,11 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     // slot SL has landed once at most the 17 loads of the stage issued after it are outstanding
 #define WGS_WAIT(SL) asm volatile("s_waitcnt vmcnt(17)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
 #define WGS_DRAIN(SL) asm volatile("s_waitcnt vmcnt(0)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
-    // split + store, one plane at a time with the residual kept in place (x <- x - hi16(x), exact)
-#define WGS_STORE(R0, SL, S_)                                                                                              \
+    // split + store of ONE item, one plane at a time with the residual kept in place (x <- x - hi16(x), exact)
+#define WGS_STORE_IT(R0, SL, S_, IT)                                                                                       \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                 \
-            if (!valid[it]) continue;                                                                                      \
+        constexpr int it = (IT);                                                                                           \
+        if (valid[it]) {                                                                                                   \
             float x[8];                                                                                                    \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
                 const int r = (R0) + oct8[it] + j;                                                                         \
@@ -978,28 +978,31 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
             }                                                                                                              \
         }                                                                                                                  \
     } while (0)
+#define WGS_STORE(R0, SL, S_) do { WGS_STORE_IT(R0, SL, S_, 0); WGS_STORE_IT(R0, SL, S_, 1); } while (0)
     const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = 3 * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
-    auto mfma_stage = [&](const char* S) {
-        gm_bf16x8 af[NTK][3];                           // the A fragments of the wave's tile rows stay resident, the G fragments stream by
-#pragma unroll
-        for (int a = 0; a < NTK; ++a)
-#pragma unroll
-            for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + a * 512);
-#pragma unroll
-        for (int b = 0; b < NTN; ++b) {
-            gm_bf16x8 gf[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>(S + g_lane + p * G_PLANE + b * 512);
-            // product by product over the tile rows: independent accumulators back to back (per tile the order of the six products is
-            // the 16-wave kernel's: l*h, h*l, m*m, m*h, h*m, h*h)
+    // One stage: the MFMAs over LDS buffer SCUR with the split + store of the NEXT stage (register slot SLN -> LDS buffer SNEXT, last read
+    // before the previous barrier) interleaved between the tile columns, so that the VALU work of the split runs under the matrix pipe
+    // instead of after it (two waves per SIMD reach the end of their MFMAs together: as a separate phase the split left the pipe idle
+    // for ~30 % of a stage).  The A fragments of the wave's tile rows stay resident, the G fragments stream by; per tile the order of the
+    // six products is the 16-wave kernel's (l*h, h*l, m*m, m*h, h*m, h*h).  A stage past the chunk end is all zeros: its MFMAs add +0.
+#define WGS_STAGE(SCUR, R0N, SLN, SNEXT)                                                                                   \
+    do {                                                                                                                   \
+        gm_bf16x8 af[NTK][3];                                                                                              \
+        _Pragma("unroll") for (int a = 0; a < NTK; ++a)                                                                    \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const gm_bf16x8*>((SCUR) + a_lane + p * A_PLANE + a * 512); \
+        WGS_WAIT(SLN);                                                                                                     \
+        _Pragma("unroll") for (int b = 0; b < NTN; ++b) {                                                                  \
+            gm_bf16x8 gf[3];                                                                                               \
+            _Pragma("unroll") for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>((SCUR) + g_lane + p * G_PLANE + b * 512); \
+            WGS_PROD(2, 0) WGS_PROD(0, 2) WGS_PROD(1, 1) WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0)                      \
+            if (b == 0) WGS_STORE_IT(R0N, SLN, SNEXT, 0);                                                                  \
+            if (b == NTN / 2) WGS_STORE_IT(R0N, SLN, SNEXT, 1);                                                            \
+        }                                                                                                                  \
+    } while (0)
 #define WGS_PROD(PA, PB) _Pragma("unroll") for (int a = 0; a < NTK; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], gf[PB], acc[a][b], 0, 0, 0);
-            WGS_PROD(2, 0) WGS_PROD(0, 2) WGS_PROD(1, 1) WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0)
-#undef WGS_PROD
-        }
-    };
     // Stage s lives in LDS buffer s & 1 and came through register slot s & 1.  Half-iteration of stage s: issue stage s + 2 (its slot was
-    // emptied into LDS one half-iteration ago), MFMAs of stage s, then split stage s + 1 into the other LDS buffer (last read before the
-    // previous barrier).  Two half-iterations per loop trip so that the slots are compile-time registers.
+    // emptied into LDS one half-iteration ago), then the stage.  Two half-iterations per loop trip so that the slots are compile-time
+    // registers; no control flow around the asm (a copy the compiler inserted on one arm of a branch read a register before its wait).
     const int nst = (nrows + 15) >> 4;
     char* const S0 = sm; char* const S1 = sm + STAGE;
     WGS_ISSUE(0, 0);
@@ -1010,14 +1013,10 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
 #pragma unroll 1
     for (int st = 0; st < nst; st += 2) {
         WGS_ISSUE((st + 2) * 16, 0);
-        mfma_stage(S0);
-        WGS_WAIT(1);
-        if (st + 1 < nst) WGS_STORE((st + 1) * 16, 1, S1);
+        WGS_STAGE(S0, (st + 1) * 16, 1, S1);
         GS_BARRIER();
         WGS_ISSUE((st + 3) * 16, 1);
-        if (st + 1 < nst) mfma_stage(S1);
-        WGS_WAIT(0);
-        if (st + 2 < nst) WGS_STORE((st + 2) * 16, 0, S0);
+        WGS_STAGE(S1, (st + 2) * 16, 0, S0);
         GS_BARRIER();
     }
     WGS_DRAIN(1);                                       // the last (never used) issue: nothing may land in a register after this point
@@ -1026,6 +1025,9 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
 #undef WGS_WAIT
 #undef WGS_DRAIN
 #undef WGS_STORE
+#undef WGS_STORE_IT
+#undef WGS_STAGE
+#undef WGS_PROD
     float* out = w.partial + (int64_t)chunk * (K + 1) * N;
 #pragma unroll
     for (int a = 0; a < NTK; ++a)

@@ -152,7 +152,6 @@ struct gm_knobs {
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
-    int head_blocks;               // workgroups per task of the head/loss kernel's gather phase
 };
 const gm_knobs& gm_knob();
 
