@@ -15,6 +15,12 @@ from .learner import Classifier
 from .subgraphs import SubgraphBatch
 
 
+import os as _os
+# how the per-step all-reduce is issued: 'plain' (default) queues it behind the meta-step on the stream, no host synchronisation;
+# 'async' = async_op + stream-level wait; 'sync' drains the compute stream first (round 2's workaround, see forward_deferred)
+_ALLREDUCE_MODE = _os.environ.get('GMETA_ALLREDUCE_MODE', 'plain')
+
+
 class Meta(nn.Module):
     def __init__(self, args, config):                                          # meta.py:83-99
         super(Meta, self).__init__()
@@ -173,11 +179,17 @@ class Meta(nn.Module):
         K1 = K + 1
         head = out[:P + 2 * K1 + 1]                           # [grad | losses_q | corrects | task count], contiguous view
         if self._dist_on() and (torch.distributed.get_world_size() > 1 or getattr(self, 'force_allreduce', False)):
-            # Drain the compute stream first: queued behind pending work on another stream, torch's synchronous NCCL
-            # all_reduce takes a slow wait path on this stack (measured: a constant +7 ms per call; 32 us otherwise).
-            if head.is_cuda:
+            # Round 2 drained the compute stream before the all-reduce (a +7 ms slow wait path when the collective was queued behind work on a
+            # same-priority side stream).  With the query stream on its own low-priority hardware queue that path is gone: measured with a
+            # 1-rank RCCL group (GMETA_FORCE_DIST=1), 4-task shard: no group 4.93 ms, plain 4.93, async 4.96, drained first 5.04 -- so the
+            # all-reduce is simply queued on the stream and the host never waits (GMETA_ALLREDUCE_MODE=sync restores the drain).
+            mode = _ALLREDUCE_MODE
+            if mode == 'sync' and head.is_cuda:
                 torch.cuda.current_stream().synchronize()
-            torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
+            if mode == 'async':
+                torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM, async_op=True).wait()     # stream-level wait only
+            else:
+                torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
         if head.is_cuda and self._adam_fused:
             # mean + NaN guard on the device (gm_meta_finish), then the fused Adam with `found_inf`: the kernel skips the
             # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)

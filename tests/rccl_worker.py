@@ -19,8 +19,14 @@ from hip_util import fixture_batches, fixture_meta, make_store      # noqa: E402
 def main():
     rank, world, port, case, outdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = port
-    torch.cuda.set_device(rank)
-    dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    if os.environ.get('GMETA_TEST_ONE_GPU') == '1':
+        # every rank on cuda:0, collectives over gloo (RCCL refuses two ranks on one device): the sharded HIP path -- shard, [grad | stats]
+        # buffer, global-T mean, device-side NaN guard, sharded evaluation -- on real hardware where only one GPU is available
+        torch.cuda.set_device(0)
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    else:
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
     fx = Fixture(case)
     store = make_store(fx)
     S, Q = fixture_batches(fx, store, replay=True)

@@ -18,9 +18,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 needs2 = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason='needs two GPUs (RCCL refuses two ranks on one device)')
 
 
-def _run(case, world, tmp_path):
+def _run(case, world, tmp_path, one_gpu=False):
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = str(s.getsockname()[1]); s.close()
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    if one_gpu:
+        env['GMETA_TEST_ONE_GPU'] = '1'
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'rccl_worker.py'), str(r), str(world), port, case, str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
@@ -29,11 +31,8 @@ def _run(case, world, tmp_path):
     return [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(world)]
 
 
-@needs2
-@pytest.mark.parametrize('case', ['g2_shared', 'g0_disjoint_h1'])
-def test_two_rccl_ranks_equal_single_process_reference(case, tmp_path):
+def _check_two_ranks(case, res):
     fx = Fixture(case)
-    res = _run(case, 2, tmp_path)
     for r in res:
         assert float(r['task_num']) == fx.T
         np.testing.assert_allclose(r['accs'], fx.z['accs'], atol=1e-6)
@@ -47,14 +46,34 @@ def test_two_rccl_ranks_equal_single_process_reference(case, tmp_path):
     assert np.array_equal(res[0]['ft'], res[1]['ft'])
 
 
-@needs2
-def test_nan_guard_over_rccl(tmp_path):
+def _check_nan(res):
     fx = Fixture('g6_nan_skip')
-    res = _run('g6_nan_skip', 2, tmp_path)
     for r in res:
         assert np.isnan(float(r['loss_q']))
         for k, v0 in enumerate(fx.vars0):
             assert np.array_equal(r['v%d' % k], v0)                       # fused Adam skipped its step on found_inf (meta.py:163-164)
+
+
+@needs2
+@pytest.mark.parametrize('case', ['g2_shared', 'g0_disjoint_h1'])
+def test_two_rccl_ranks_equal_single_process_reference(case, tmp_path):
+    _check_two_ranks(case, _run(case, 2, tmp_path))
+
+
+@needs2
+def test_nan_guard_over_rccl(tmp_path):
+    _check_nan(_run('g6_nan_skip', 2, tmp_path))
+
+
+@pytest.mark.parametrize('case', ['g2_shared', 'g0_disjoint_h1'])
+def test_two_ranks_sharing_one_gpu_equal_single_process_reference(case, tmp_path):
+    """The same two-rank checks where only ONE GPU exists: both ranks run their task shard through the HIP path on cuda:0 and exchange
+    the [grad | losses_q | corrects | count] block over gloo (uneven shards for g2_shared: T = 3)."""
+    _check_two_ranks(case, _run(case, 2, tmp_path, one_gpu=True))
+
+
+def test_nan_guard_with_two_ranks_sharing_one_gpu(tmp_path):
+    _check_nan(_run('g6_nan_skip', 2, tmp_path, one_gpu=True))
 
 
 def test_single_rank_rccl_group_runs_the_allreduce_path(tmp_path):
