@@ -214,6 +214,7 @@ def main():
     ap.add_argument('--task_num', type=int, default=None)
     ap.add_argument('--hoist_z1', type=int, default=0)
     ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_eval', action='store_true', help='skip the evaluation (finetunning) leg of the configs that have one')
     ap.add_argument('--n_batches', type=int, default=2, help='distinct pre-extracted meta-batches cycled through')
     ap.add_argument('--sparse_bwd', type=int, default=0, help='1: time the flagged exact row-sparse backward schedule instead of the default dense one')
     ap.add_argument('--cone', type=int, default=0, help='1: time the flagged receptive-field schedule (layer l only on the rows that reach a centre)')
@@ -256,7 +257,7 @@ def main():
     config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], synth.n_out(cfg), link=link)
     maml = gmeta_amd.Meta(args, config).to('cuda')
     maml.force_allreduce = os.environ.get('GMETA_FORCE_DIST') == '1' and os.environ.get('GMETA_SKIP_ALLREDUCE') != '1'
-    n_eval = int(cfg.get('eval_tasks', 0)) if world == 1 else 0
+    n_eval = int(cfg.get('eval_tasks', 0)) if (world == 1 and not a.no_eval) else 0
     db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'],
                              batchsz=T * (a.n_batches + (a.e2e_steps + 2 if world == 1 else 0)) + n_eval, args=args, adjs=store, h=cfg['h'],
                              tables=data['tables'], verbose=False)

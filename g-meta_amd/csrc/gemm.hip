@@ -23,6 +23,7 @@ struct GemmK {
     const float* row_scale; const float* bias; int64_t bias_stride; const float* mask_h; int relu;
     const uint8_t* mask_b; uint8_t* relu_bits;
     const int32_t* tiles; int n_tiles; int n_col_tiles; int a_vec, b_vec, c_vec; int nt_store;
+    float* zero_out;            // DMA kernels only: the epilogue also zero-fills this [rows, ldc] buffer (dQ of the backward pass that follows)
 };
 
 // Block tile 128 x (64*WC); 2 x WC waves, each wave a 64 x 64 sub-tile = 2 x 2 MFMA 32x32 blocks.
@@ -349,6 +350,7 @@ __global__ __launch_bounds__(128 * WC) void k_gemm_glds(GemmK g) {
                 f4v vv = {v.x, v.y, v.z, v.w};
                 __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
             } else *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+            if (g.zero_out) *reinterpret_cast<float4*>(g.zero_out + row * g.ldc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 }
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(512) void k_gemm_glds_small(GemmK g) {
             f4v vv = {v.x, v.y, v.z, v.w};
             __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
         } else *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+        if (g.zero_out) *reinterpret_cast<float4*>(g.zero_out + row * g.ldc + col) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -551,7 +554,7 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         return GM_OK;
     }
     GemmK g{a.A, a.lda, a.B, a.b_stride, a.transB, a.C, a.ldc, a.K, a.N, a.row_scale, a.bias, a.bias_stride, a.mask_h, a.relu,
-            a.mask_b, a.relu_bits, a.tiles, a.n_tiles, 0, 0, 0, 0, 0};
+            a.mask_b, a.relu_bits, a.tiles, a.n_tiles, 0, 0, 0, 0, 0, nullptr};
     g.a_vec = (a.K % 4 == 0) && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0);
     g.b_vec = (((uintptr_t)a.B & 15) == 0) && (a.b_stride % 4 == 0) && ((a.transB ? a.K : a.N) % 4 == 0);
     g.c_vec = (a.N % 4 == 0) && (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.mask_h || (((uintptr_t)a.mask_h & 15) == 0));
@@ -577,7 +580,12 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     const int use_glds = gm_knob().gemm_glds;
     const bool bias_al = !a.bias || ((((uintptr_t)a.bias & 15) == 0) && (a.bias_stride % 4 == 0));
     g.nt_store = gm_knob().gemm_nt;
-    if (use_glds && vec && !a.transB && !a.mask_b && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0) {
+    const bool dma = use_glds && vec && !a.transB && !a.mask_b && g.c_vec && bias_al && a.K % BK == 0 && a.K >= 2 * BK && a.N % bn == 0;
+    if (a.zero_out) {               // honoured on every path: in the DMA kernels' epilogue (needs the whole row range of ldc covered), else a memset
+        if (dma && a.N == a.ldc) g.zero_out = a.zero_out;
+        else GM_HIP(hipMemsetAsync(a.zero_out, 0, sizeof(float) * (size_t)a.rows * a.ldc, s));
+    }
+    if (dma) {
         const dim3 grid(g.n_tiles * g.n_col_tiles);
         if (bn == 256) hipLaunchKernelGGL((k_gemm_glds<4>), grid, dim3(512), 0, s, g);
         else if (bn == 128) hipLaunchKernelGGL((k_gemm_glds<2>), grid, dim3(256), 0, s, g);

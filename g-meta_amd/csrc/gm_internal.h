@@ -258,7 +258,7 @@ struct gm_gemm_args {
     // with Bsplit: fused aggregate + GEMM.  fuse2 = gm_batch::d_fuse2 / d_fuse2_feat; A / lda then address the aggregate's INPUT rows
     // (previous layer's output or the feature table) and rows the table flags GM_FUSE_SELF read their finished aggregate from zside
     const void* fuse2; const float* zside; int64_t ldz;
-    float* zero_out;                    // with Bsplit: also zero-fill this [rows, ldc] buffer (saves the memset of the backward's dQ)
+    float* zero_out;                    // also zero-fill this [rows, ldc] buffer (dQ of the backward pass that follows): in the epilogue of the split / DMA kernels, a memset on the other paths
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
     int64_t rows;                       // total rows covered by the tiles (profiling: flops = 2*rows*K*N)

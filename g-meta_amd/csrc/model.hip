@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
 template <int NT>
 __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
-                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr, int dbase = 0) {     // dlogits holds subgraphs [dbase, ..)
+                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr, int dbase = 0,
+                                             const int* crow_s = nullptr) {     // dlogits holds subgraphs [dbase, ..); crow_s: LDS table of the set's centre rows
     const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
     const float* P = k.params + (int64_t)set * k.pstride;
     const float* WL = wl_s ? wl_s : P + k.wl_off;                     // [C, hc]
@@ -83,12 +84,23 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
     // one thread per (subgraph, column); both centres of a pair stay in one thread (they may share a row)
     for (int id = tid; id < (s1 - s0) * k.Hd; id += NT) {
         const int s = s0 + id / k.Hd, col = id % k.Hd;
+        float vv[2] = {0.f, 0.f};
         for (int which = 0; which < k.nc; ++which) {
             float v = 0.f;
             for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)(s - dbase) * k.C + c] * WL[(int64_t)c * k.hc + which * k.Hd + col];
             const float hval = centre_feat(k, s, which, hs, s0)[col];
             if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
-            else if (hval > 0.f) dQ[centre_row(k, s, which) * k.ldh + col] += v;
+            else vv[which] = hval > 0.f ? v : 0.f;
+        }
+        if (!Gc) {
+            // dQ is all zeros when this runs and a row is the centre of ONE subgraph, so the "+=" of learner.py's index_select backward is a
+            // plain store (no dependent read of dQ); the two centres of a pair may be the same row: (0 + v0) + v1
+            const int64_t r0 = crow_s ? crow_s[(s - s0) * k.nc] : centre_row(k, s, 0);
+            if (k.nc == 2) {
+                const int64_t r1 = crow_s ? crow_s[(s - s0) * k.nc + 1] : centre_row(k, s, 1);
+                if (r1 == r0) vv[0] = vv[0] + vv[1]; else dQ[r1 * k.ldh + col] = vv[1];
+            }
+            dQ[r0 * k.ldh + col] = vv[0];
         }
     }
 }
@@ -114,13 +126,13 @@ __device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
 }
 
 template <int NT>
-__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, float* sm) {
+__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, float* sm, const int32_t* rows_l = nullptr) {
     const int Ct = k.tab[set * 3 + 1], n = k.tab[set * 3 + 2];
     const int Q = Ct * n, D = k.D;
     float* protos = sm;                 // [Ct*D]   (LDS sized for the largest set)
     float* lse = sm + k.Ct * D;         // [Q]
     float* red = lse + k.Ct * k.n;      // [2 * NT]
-    const int32_t* rows = k.rows + k.tab[set * 3];
+    const int32_t* rows = rows_l ? rows_l : k.rows + k.tab[set * 3];      // rows_l: the set's class rows already in LDS (k_head_loss)
     for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float p;
@@ -152,12 +164,17 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
         lpart += -(at - l);                                                          // -log_p[q, class(q)]
         apart += (best == tgt) ? 1.f : 0.f;
     }
-    red[tid] = lpart; red[NT + tid] = apart;
+    // block sum of (loss, correct): wave shuffles, then the first wave adds the NT / 64 wave partials (two barriers instead of log2 NT)
+    lpart = wave_sumf(lpart); apart = wave_sumf(apart);
+    if ((tid & 63) == 0) { red[tid >> 6] = lpart; red[NT + (tid >> 6)] = apart; }
     __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) { if (tid < o) { red[tid] += red[tid + o]; red[NT + tid] += red[NT + tid + o]; } __syncthreads(); }
-    if (tid == 0) {
-        k.loss[(int64_t)set * k.ld_out + k.col_out] = red[0] / (float)Q;
-        k.acc[(int64_t)set * k.ld_out + k.col_out] = red[NT] / (float)Q;
+    if (tid < 64) {
+        float l2 = tid < NT / 64 ? red[tid] : 0.f, a2 = tid < NT / 64 ? red[NT + tid] : 0.f;
+        l2 = wave_sumf(l2); a2 = wave_sumf(a2);
+        if (tid == 0) {
+            k.loss[(int64_t)set * k.ld_out + k.col_out] = l2 / (float)Q;
+            k.acc[(int64_t)set * k.ld_out + k.col_out] = a2 / (float)Q;
+        }
     }
     if (!k.dlogits) return;
     // G[q,c] = (softmax(-d)[q,c] - [c == tgt(q)]) / Q ;  d(-d_qc)/dx_q = -2 (x_q - p_c) ; d(-d_qc)/dp_c = +2 (x_q - p_c)
@@ -206,6 +223,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
     // stage != 0: everything the three phases share stays in LDS -- the set's centre rows of H_L, its head weights, its
     // logits and dlogits -- so that a phase costs LDS latency instead of an L2 round trip (the kernel is pure latency)
     float *hs = nullptr, *wl_s = nullptr;
+    int* crow = nullptr; int* rows_l = nullptr;
     float* lg = logits; float* dl = pk.dlogits;
     if (stage) {
         hs = sm + proto_floats;
@@ -216,23 +234,44 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
         // centre rows of H_L -> LDS.  The row ids (two dependent loads each) are resolved first, then the row reads are
         // issued eight deep: the kernel is one workgroup per task and pure latency, so a serial chain of 18 dependent
         // global loads per thread (the first version) was most of its time.
-        int* crow = reinterpret_cast<int*>(dl_s + S * D);               // [S * nc] row of every centre (scratch past the dlogits copy)
+        crow = reinterpret_cast<int*>(dl_s + S * D);                    // [S * nc] row of every centre (scratch past the dlogits copy)
+        rows_l = crow + S * hk.nc;                                      // [Ct * n] the set's class rows (subgraph ids)
         const int nq = S * hk.nc;
+        // first round trip, everything that needs no other load: centre rows (two loads each), class rows, head weights
         for (int q = tid; q < nq; q += HL_THREADS) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
-        __syncthreads();
-        const int total = nq * hk.Hd;
-        for (int id0 = tid; id0 < total; id0 += 8 * HL_THREADS) {
-            float v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int id = min(id0 + u * HL_THREADS, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
-                v[u] = hk.H[(int64_t)crow[q] * hk.ldh + col];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total) hs[id] = v[u]; }
+        {
+            const int off = pk.tab[set * 3], Qs = pk.tab[set * 3 + 1] * pk.tab[set * 3 + 2];
+            for (int q = tid; q < Qs; q += HL_THREADS) rows_l[q] = pk.rows[off + q];
         }
         for (int id = tid; id < hk.C * hk.hc; id += HL_THREADS) wl_s[id] = P[hk.wl_off + id];
         for (int id = tid; id < hk.C; id += HL_THREADS) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
+        __syncthreads();
+        // second round trip: the centre rows of H_L, all loads of a thread in flight together (16-byte loads when the rows allow it)
+        if ((hk.Hd & 3) == 0 && (hk.ldh & 3) == 0 && ((uintptr_t)hk.H & 15) == 0) {
+            const int hd4 = hk.Hd >> 2, total4 = nq * hd4;
+            for (int id0 = tid; id0 < total4; id0 += 8 * HL_THREADS) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = min(id0 + u * HL_THREADS, total4 - 1), q = id / hd4, c4 = id - q * hd4;
+                    v[u] = *reinterpret_cast<const float4*>(hk.H + (int64_t)crow[q] * hk.ldh + c4 * 4);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total4) *reinterpret_cast<float4*>(hs + (int64_t)id * 4) = v[u]; }
+            }
+        } else {
+            const int total = nq * hk.Hd;
+            for (int id0 = tid; id0 < total; id0 += 8 * HL_THREADS) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int id = min(id0 + u * HL_THREADS, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
+                    v[u] = hk.H[(int64_t)crow[q] * hk.ldh + col];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total) hs[id] = v[u]; }
+            }
+        }
         lg = lg_s;                              // LDS copies hold the set's subgraphs only: indexed relative to s0 (base below)
         if (pk.dlogits) { dl = dl_s; for (int id = tid; id < S * D; id += HL_THREADS) dl_s[id] = 0.f; }
         __syncthreads();
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
     __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
     ProtoK pl = pk;
     pl.logits = lg; pl.dlogits = dl; pl.row_base = base;
-    proto_set<HL_THREADS>(pl, set, tid, sm);
+    proto_set<HL_THREADS>(pl, set, tid, sm, rows_l);
     if (stage) {              // the global copies (API / debugging): logits always, dlogits when requested
         __syncthreads();
         for (int id = tid; id < S * D; id += HL_THREADS) {
@@ -254,7 +293,7 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
     }
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base);
+    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base, crow);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -509,7 +548,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
             }
             // fwd_only == 2: the head + loss + backward follow (gm_meta_step): the last layer's GEMM zero-fills dQ on its way out instead of a memset launch
-            if (fwd_only == 2 && l == L.n_gcn - 1 && g.Bsplit && fo == L.dims[L.n_gcn]) { g.zero_out = c.bufA; c.dq_zeroed = 1; }
+            if (fwd_only == 2 && l == L.n_gcn - 1 && fo == L.dims[L.n_gcn]) { g.zero_out = c.bufA; c.dq_zeroed = 1; }
             if (fuse) {
                 g.zside = c.Z[l]; g.ldz = fi;
                 if (gather) { g.A = b->store->d_feat; g.lda = b->store->feat_ld; g.fuse2 = b->d_fuse2_feat; }
@@ -908,7 +947,7 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     int max_subs = 0;
     for (int t = 0; t < b->sets; ++t) max_subs = std::max(max_subs, b->h_set_sub_off[t + 1] - b->h_set_sub_off[t]);
     const size_t hs_bytes = sizeof(float) * ((size_t)max_subs * b->centres * L.dims[L.n_gcn] + (size_t)L.n_out * (L.hc + 1) + 2 * (size_t)max_subs * L.n_out +
-                                             (size_t)max_subs * b->centres);      // + the centre-row scratch
+                                             (size_t)max_subs * b->centres + (size_t)pk.Ct * pk.n) + 16;      // + the centre-row scratch + the class rows
     const int stage_on = gm_knob().head_stage;
     const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
     const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
