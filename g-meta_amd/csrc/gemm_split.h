@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
 //                 global LOAD, so they never wait on vmcnt: the stores of tile i drain while tile i+1 is being computed.
 //   waves 8,9     A FEEDERS  HBM -> registers PF_DA chunks ahead (inline-asm loads, hand-counted vmcnt) -> exact split -> LDS;
 //                 they also stage the tile's row scales and bias (so that the compute waves need no global load).
-//   waves 10..13  B FEEDERS  LDS-DMA of the three bf16 weight planes, one chunk ahead (6 one-KiB pieces per wave and chunk).
+//   waves 12..15  B FEEDERS  LDS-DMA of the three bf16 weight planes, TWO chunks ahead (6 one-KiB pieces per wave and chunk, three stages).
 // Every wave runs the same flattened (tile, chunk) sequence with ONE raw barrier per chunk; feeders run one chunk ahead across
 // tile boundaries.  One workgroup per CU, grid = min(tiles, CUs); workgroup b walks tiles b, b + G, ... of the XCD-contiguous
 // order.  LDS: 2 stages x 36 KiB + 8 x 8.5 KiB staging + scales/bias = 143 KiB.
@@ -127,9 +127,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     // leave more than half of the CUs without a tile -- a small batch is bound by one tile's MFMA chain, not by throughput
     constexpr int BK = 16, BN = 256, WC = 4, BM = 64 * MI;
     constexpr int A_OCT = BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
-    constexpr int STAGE = 3 * A_PLANE + 3 * B_PLANE;                                  // 12 + 24 KiB
-    constexpr int EP_LD = 68, E_WAVE = 32 * EP_LD * 4;                                // 8704 B per compute wave
-    constexpr int OFF_E = 2 * STAGE, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
+    // LDS: two A stages (12 KiB each), NB = 3 B stages (24 KiB each: the weight planes are DMA-ed TWO chunks ahead -- in the meta-step the
+    // part runs this kernel at ~2 GHz, where one chunk of MFMAs (1536 cycles) no longer covers the issue cost of six DMA pieces plus an L2
+    // round trip, and every chunk's barrier waited for the B feeders), epilogue staging of 16 rows x 64 columns per compute wave
+    constexpr int A_ST = 3 * A_PLANE, B_ST = 3 * B_PLANE, NB = 3;
+    constexpr int OFF_B = 2 * A_ST;
+    constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
+    constexpr int OFF_E = OFF_B + NB * B_ST, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
     constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
     constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6
     __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
@@ -159,13 +163,14 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         for (int p = 0; p < B_PPW; ++p) {
             const int piece = fw * B_PPW + p, cb = piece % (BN / 64), po = piece / (BN / 64), oct = po % 2, plane = po / 2;
             boff[p] = (unsigned)(((int64_t)plane * g.N * g.K + ((int64_t)oct * g.N + cb * 64 + lane) * 8) * 2);
-            bdst[p] = 3 * A_PLANE + plane * B_PLANE + oct * B_OCT + cb * 1024;
+            bdst[p] = OFF_B + plane * B_PLANE + oct * B_OCT + cb * 1024;
         }
         const int64_t b_chunk_bytes = (int64_t)BK * g.N * 2;
         // chunks are issued in order: (tile, chunk) counters instead of a division per chunk, the tile's set looked up once per tile
         int ib_c = 0, ib_ti = 0;
         uint64_t ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)tile_of(b).set * g.bt_stride);
-        auto issue_b = [&](int gc) {                                                  // global chunk gc (= the next in order) -> stage gc & 1
+        int ib_st = 0;                                                                // B stage of the next chunk to issue (gc % NB)
+        auto issue_b = [&](int gc) {                                                  // global chunk gc (= the next in order) -> B stage gc % NB
             if (ib_c == nchunks) { ib_c = 0; ++ib_ti; ib_base = (uint64_t)(uintptr_t)(g.Bt + (int64_t)tile_of(b + ib_ti * G).set * g.bt_stride); }
             const uint64_t base = ib_base + (uint64_t)(ib_c * b_chunk_bytes);
             ++ib_c;
@@ -173,18 +178,24 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             const uint64_t sbase = ((uint64_t)bhi << 32) | blo;
 #pragma unroll
             for (int p = 0; p < B_PPW; ++p) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((gc & 1) * STAGE + bdst[p]));
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(ib_st * B_ST + bdst[p]));
                 unsigned keep;
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                              : "=&s"(keep) : "v"(boff[p]), "s"(sbase), "s"(dst) : "memory");
             }
+            ib_st = ib_st + 1 == NB ? 0 : ib_st + 1;
+            (void)gc;
         };
+        static_assert(B_PPW == 6, "the counted wait below is written for six pieces per wave and chunk");
         issue_b(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (total > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      // chunk 0 has landed, chunk 1 may still fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GS_BARRIER();
         for (int gc = 0; gc < total; ++gc) {
-            if (gc + 1 < total) issue_b(gc + 1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // chunk gc + 2 -> the stage chunk gc - 1 was read from (all waves are past that chunk's barrier); chunk gc + 1 must have landed
+            // before the barrier that ends chunk gc
+            if (gc + 2 < total) { issue_b(gc + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GS_BARRIER();
         }
     } else if (wave >= 8) {
@@ -287,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 biasl[(sa_ti & 1) * BN + ft] = rc_b;
             }
             ++sa_c;
-            char* As = smem + (gc & 1) * STAGE;
+            char* As = smem + (gc & 1) * A_ST;
 #pragma unroll
             for (int p = 0; p < A_PER; ++p) {
                 uint2 h, m, l;
@@ -357,7 +368,8 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     } else {
         // ================= compute
         const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
-        const int a_lane = kh * A_OCT + (wr * 32 * MI + li) * 16, b_lane = 3 * A_PLANE + kh * B_OCT + (wc * 64 + li) * 16;
+        const int a_lane = kh * A_OCT + (wr * 32 * MI + li) * 16, b_lane = OFF_B + kh * B_OCT + (wc * 64 + li) * 16;
+        int b_st = 0;                                                                 // B stage of the current chunk (gc % NB)
         float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
         const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
@@ -371,7 +383,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
             for (int c = 0; c < nchunks; ++c, ++gc) {
-                const char* S = smem + (gc & 1) * STAGE;
+                const char* S = smem + (gc & 1) * A_ST;
+                const char* SB = smem + b_st * B_ST;
+                b_st = b_st + 1 == NB ? 0 : b_st + 1;
                 gm_bf16x8 af[MI][3], bf[2][3];
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -380,7 +394,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(S + b_lane + p * B_PLANE + j * 512);
+                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(SB + b_lane + p * B_PLANE + j * 512);
 #define PF_PROD(PA, PB)                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
@@ -395,15 +409,16 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             const int col = wc * 64 + ec;
             const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
+            for (int ih = 0; ih < 2 * MI; ++ih) {                  // 16 rows of the wave's block at a time: accumulator registers e with (e >> 3) == ih & 1
+                const int i = ih >> 1, h = ih & 1;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) E[((e & 3) + 8 * (e >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][e];
+                    for (int e8 = 0; e8 < 8; ++e8) E[((e8 & 3) + 8 * (e8 >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][h * 8 + e8];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int rl = wr * 32 * MI + i * 32 + it * 4 + er;
+                for (int it = 0; it < 4; ++it) {
+                    const int rl = wr * 32 * MI + i * 32 + h * 16 + it * 4 + er;
                     if (rl >= nrows) continue;
                     const int64_t row = row0 + rl;
                     const float sc = sc_t[rl];
