@@ -41,6 +41,18 @@ def cpu_model():
     return 'unknown'
 
 
+def cpu_quota():
+    """CPUs this process may actually use: the cgroup quota when there is one (a container can see 256 CPUs and own 16), else the affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            return min(float(n), float(q) / float(per)), True
+    except (OSError, ValueError):
+        pass
+    return float(n), False
+
+
 def shard_bounds(T, world):
     """Contiguous task ranges of a meta-batch per rank (sizes differ by at most one)."""
     return np.linspace(0, T, world + 1).round().astype(int)
@@ -131,11 +143,19 @@ def cpu_baseline(db, data, cfg, config, batch, budget_s=45.0):
     # ---- the same restatement with the tasks of the meta-batch run SIDE BY SIDE (they are independent, meta.py:118-161): W worker
     # processes x the tuned thread count, all T tasks of the meta-batch, wall time from a common start to the last worker's end
     par = None
+    quota, has_quota = cpu_quota()
     try:
-        par = cpu_baseline_task_parallel(db, data, cfg, config, batch, theta, variants['numpy-omp']['threads'], host_cores)
+        # task-level parallelism beats thread-level parallelism on these op sizes: one worker per task, 1 or 2 threads each (both timed on the
+        # whole meta-batch, the better one reported); with a cgroup CPU quota the workers share `quota` cores
+        runs = [cpu_baseline_task_parallel(db, data, cfg, config, batch, theta, nt, max(host_cores, len(batch[0]) * nt)) for nt in (1, 2)]
+        par = max(runs, key=lambda r: r['value'])
+        par['tried'] = [{'workers': r['workers'], 'threads_per_worker': r['threads_per_worker'], 'value': r['value']} for r in runs]
+        par['cpus_available'] = quota
+        par['cpus_available_source'] = 'cgroup cpu.max quota' if has_quota else 'sched_getaffinity'
     except Exception as e:       # a reported extra, never the product path
         par = {'value': None, 'error': repr(e)}
-    return {'value': variants[best]['value'], 'unit': 'meta-tasks/s', 'cores': variants[best]['threads'], 'host_cores': host_cores, 'kind': 'port',
+    return {'value': variants[best]['value'], 'unit': 'meta-tasks/s', 'cores': variants[best]['threads'], 'host_cores': host_cores,
+            'cpus_available': quota, 'kind': 'port',
             'variant': best, 'cpu_model': cpu_model(), 'variants': variants, 'task_parallel': par,
             'sample': 'whole tasks of the first meta-batch of the same config (K=%d inner steps incl. the meta-gradient), one task at a '
                       'time like the reference loop (meta.py:118), subgraphs pre-extracted on both sides; per variant: thread count tuned on '
