@@ -151,7 +151,7 @@ const gm_knobs& gm_knob() {
         k.agg_nt = env("GM_AGG_NT", 1);
         k.agg_variant = env("GM_AGG_VARIANT", 0);                      // 1 = force the generic row-per-group kernel (debug)
         k.agg_edge_tables = env("GM_AGG_EDGE_TABLES", 1);
-        k.heavy_deg = std::max(2, env("GM_HEAVY_DEG", 64));
+        k.heavy_deg = env("GM_HEAVY_DEG", 0);                          // 0 = by batch density (gm_heavy_deg_for)
         k.extract_global_bitmap = env("GM_EXTRACT_GLOBAL_BITMAP", 0);
         k.feat_pad = env("GM_FEAT_PAD", 1);
         k.timing = env("GM_TIMING", 0);
@@ -177,7 +177,15 @@ const gm_knobs& gm_knob() {
     return k;
 }
 
-int gm_heavy_deg() { return gm_knob().heavy_deg; }
+int gm_heavy_deg() { return gm_knob().heavy_deg > 0 ? std::max(2, gm_knob().heavy_deg) : 64; }
+// Rows with more in-edges than this leave the wave windows for whole workgroups (hub parts).  A window row walks its edges four loads at a
+// time, so a 60-edge row is a ~30-us serial chain -- the fixed cost of every launch over SPARSE induced subgraphs (arxiv shape: mean
+// in-degree 2, a few hundred rows above 32), where 32 is better (4-task shard 4.73 -> 4.64 ms, roofline 0.50 -> 0.515 at task_num 32).
+// Dense subgraphs (Tissue shape: mean in-degree 24) would turn a quarter of their rows into workgroups: they keep 64 (32 costs +8 %).
+int gm_heavy_deg_for(int64_t rows, int64_t edges) {
+    if (gm_knob().heavy_deg > 0) return std::max(2, gm_knob().heavy_deg);
+    return edges <= 8 * rows ? 32 : 64;
+}
 
 // ---------------------------------------------------------------- per-device facts (one process may drive several GPUs)
 static std::mutex g_dev_mu;

@@ -444,7 +444,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     GM_HIP(hipStreamSynchronize(s));     // host vectors go out of scope
     tm.lap("tables");
     // heavy-row lists for both CSR orientations (a row can have at most rows-1... edges: cap = edges / heavy_deg + 1)
-    b->heavy_deg = gm_heavy_deg();
+    b->heavy_deg = gm_heavy_deg_for(b->rows, b->edges);
     const int cap = (int)(b->edges / b->heavy_deg + 1);
     int32_t* d_cnt = nullptr;
     GM_TRY(gm_alloc(&d_cnt, 2, s));

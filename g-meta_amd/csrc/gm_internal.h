@@ -238,7 +238,8 @@ int gm_agg_window(int64_t rows);
 // split: out->d_hub == NULL), -1: nothing.  A hub row's blocks follow the window block that contains the row, on the XCD whose L2 is
 // streaming that subgraph.  heavy_deg_host: the rows' edge counts (NULL: never split).
 int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s);
-int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG, default 64)
+int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG; default by density, see gm_heavy_deg_for)
+int gm_heavy_deg_for(int64_t rows, int64_t edges);
 int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);
 
 // Grouped GEMM  C[rows of set t] = epi( A[rows] @ op(B_t) ),  A [rows,K] (lda), C [rows,N] (ldc).
