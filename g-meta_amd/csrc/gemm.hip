@@ -496,7 +496,7 @@ const float* gm_zero_row(hipStream_t s) {
 bool gm_gemm_split_ok(int n_tiles, int K, int N) {
     // default: from a quarter of the (current device's) CUs busy upwards (measured on the 141-tile support batch of a 4-task shard: still ahead of the fp32 small-tile kernel)
     const int min_tiles = gm_knob().gemm_split_min_tiles >= 0 ? gm_knob().gemm_split_min_tiles : gm_num_cus() / 4;
-    return gm_gemm_mode() == 1 && N == 256 && K % 16 == 0 && K >= 32 && n_tiles >= min_tiles;
+    return gm_gemm_mode() == 1 && (N == 256 || N == 128) && K % 16 == 0 && K >= 32 && n_tiles >= min_tiles;
 }
 int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s) {
     hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, sets), dim3(256), 0, s, params, pstride, w_off, K, N, trans, out);
@@ -516,7 +516,7 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.Bsplit) {
         // fp32-accurate product on the bf16 matrix cores (exact 3-way operand split, 6 MFMA products, fp32 accumulation)
-        const bool ok = a.N == 256 && a.K % 16 == 0 && a.K >= 32 && !a.mask_h && !a.mask_b && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
+        const bool ok = (a.N == 256 || a.N == 128) && a.K % 16 == 0 && a.K >= 32 && !a.mask_h && !a.mask_b && (a.lda % 4 == 0) && (((uintptr_t)a.A & 15) == 0) &&
                         (a.ldc % 4 == 0) && (((uintptr_t)a.C & 15) == 0) && (!a.bias || a.bias_stride % 4 == 0);
         GM_REQUIRE(ok, GM_EINVAL, "gemm: launch not eligible for the split-bf16 kernel (N=%d K=%d)", a.N, a.K);
         SplitGemmK k{};
@@ -540,11 +540,13 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             // 1/mult of the tiles, give the dispatcher a yield point every ~0.65/mult ms (default 4: 27.7 -> 27.4 ms at task_num 32, 5.12 -> 4.86 ms
             // for the 4-task shard, where the support chain is the critical path; 8 and more lose to the per-workgroup prologue).
             const int mult_f = gm_knob().gemm_fused_rounds;
-            hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
+            if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
+            else hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
         } else {
             // a launch that would leave more than half of the CUs without a tile walks 64-row half tiles: half the MFMA chain per workgroup
             const int half_on = gm_knob().gemm_half_tiles;
-            if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
+            if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<false, 1, 2>), dim3(std::min(a.n_tiles, gm_knob().gemm_plain_rounds * grid_cap)), dim3(1024), 0, s, k);
+            else if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
             else {
                 const int mult_p = gm_knob().gemm_plain_rounds;
                 hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, mult_p * grid_cap)), dim3(1024), 0, s, k);

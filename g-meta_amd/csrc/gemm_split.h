@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 (one 128 x 256 tile per step, 16-k chunks):
+// PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 or 128 (one 128 x N tile per step, 16-k chunks):
 //   waves 0..7    COMPUTE  64x64 sub-tiles: LDS fragments -> 24 bf16 MFMAs per chunk; at the end of a tile the accumulators go
 //                 through a wave-PRIVATE LDS staging area to row-contiguous 16-B global stores.  These waves never issue a
 //                 global LOAD, so they never wait on vmcnt: the stores of tile i drain while tile i+1 is being computed.
@@ -121,11 +121,15 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
 #ifndef PF_DA
 #define PF_DA 4
 #endif
-template <bool GATHER, int MI>
+template <bool GATHER, int MI, int WC = 4>
 __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
-    // MI = 2: 128-row tiles (each compute wave a 64 x 64 block); MI = 1: 64-row HALF tiles (32 x 64 per wave) for launches that would
-    // leave more than half of the CUs without a tile -- a small batch is bound by one tile's MFMA chain, not by throughput
-    constexpr int BK = 16, BN = 256, WC = 4, BM = 64 * MI;
+    // The eight compute waves form a (8 / WC) x WC grid of (32 MI) x 64 blocks: N = 64 WC columns, tile height BM = 32 MI (8 / WC).
+    //   <., 2, 4>  N = 256, 128-row tiles (each compute wave a 64 x 64 block)
+    //   <., 1, 4>  N = 256, 64-row HALF tiles (32 x 64 per wave) for launches that would leave more than half of the CUs without a tile --
+    //              a small batch is bound by one tile's MFMA chain, not by throughput
+    //   <., 1, 2>  N = 128 (hidden_dim 128: the Tissue-PPI / FirstMM-DB configurations), 128-row tiles, 32 x 64 per wave
+    constexpr int BK = 16, BN = 64 * WC, BM = 32 * MI * (8 / WC), SPLIT = GS_BM / BM;
+    static_assert((WC == 4 || WC == 2) && (BM == 128 || BM == 64), "wave grid");
     constexpr int A_OCT = BM * 16, B_OCT = BN * 16, A_PLANE = 2 * A_OCT, B_PLANE = 2 * B_OCT;
     // LDS: two A stages (12 KiB each), NB = 3 B stages (24 KiB each: the weight planes are DMA-ed TWO chunks ahead -- in the meta-step the
     // part runs this kernel at ~2 GHz, where one chunk of MFMAs (1536 cycles) no longer covers the issue cost of six DMA pieces plus an L2
@@ -135,18 +139,18 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
     constexpr int OFF_E = OFF_B + NB * B_ST, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
     constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
-    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6
+    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6 (N = 256) / 3
     __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = g.K / BK;
     const int G = gridDim.x, b = blockIdx.x;
     // XCD-contiguous tile order over this launch: hardware id t -> logical tile
-    const int nb = g.n_tiles * (2 / MI), q8 = nb / 8, r8 = nb % 8;
+    const int nb = g.n_tiles * SPLIT, q8 = nb / 8, r8 = nb % 8;
     auto logical = [&](int t) -> int { const int x = t % 8, i = t / 8; return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + i; };
     const int ntb = b < nb ? (nb - b + G - 1) / G : 0;                                // tiles of this workgroup
     auto tile_of = [&](int w) -> GsTile {                                             // hardware work id -> {set, row0, nrows} of its (half) tile
         const int lt = logical(w);
-        if constexpr (MI == 2) return gs_tile(g.tiles, lt);
+        if constexpr (SPLIT == 1) return gs_tile(g.tiles, lt);
         else { GsTile t = gs_tile(g.tiles, lt >> 1); const int h = (lt & 1) * 64; t.row0 += h; t.nrows = max(0, min(64, t.nrows - h)); return t; }
     };
     const int total = ntb * nchunks;                                                  // flattened chunk count
@@ -186,15 +190,14 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             ib_st = ib_st + 1 == NB ? 0 : ib_st + 1;
             (void)gc;
         };
-        static_assert(B_PPW == 6, "the counted wait below is written for six pieces per wave and chunk");
         issue_b(0);
-        if (total > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }      // chunk 0 has landed, chunk 1 may still fly
+        if (total > 1) { issue_b(1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(B_PPW) : "memory"); }      // chunk 0 has landed, chunk 1 may still fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GS_BARRIER();
         for (int gc = 0; gc < total; ++gc) {
             // chunk gc + 2 -> the stage chunk gc - 1 was read from (all waves are past that chunk's barrier); chunk gc + 1 must have landed
             // before the barrier that ends chunk gc
-            if (gc + 2 < total) { issue_b(gc + 2); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+            if (gc + 2 < total) { issue_b(gc + 2); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(B_PPW) : "memory"); }
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             GS_BARRIER();
         }
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             }
             if (consts) {
                 if (g.row_scale) { const float* q = g.row_scale + t.row0 + min(ft & (BM - 1), t.nrows - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_sc) : "v"(q) : "memory"); }
-                if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + ft; asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
+                if (g.bias) { const float* q = g.bias + (int64_t)t.set * g.bias_stride + min(ft, BN - 1); asm volatile("global_load_dword %0, %1, off" : "=v"(rc_b) : "v"(q) : "memory"); }
             }
         };
         if constexpr (GATHER) {
@@ -295,7 +298,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             if (sa_c == 0 && sa_ti > 0 && fast_consts) {                               // first chunk of a later tile: its consts arrived with (before) this chunk's loads
                 asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
                 if (ft < BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
-                biasl[(sa_ti & 1) * BN + ft] = rc_b;
+                if (ft < BN) biasl[(sa_ti & 1) * BN + ft] = rc_b;
             }
             ++sa_c;
             char* As = smem + (gc & 1) * A_ST;
@@ -322,9 +325,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             float sc = 1.f;
             if (g.row_scale) sc = g.row_scale[row0 + min(ft & (BM - 1), nrows - 1)];
             float b0 = 0.f;
-            if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[ft];
+            if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[min(ft, BN - 1)];
             if (ft < BM) scales[(ti & 1) * GS_BM + ft] = sc;
-            biasl[(ti & 1) * BN + ft] = b0;
+            if (ft < BN) biasl[(ti & 1) * BN + ft] = b0;
         };
         static_assert((A_PER == 1 || A_PER == 2) && PF_DA >= 2 && PF_DA <= 8, "wait macro is written for 1 or 2 rows per lane and chunk");
 #define PF_WAIT_SLOT(NEWER, SLOT)                                                                                                              \

@@ -1097,8 +1097,8 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
             p.pd.off[l][0] = p.pd.off[l][1] = -1;
             if (fi > fo) continue;                                           // multiply-first layers keep the on-the-fly path
             const int64_t sz = (int64_t)p.T * 3 * fi * fo;
-            if (fo == 256 && fi % 16 == 0 && fi >= 32) { p.pd.off[l][0] = per_k; per_k += sz; }                 // X @ W: K = fi, N = fo
-            if (l > 0 && fi == 256 && fo % 16 == 0 && fo >= 32) { p.pd.off[l][1] = per_k; per_k += sz; }        // dQ @ W^T: K = fo, N = fi
+            if ((fo == 256 || fo == 128) && fi % 16 == 0 && fi >= 32) { p.pd.off[l][0] = per_k; per_k += sz; }                 // X @ W: K = fi, N = fo
+            if (l > 0 && (fi == 256 || fi == 128) && fo % 16 == 0 && fo >= 32) { p.pd.off[l][1] = per_k; per_k += sz; }        // dQ @ W^T: K = fo, N = fi
         }
         if (per_k > 0) {
             p.pd.base = cv.take<uint16_t>(per_k * p.K); p.pd.per_k = per_k; p.pd.fw0 = p.fw; p.pd.TP = TP; p.pd.K = p.K;
@@ -1284,7 +1284,7 @@ extern "C" int gm_dense_update(const gm_batch_t* b, const float* x, int32_t K, c
     uint16_t* planes = nullptr;
     const bool split = mode == 1 || (mode < 0 && gm_gemm_split_ok(b->n_tiles, K, N));
     if (split) {
-        GM_REQUIRE(N == 256 && K % 16 == 0 && K >= 32, GM_EINVAL, "dense_update: the split-bf16 kernel needs N = 256 and K a multiple of 16 (>= 32)");
+        GM_REQUIRE((N == 256 || N == 128) && K % 16 == 0 && K >= 32, GM_EINVAL, "dense_update: the split-bf16 kernel needs N = 128 or 256 and K a multiple of 16 (>= 32)");
         const int sets = w_stride ? b->sets : 1;
         GM_TRY(gm_alloc(&planes, (size_t)sets * 3 * K * N, st));
         int rc = gm_split_weights(W, w_stride, 0, K, N, 0, sets, planes, st);

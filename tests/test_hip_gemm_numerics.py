@@ -1,6 +1,6 @@
 """GPU (-m gpu): numerics of the two update-GEMM kernels (learner.py:36,47 `torch.matmul(feat, weight)`) at the arxiv query-batch
 shape (286k rows, per-task weights) against an fp64 product: the split-bf16 kernel (every fp32 operand split exactly into three
-bf16 pieces, six MFMA products, fp32 accumulation -- the default for large N = 256 launches) must be as accurate as the exact-fp32
+bf16 pieces, six MFMA products, fp32 accumulation -- the default for large N = 256 / N = 128 launches) must be as accurate as the exact-fp32
 MFMA kernel and as a plain PyTorch fp32 matmul."""
 import random
 
@@ -26,12 +26,12 @@ def qbatch():
     return batch[2][0].view_of, store
 
 
-@pytest.mark.parametrize('K', [256, 128])
-def test_split_bf16_gemm_is_as_accurate_as_fp32(qbatch, K):
+@pytest.mark.parametrize('K,N', [(256, 256), (128, 256), (128, 128), (64, 128)])
+def test_split_bf16_gemm_is_as_accurate_as_fp32(qbatch, K, N):
     from gmeta_amd import _lib
     lib = _lib.lib()
     Q, _ = qbatch
-    N, T = 256, Q.sets
+    T = Q.sets
     g = torch.Generator(device='cuda').manual_seed(K)
     # wide dynamic range: rows scaled over three decades, a few exact zeros and denormal-ish values
     x = torch.randn(Q.rows, K, device='cuda', generator=g) * torch.logspace(-2, 1, Q.rows, device='cuda')[torch.randperm(Q.rows, device='cuda', generator=g)][:, None]
