@@ -151,6 +151,7 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
 };
 const gm_knobs& gm_knob();
@@ -326,7 +327,7 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
         const int cr = std::max(128, 32 * lo);
         const int64_t c = chunks_at(cr);
         const double eff = (double)total / ((double)((c + n_cu - 1) / n_cu) * n_cu * cr);   // useful rows / rows the rounds have room for
-        if (eff > best_eff + 0.03) { best_eff = eff; best = cr; }
+        if (eff > best_eff + 0.01 * gm_knob().wgrad_round_bias) { best_eff = eff; best = cr; }
     }
     return best;
 }
