@@ -65,10 +65,11 @@ def test_nan_guard_over_rccl(tmp_path):
     _check_nan(_run('g6_nan_skip', 2, tmp_path))
 
 
-@pytest.mark.parametrize('case', ['g2_shared', 'g0_disjoint_h1'])
+@pytest.mark.parametrize('case', ['g2_shared', 'g0_disjoint_h1', 'g3_linkpred', 'g5_in_gt_out'])
 def test_two_ranks_sharing_one_gpu_equal_single_process_reference(case, tmp_path):
     """The same two-rank checks where only ONE GPU exists: both ranks run their task shard through the HIP path on cuda:0 and exchange
-    the [grad | losses_q | corrects | count] block over gloo (uneven shards for g2_shared: T = 3)."""
+    the [grad | losses_q | corrects | count] block over gloo (uneven shards for g2_shared: T = 3; g3_linkpred = the task-sharded
+    link-prediction setup of BASELINE configs[4]: pair centres, head [2, 2H], one task per rank; g5 = multiply-first layers)."""
     _check_two_ranks(case, _run(case, 2, tmp_path, one_gpu=True))
 
 
