@@ -121,13 +121,20 @@ def test_arxiv_headline_config_matches_oracle():
     _meta_vs_oracle(w)
 
 
-def test_arxiv_forward_backward_per_task_weights_match_oracle(arxiv):
+@pytest.mark.parametrize('shape', ['config', '256-128', '128-128'])
+def test_arxiv_forward_backward_per_task_weights_match_oracle(arxiv, shape):
     """gm_gcn_forward / gm_gcn_backward with param_stride = P (every task its own fast weights, as inside the K-loop) on the
     286k-row query batch: per-set logits and per-set parameter gradients of two tasks -- one of them holding the largest
-    (sampled, hub-centred) subgraph -- against the oracle's forward/backward (learner.py:25-56,134-175)."""
-    from gmeta_amd import _lib
+    (sampled, hub-centred) subgraph -- against the oracle's forward/backward (learner.py:25-56,134-175).  'config' = the arxiv
+    model (128 -> 256 -> 256); '256-128' ends in a multiply-first layer (learner.py:34-40: the K = 256, N = 128 weight-gradient and
+    N = 128 GEMM instantiations at scale); '128-128' = hidden_dim 128 on this batch."""
+    from gmeta_amd import _lib, synth
     lib = _lib.lib()
-    w = arxiv
+    w = dict(arxiv)
+    if shape == '256-128':
+        w['config'] = [('GraphConv', [128, 256]), ('GraphConv', [256, 128]), ('Linear', [128, 3])]
+    elif shape == '128-128':
+        w['config'] = synth.make_config(128, 128, 2, 3)
     Q, T = w['Q'], w['T']
     model = _lib.make_model(w['config'])
     P = int(lib.gm_model_param_count(C.byref(model)))
