@@ -347,10 +347,17 @@ __global__ void k_fuse2(const int32_t* indptr, const int32_t* indices, int64_t r
         if (d > GM_FUSE_MAXDEG) { ++nr; ne += (unsigned long long)d; }
         f2[r] = t; f2_feat[r] = tf;
     }
-    // one pair of atomics per wave, not per thread (92k contended atomics took longer than the table itself)
+    // one pair of atomics per WORKGROUP (wave shuffles, then the four wave partials through LDS): the two counters are a single contended
+    // address each -- per thread 92k atomics took longer than the table itself, per wave the 16k of the 1.14 M-row batch still cost ~100 us
+    __shared__ unsigned long long part[2][4];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nr += __shfl_down(nr, off, 64); ne += __shfl_down(ne, off, 64); }
-    if ((threadIdx.x & 63) == 0 && nr) { atomicAdd(counts, nr); atomicAdd(counts + 1, ne); }
+    if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = nr; part[1][threadIdx.x >> 6] = ne; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long a = part[0][0] + part[0][1] + part[0][2] + part[0][3], e = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+        if (a) { atomicAdd(counts, a); atomicAdd(counts + 1, e); }
+    }
 }
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
