@@ -1066,12 +1066,12 @@ static int launch_wgrad_split(const WgradK& w, hipStream_t s) {
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
 struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; uint16_t* pl_fwd; uint16_t* pl_dz; };
 
-__global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
-                               float* db, int64_t db_stride, WgradSgd u) {
+__device__ __forceinline__ void wgrad_reduce_body(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
+                                                  float* db, int64_t db_stride, const WgradSgd& u, const int bx, const int gx) {
     const int set = blockIdx.y;
     const int c0 = set_chunk_off[set], c1 = set_chunk_off[set + 1];
     const int tot = KN + N;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < tot; j += gridDim.x * blockDim.x) {
+    for (int j = bx * blockDim.x + threadIdx.x; j < tot; j += gx * blockDim.x) {
         // 8 independent loads in flight; the summation order is fixed (deterministic), just not sequential
         float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int c = c0;
@@ -1114,8 +1114,8 @@ __global__ void k_wgrad_reduce(const float* partial, const int32_t* set_chunk_of
 // (K % 8 == 0, N % 32 == 0): a block owns an 8 (k) x 32 (n) patch of W, so that a k-octet of one column (forward planes [k/8][n][8])
 // and an n-octet of one row (dZ planes [n/8][k][8]) are each ONE 16-byte store instead of eight scattered 2-byte ones -- the
 // element-per-thread version spent more time on those stores than on the partial sums.  Blocks past the patches reduce db.
-__global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, const int32_t* set_chunk_off, int K, int N, float* dW, int64_t dw_stride,
-                                                          float* db, int64_t db_stride, WgradSgd u) {
+__device__ __forceinline__ void wgrad_reduce_pl_body(const float* partial, const int32_t* set_chunk_off, int K, int N, float* dW, int64_t dw_stride,
+                                                     float* db, int64_t db_stride, const WgradSgd& u, const int bx) {
     __shared__ uint16_t pl[3][8][40];                       // [plane][k in patch][n in patch], rows padded to 80 B
     const int set = blockIdx.y, tid = threadIdx.x;
     const int c0 = set_chunk_off[set], c1 = set_chunk_off[set + 1];
@@ -1130,8 +1130,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, c
         for (int u_ = 0; c < c1; ++c, ++u_) s8[u_] += partial[(int64_t)c * tot + j];
         return ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));      // same order as k_wgrad_reduce
     };
-    if ((int)blockIdx.x >= n_patch) {                       // db (and the bias step)
-        const int n = ((int)blockIdx.x - n_patch) * 256 + tid;
+    if (bx >= n_patch) {                                    // db (and the bias step)
+        const int n = (bx - n_patch) * 256 + tid;
         if (n < N && db) {
             const float s = sum_of(KN + n);
             db[(int64_t)set * db_stride + n] = s;
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, c
         }
         return;
     }
-    const int kb = blockIdx.x / npn, nb = blockIdx.x - kb * npn, tk = tid >> 5, tn = tid & 31;
+    const int kb = bx / npn, nb = bx - kb * npn, tk = tid >> 5, tn = tid & 31;
     const int k = kb * 8 + tk, n = nb * 32 + tn, j = k * N + n;
     const float s = sum_of(j);
     dW[(int64_t)set * dw_stride + j] = s;
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, c
     u.next[(int64_t)set * u.next_stride + u.w_off + j] = wn;
     if (u.wt) u.wt[(int64_t)set * KN + (int64_t)n * K + k] = wn;
     if (!(u.pl_fwd || u.pl_dz)) return;                     // (uniform)
-    const uint32_t bx = __float_as_uint(wn), bh = bx & 0xffff0000u;
+    const uint32_t bits = __float_as_uint(wn), bh = bits & 0xffff0000u;
     const float r1 = wn - __uint_as_float(bh);
     const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
     const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
@@ -1171,6 +1171,22 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_pl(const float* partial, c
     }
 }
 
+// One reduction launch: its arguments, the variant (use_pl: the updated weights also leave as split-bf16 planes) and its grid width
+struct RedK {
+    const float* partial; const int32_t* set_chunk_off; int K, N; float* dW; int64_t dw_stride; float* db; int64_t db_stride; WgradSgd u;
+    int use_pl, gx;
+};
+__device__ __forceinline__ void wgrad_reduce_one(const RedK& r, const int bx) {
+    if (bx >= r.gx) return;
+    if (r.use_pl) wgrad_reduce_pl_body(r.partial, r.set_chunk_off, r.K, r.N, r.dW, r.dw_stride, r.db, r.db_stride, r.u, bx);
+    else wgrad_reduce_body(r.partial, r.set_chunk_off, r.K * r.N, r.N, r.dW, r.dw_stride, r.db, r.db_stride, r.u, bx, r.gx);
+}
+__global__ __launch_bounds__(256) void k_wgrad_reduce(RedK r) { wgrad_reduce_one(r, blockIdx.x); }
+// The reductions of SEVERAL layers in one launch (blockIdx.z = layer): the backward of gm_meta_step holds the reductions of the layers above
+// the first back (gm_wgrad_args::hold) and runs them with the first layer's -- nobody needs the updated W_l before the next forward.
+struct RedN { RedK r[GM_MAX_GCN]; };
+__global__ __launch_bounds__(256) void k_wgrad_reduce_n(RedN a) { wgrad_reduce_one(a.r[blockIdx.z], blockIdx.x); }
+
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
 static bool wgrad_fast_ok(const gm_wgrad_args& a) {
     return (a.K % 32 == 0) && (a.N % 32 == 0) && !a.a_row && !a.Gb && (a.lda % 4 == 0) && (a.ldg % 4 == 0) &&
@@ -1191,12 +1207,29 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off, a.sgd_next ? a.wt_next : nullptr,
                        a.sgd_next ? a.pl_fwd : nullptr, a.sgd_next ? a.pl_dz : nullptr};
-    if (a.n_chunks <= 0) {      // no rows at all: the gradients are zero
-        const int tot0 = (a.K + 1) * a.N;
-        hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot0 + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off, a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
+    // the reduction of this call's partials: launched now, or held back and launched together with a later call's (gm_wgrad_hold)
+    auto reduce = [&](bool want_pl) -> int {
+        RedK r{a.partial, a.set_chunk_off, a.K, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd, 0, 0};
+        r.use_pl = want_pl && (sgd.pl_fwd || sgd.pl_dz) && a.K % 8 == 0 && a.N % 32 == 0;
+        r.gx = r.use_pl ? (a.K / 8) * (a.N / 32) + (a.N + 255) / 256 : ((a.K + 1) * a.N + 255) / 256;
+        gm_wgrad_hold* h = a.hold;
+        if (h && a.hold_this && h->n < GM_MAX_GCN - 1) {            // keep it for the flush
+            static_assert(sizeof(RedK) <= sizeof(h->slot[0]), "gm_wgrad_hold slot too small");
+            memcpy(h->slot[h->n], &r, sizeof(RedK)); h->sets[h->n] = a.sets; ++h->n;
+            return GM_OK;
+        }
+        if (h && h->n > 0) {                                        // flush: the held reductions + this one, one launch
+            RedN all{}; int gx = r.gx, n = 0;
+            for (; n < h->n; ++n) { memcpy(&all.r[n], h->slot[n], sizeof(RedK)); gx = std::max(gx, all.r[n].gx); GM_REQUIRE(h->sets[n] == a.sets, GM_EINVAL, "wgrad: held reductions of different batches"); }
+            all.r[n++] = r; h->n = 0;
+            hipLaunchKernelGGL(k_wgrad_reduce_n, dim3(gx, a.sets, n), dim3(256), 0, s, all);
+        } else {
+            hipLaunchKernelGGL(k_wgrad_reduce, dim3(r.gx, a.sets), dim3(256), 0, s, r);
+        }
         GM_HIP(hipGetLastError());
         return GM_OK;
-    }
+    };
+    if (a.n_chunks <= 0) return reduce(false);      // no rows at all: the gradients are zero
     WgradK w{};
     w.A = a.A; w.lda = a.lda; w.K = a.K; w.a_row = a.a_row; w.G = a.G; w.ldg = a.ldg; w.N = a.N; w.Gb = a.Gb; w.ldgb = a.ldgb;
     w.a_scale = a.a_scale; w.chunks = a.chunks; w.n_chunks = a.n_chunks; w.partial = a.partial;
@@ -1218,16 +1251,7 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     }
     if (launched) {
         GM_HIP(hipGetLastError());
-        const int tot = (a.K + 1) * a.N;
-        if ((sgd.pl_fwd || sgd.pl_dz) && a.K % 8 == 0 && a.N % 32 == 0) {
-            hipLaunchKernelGGL(k_wgrad_reduce_pl, dim3((a.K / 8) * (a.N / 32) + (a.N + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
-                               a.K, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
-        } else {
-            hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
-                               a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
-        }
-        GM_HIP(hipGetLastError());
-        return GM_OK;
+        return reduce(true);
     }
     const int ld = (w.TK + w.TN) * 32;
     w.RK = 32;
@@ -1240,9 +1264,5 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const int zgroups = (w.TK * w.TN + WG_WAVES * WG_MAXT - 1) / (WG_WAVES * WG_MAXT);
     hipLaunchKernelGGL(k_wgrad, dim3(a.n_chunks, zgroups), dim3(WG_THREADS), lds, s, w);
     GM_HIP(hipGetLastError());
-    const int tot = (a.K + 1) * a.N;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((tot + 255) / 256, a.sets), dim3(256), 0, s, a.partial, a.set_chunk_off,
-                       a.K * a.N, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd);
-    GM_HIP(hipGetLastError());
-    return GM_OK;
+    return reduce(false);
 }

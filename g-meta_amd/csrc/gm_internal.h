@@ -277,6 +277,9 @@ int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K,
 //   dW_t[K,N] = sum_{rows of set t} a_scale[row] * A[row,:]^T  G[row,:]   and   db_t[N] = sum G[row,:]
 // computed as per-chunk partials followed by a deterministic reduction that also applies `beta`:
 //   out_t = (beta_is_sgd ? w_t - lr * sum : sum)
+// Reductions held back by gm_launch_wgrad (hold_this) until a later call on the same batch flushes them together with its own
+// (k_wgrad_reduce_n): opaque argument blocks, filled and consumed by gemm.hip.
+struct gm_wgrad_hold { int n = 0; int sets[GM_MAX_GCN] = {}; alignas(16) unsigned char slot[GM_MAX_GCN][256] = {}; };
 struct gm_wgrad_args {
     const float* A; int64_t lda; int K;
     const int32_t* a_row;               // optional row indirection for A (layer-1 feature gather)
@@ -298,6 +301,8 @@ struct gm_wgrad_args {
     float* wt_next;                     // optional (with sgd_next): the updated W also written transposed, [set][N][K] -- what the NEXT
                                         // step's dZ GEMM (dQ @ W^T on the row-major DMA kernel) reads, instead of a transpose launch
     int64_t rows;                       // total rows covered by the chunks (profiling: flops = 2*rows*K*N)
+    gm_wgrad_hold* hold; int hold_this; // optional: hold this call's reduction back (hold_this = 1; its `partial` must then stay untouched) /
+                                        // flush the held ones with this call's reduction (hold_this = 0)
 };
 #define GM_WGRAD_ROWS 1024
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);

@@ -396,6 +396,8 @@ struct GcnCtx {
     PlaneDir* pd;                // non-NULL inside gm_meta_step
     int dq_zeroed = 0;           // the last forward GEMM already zero-filled bufA (= dQ) for the head/loss launch that follows
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
+    float* partial_l[GM_MAX_GCN];    // dense backward: own partials for the layers above the first, whose reductions are held back and run
+    gm_wgrad_hold hold;              // together with the first layer's (one launch less per layer and backward pass)
     uint16_t* Wsplit;            // per-task weights of the GEMM being launched as three bf16 planes (split-bf16 kernel, gemm_split.h)
     float* WTl[GM_MAX_GCN];      // per-task transposed weights of layer l >= 1, [set][fo][fi]: B of the dZ GEMM (dense backward)
     const float* wt_of[GM_MAX_GCN]; int64_t wt_stride[GM_MAX_GCN];      // the parameter vector (pointer, per-set stride) WTl[l] is the transpose of
@@ -447,6 +449,7 @@ static void gcn_carve(GcnCtx& c, Carver& cv) {
     c.bufA = cv.take<float>(rows * maxd);
     c.bufB = cv.take<float>(rows * maxd);
     c.partial = cv.take<float>((int64_t)c.b->n_chunks * maxkn);
+    for (int l = 1; l < L.n_gcn; ++l) c.partial_l[l] = cv.take<float>((int64_t)c.b->n_chunks * (L.dims[l] + 1) * L.dims[l + 1]);
     for (int l = 1; l < L.n_gcn; ++l) c.WTl[l] = cv.take<float>((int64_t)c.b->sets * L.dims[l] * L.dims[l + 1]);
     c.Wsplit = cv.take<uint16_t>((int64_t)c.b->sets * 3 * maxd * maxd);
     c.cG2 = cv.take<float>((int64_t)c.b->n_c * maxd); c.cT2 = cv.take<float>((int64_t)c.b->n_c * maxd);
@@ -576,6 +579,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
     const gm_layout& L = c.L; const gm_batch* b = c.b;
     const int Lg = L.n_gcn;
     float* dQ = c.bufA; float* T = c.bufB;
+    c.hold.n = 0;
     if (!skip_head) {
         GM_HIP(hipMemsetAsync(dQ, 0, sizeof(float) * b->rows * L.dims[Lg], st));
         HeadK k = make_head(c, params, pstride);
@@ -592,6 +596,10 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         w.partial = c.partial; w.dW = dparams + L.w_off[l]; w.dw_stride = dstride; w.db = dparams + L.b_off[l]; w.db_stride = dstride;
         w.a_scale = b->d_norm; w.K = fi; w.N = fo;
         wgrad_sgd(w, c, l);
+        // the reduction (+ SGD step, weight planes) of a layer above the first is held back and launched with the first layer's: the new
+        // W_l has no reader before the next forward
+        w.hold = &c.hold; w.hold_this = l > 0 ? 1 : 0;
+        if (l > 0) w.partial = c.partial_l[l];
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
             gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1, st); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
