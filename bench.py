@@ -328,7 +328,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ov_ms, ov_n, ov_bytes = 0.0, 0, 0
-    MM_CATS = (1, 2, 4, 5)      # exact-fp32 GEMM / weight gradient, split-bf16 GEMM / weight gradient (gm_profile_read categories)
+    MM_CATS = (1, 2, 4, 5, 6, 7)      # exact-fp32 GEMM / weight gradient, split-bf16 (three pieces) ditto, split-fp16 (two pieces) ditto (gm_profile_read categories)
     ov_mm = {c: [0.0, 0, 0] for c in MM_CATS}
     strict_bytes = 0
     for k in range(a.steps):
@@ -405,6 +405,18 @@ def main():
             extra['exact_f32_mfma_gemm'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
                                             'what': 'default schedule with GM_GEMM_MODE=f32: every update GEMM on v_mfma_f32_32x32x2_f32'}
             lib.gm_set_gemm_mode(1)
+            if lib.gm_get_split_pieces() == 2:      # ... and with the three-piece bf16 split kernels (six exact products) in place of the two-piece fp16 ones
+                lib.gm_set_split_pieces(3)
+                step(0); drain()
+                torch.cuda.synchronize(); te = time.perf_counter()
+                for k in range(a.extra_steps):
+                    step(k)
+                drain()
+                torch.cuda.synchronize()
+                ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
+                extra['split_bf16_three_pieces'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
+                                                    'what': 'default schedule with GM_SPLIT_PIECES=3: every split launch on the exact three-piece bf16 kernels (six products)'}
+                lib.gm_set_split_pieces(-1)
         if lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1:
             # the same schedule with every pass writing Z (fused aggregate + GEMM off): step time, and the aggregate's roofline over an
             # all-full-launch sample -- the figure of the earlier rounds (the large query launches are aggregate launches again)
@@ -489,8 +501,13 @@ def main():
                 traffic_source = 'profiles/agg_traffic.json (%s; separate rocprofv3 --pmc pass, not this run)' % tj.get('taken', 'date unknown')
             except Exception:
                 traffic = None
-        gemm_mode = ('split-bf16: large N=256 launches on v_mfma_f32_32x32x16_bf16 with every fp32 operand split exactly into three bf16 pieces, six '
-                     'products, fp32 accumulation (error vs fp64 <= the fp32 fmaf chain\'s; DESIGN.md section 4); other launches exact fp32'
+        two_piece = lib.gm_get_gemm_mode() == 1 and lib.gm_get_split_pieces() == 2 and not (a.cone or a.sparse_bwd)
+        gemm_mode = (('split-fp16: large N=128/256 launches on v_mfma_f32_32x32x16_f16 with every fp32 operand split into two fp16 pieces (22 significand bits) '
+                      'under per-task power-of-two scales from magnitude bounds recorded on the device, three products, fp32 accumulation (error vs fp64 below the '
+                      'fp32 fmaf chain\'s, tests/test_hip_gemm_numerics.py; DESIGN.md section 4); launches without bounds: split-bf16, three exact pieces / six '
+                      'products; other launches exact fp32' if two_piece else
+                      'split-bf16: large N=128/256 launches on v_mfma_f32_32x32x16_bf16 with every fp32 operand split exactly into three bf16 pieces, six '
+                      'products, fp32 accumulation (error vs fp64 <= the fp32 fmaf chain\'s; DESIGN.md section 4); other launches exact fp32')
                      if lib.gm_get_gemm_mode() == 1 else 'exact fp32 (v_mfma_f32_32x32x2_f32) everywhere')
         fused = lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1 and not (a.cone or a.hoist_z1)
         out = {
@@ -532,14 +549,20 @@ def main():
                                         'sources read once = min(edges, rows) rows).  GM_FUSE_AGG=0 gives the all-full-launch sample of the earlier rounds.')
                                        if fused else 'full launches only (fused aggregate+GEMM off or not applicable to this schedule)'},
         }
-        if mm[1][0] + mm[4][0] > 0:
+        if mm[1][0] + mm[4][0] + mm[6][0] > 0:
             # Every launch is priced on the matrix pipe it ran on: the exact-fp32 kernels (v_mfma_f32_32x32x2_f32) against the 157.3 TFLOP/s dense
             # fp32 matrix peak, the split-bf16 kernels -- which issue SIX bf16 MFMA flops per flop of the fp32 product -- against 2.5 PFLOP/s bf16.
-            def pipe(exact, split):
-                ms = mm[exact][0] + mm[split][0]; fl = mm[exact][2] + mm[split][2]
-                t_pk = mm[exact][2] / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3 + 6.0 * mm[split][2] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3   # ms at the peak of the pipe used
-                d = {'fp32_equivalent_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, 'launches': mm[exact][1] + mm[split][1],
+            def pipe(exact, split, split16):
+                ms = mm[exact][0] + mm[split][0] + mm[split16][0]; fl = mm[exact][2] + mm[split][2] + mm[split16][2]
+                t_pk = (mm[exact][2] / (MFMA_F32_PEAK_TFLOPS * 1e12) + 6.0 * mm[split][2] / (MFMA_BF16_PEAK_TFLOPS * 1e12) +
+                        3.0 * mm[split16][2] / (MFMA_BF16_PEAK_TFLOPS * 1e12)) * 1e3       # ms at the peak of the pipe used (fp16 and bf16 MFMA: the same dense peak)
+                d = {'fp32_equivalent_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, 'launches': mm[exact][1] + mm[split][1] + mm[split16][1],
                      'frac': round(t_pk / ms, 4) if ms > 0 else None}
+                if mm[split16][0] > 0:
+                    tf6 = mm[split16][2] / (mm[split16][0] * 1e-3) / 1e12
+                    d['split_fp16'] = {'launches': mm[split16][1], 'fp32_equivalent_tflops': round(tf6, 1), 'fp16_mfma_tflops': round(3 * tf6, 1),
+                                       'frac_of_fp16_peak': round(3 * tf6 / MFMA_BF16_PEAK_TFLOPS, 4), 'ms_per_step': round(mm[split16][0] / max(ser_steps, 1), 3),
+                                       'note': 'memory-bound at three products per fp32 product: see DESIGN.md section 4 for the bytes these launches move'}
                 if mm[split][0] > 0:
                     tfs = mm[split][2] / (mm[split][0] * 1e-3) / 1e12
                     d['split_bf16'] = {'launches': mm[split][1], 'fp32_equivalent_tflops': round(tfs, 1), 'bf16_mfma_tflops': round(6 * tfs, 1),
@@ -549,11 +572,11 @@ def main():
                     d['exact_f32'] = {'launches': mm[exact][1], 'tflops': round(tfe, 1), 'frac_of_f32_peak': round(tfe / MFMA_F32_PEAK_TFLOPS, 4),
                                       'ms_per_step': round(mm[exact][0] / max(ser_steps, 1), 3)}
                 return d, t_pk
-            g_d, g_pk = pipe(1, 4); w_d, w_pk = pipe(2, 5)
+            g_d, g_pk = pipe(1, 4, 6); w_d, w_pk = pipe(2, 5, 7)
             g_d['what'] = 'forward X@W and backward dZ = dQ@W^T'; w_d['what'] = 'dW = (norm*Z)^T dQ, db, incl. the partial reduction'
             out['mfma'] = {'note': 'update GEMMs, HIP events around every launch of the same serialised steps as the roofline; flops counted as 2*rows*K*N of the '
                                    'fp32 product; `frac` = time those launches would take at the dense peak of the pipe each one ran on (fp32 MFMA 157.3 TFLOP/s for '
-                                   'the exact kernels; bf16 MFMA 2.5 PFLOP/s at 6 bf16 flops per fp32 flop for the split-bf16 kernels) / measured time',
+                                   'the exact kernels; bf16 / fp16 MFMA 2.5 PFLOP/s at 6 bf16 (three-piece kernels) or 3 fp16 (two-piece kernels) flops per fp32 flop for the split kernels) / measured time',
                            'peak_tflops': {'f32': MFMA_F32_PEAK_TFLOPS, 'bf16': MFMA_BF16_PEAK_TFLOPS}, 'gemm_mode': gemm_mode, 'gemm': g_d, 'wgrad': w_d}
             if ser_steps > 0:
                 # composite bound of the whole step: every update launch at the peak of its own pipe + all aggregate bytes at the HBM peak
@@ -565,7 +588,7 @@ def main():
                                      'frac_of_serial_bound': round((t_mfma + t_hbm) / ms_per_step, 3),
                                      'frac_of_overlapped_bound': round(max(t_mfma, t_hbm) / ms_per_step, 3),
                                      'labelled_extra_ms_if_all_flops_ran_at_fp32_mfma_peak': round(t_f32, 2),
-                                     'note': 'split-bf16 launches priced at 6 bf16 MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
+                                     'note': 'split launches priced at 6 (bf16, three pieces) or 3 (fp16, two pieces) MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
                                              'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
         if e2e:
             out['end_to_end'] = e2e

@@ -55,6 +55,8 @@ PROTOTYPES = {
     'gm_meta_finish': (C.c_int, [vp, i64, i32, vp, vp, vp]),
     'gm_set_gemm_mode': (None, [i32]),
     'gm_get_gemm_mode': (i32, []),
+    'gm_get_split_pieces': (i32, []),
+    'gm_set_split_pieces': (None, [i32]),
     'gm_set_fuse_agg': (None, [i32]),
     'gm_get_fuse_agg': (i32, []),
     'gm_profile_enable': (None, [i32]),

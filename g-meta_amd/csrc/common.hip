@@ -173,6 +173,7 @@ const gm_knobs& gm_knob() {
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
         k.wgrad_round_bias = env("GM_WGRAD_ROUND_BIAS", 25);
+        k.split_pieces = env("GM_SPLIT_PIECES", 2);
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
     });
     return k;

@@ -323,6 +323,22 @@ __global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list,
     }
 }
 // per-edge tables: source norm (both orientations) and source feature row (forward orientation)
+// Row gains of the aggregates (gm_batch::d_gain, zeroed): bit patterns of non-negative floats order as unsigned integers.
+__global__ void k_gains(const int32_t* indptr, const int32_t* indices, const int32_t* indptr_t, const float* norm, int64_t rows, unsigned* gain) {
+    float g0 = 0.f, g1 = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        // hub rows: norm <= 1, so the degree bounds the sum (their neighbours are mostly low-degree rows: within ~2x of it)
+        const int e0 = indptr[i], e1 = indptr[i + 1];
+        float s = (float)(e1 - e0);
+        if (e1 - e0 <= 32) { s = 0.f; for (int e = e0; e < e1; ++e) s += norm[indices[e]]; }
+        g0 = fmaxf(g0, s);
+        g1 = fmaxf(g1, norm[i] * (float)(indptr_t[i + 1] - indptr_t[i]));
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { g0 = fmaxf(g0, __shfl_xor(g0, o)); g1 = fmaxf(g1, __shfl_xor(g1, o)); }
+    if ((threadIdx.x & 63) == 0) { if (g0 > 0.f) atomicMax(gain, __float_as_uint(g0)); if (g1 > 0.f) atomicMax(gain + 1, __float_as_uint(g1)); }
+}
+
 __global__ void k_edge_tables(const int32_t* indices, const int32_t* indices_t, int64_t edges, const float* norm, const int32_t* feat_row,
                               float* enorm, float* enorm_t, int32_t* efeat) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < edges; e += (int64_t)gridDim.x * blockDim.x) {
@@ -418,7 +434,7 @@ static void batch_free(gm_batch* b) {
     gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
     gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
     gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
-    gm_dev_free((int4*)b->d_fuse2, s); gm_dev_free((int4*)b->d_fuse2_feat, s);
+    gm_dev_free((int4*)b->d_fuse2, s); gm_dev_free((int4*)b->d_fuse2_feat, s); gm_dev_free(b->d_gain, s);
     gm_dev_free(b->d_enorm[0], s); gm_dev_free(b->d_enorm[1], s); gm_dev_free(b->d_efeat, s);
     gm_dev_free(b->d_hub[0], s); gm_dev_free(b->d_hub[1], s); gm_dev_free(b->d_hub_scratch[0], s); gm_dev_free(b->d_hub_scratch[1], s);
     gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
@@ -484,6 +500,15 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             gm_agg_sched sc;
             GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s));
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
+        }
+    }
+    {   // at least 1: an isolated row still passes its own magnitude on wherever a kernel adds a self term
+        GM_TRY(gm_alloc(&b->d_gain, (size_t)2, s));
+        GM_HIP(hipMemsetD32Async((hipDeviceptr_t)b->d_gain, 0x3f800000, 2, s));            // 1.0f, 1.0f
+        if (b->rows > 0) {
+            hipLaunchKernelGGL(k_gains, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, b->d_norm,
+                               (int64_t)b->rows, reinterpret_cast<unsigned*>(b->d_gain));
+            GM_HIP(hipGetLastError());
         }
     }
     const int edge_tables = gm_knob().agg_edge_tables;

@@ -478,6 +478,9 @@ int gm_gemm_mode() {
 }
 extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode.store(mode ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
+static std::atomic<int> g_split_pieces{-1};     // gm_set_split_pieces override (-1: GM_SPLIT_PIECES / default 2)
+extern "C" void gm_set_split_pieces(int32_t pieces) { g_split_pieces.store(pieces == 3 ? 3 : (pieces == 2 ? 2 : -1), std::memory_order_relaxed); }
+extern "C" int32_t gm_get_split_pieces(void) { return gm_split_np(); }
 // The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
 const float* gm_zero_row(hipStream_t s) {
     static std::mutex mu;
@@ -498,16 +501,28 @@ bool gm_gemm_split_ok(int n_tiles, int K, int N) {
     const int min_tiles = gm_knob().gemm_split_min_tiles >= 0 ? gm_knob().gemm_split_min_tiles : gm_num_cus() / 4;
     return gm_gemm_mode() == 1 && (N == 256 || N == 128) && K % 16 == 0 && K >= 32 && n_tiles >= min_tiles;
 }
-int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, sets), dim3(256), 0, s, params, pstride, w_off, K, N, trans, out);
+int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s, int np, gm_bound bound) {
+    GM_REQUIRE(np == 3 || (np == 2 && bound.amax), GM_EINVAL, "split_weights: two-piece planes need a bound");
+    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, sets), dim3(256), 0, s, params, pstride, w_off, K, N, trans, out, np, bound);
     GM_HIP(hipGetLastError());
     return GM_OK;
+}
+int gm_amax(const float* x, int64_t stride, int64_t off, int64_t n, int sets, unsigned* out, int64_t out_stride, hipStream_t s) {
+    if (n <= 0 || sets <= 0) return GM_OK;
+    const int bx = (int)std::min<int64_t>(64, (n + 2047) / 2048);
+    hipLaunchKernelGGL(k_amax, dim3(bx, sets), dim3(256), 0, s, x, stride, off, n, out, out_stride);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+int gm_split_np() {
+    const int o = g_split_pieces.load(std::memory_order_relaxed);
+    return o > 0 ? o : (gm_knob().split_pieces == 3 ? 3 : 2);
 }
 
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
-    const int cat = a.Bsplit ? GM_PROF_GEMM_SPLIT : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
+    const int cat = a.Bsplit ? (a.np == 2 ? GM_PROF_GEMM_SPLIT16 : GM_PROF_GEMM_SPLIT) : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
     const int rc = launch_gemm_nn(a, s);
     gm_prof_end(cat, s);
@@ -523,6 +538,9 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
         k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
         k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;
+        const bool f16 = a.np == 2;
+        GM_REQUIRE(!f16 || (a.a_bound.amax && a.b_bound.amax), GM_EINVAL, "gemm: the two-piece split kernel needs bounds for both operands");
+        k.a_bound = f16 ? a.a_bound : gm_no_bound(); k.b_bound = f16 ? a.b_bound : gm_no_bound(); k.amax_out = a.amax_out;
         // persistent: one workgroup per CU (it fills the CU's register file, so nothing else co-resides).  GM_GEMM_SPLIT_GRID caps the
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
         const int cus = gm_stream_cus(s);                                 // the stream's CU mask, if it has one
@@ -540,17 +558,22 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             // 1/mult of the tiles, give the dispatcher a yield point every ~0.65/mult ms (default 4: 27.7 -> 27.4 ms at task_num 32, 5.12 -> 4.86 ms
             // for the 4-task shard, where the support chain is the critical path; 8 and more lose to the per-workgroup prologue).
             const int mult_f = gm_knob().gemm_fused_rounds;
-            if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
-            else hipLaunchKernelGGL((k_gemm_split_p<true, 2>), dim3(std::min(a.n_tiles, mult_f * grid_cap)), dim3(1024), 0, s, k);
+            const dim3 grid(std::min(a.n_tiles, mult_f * grid_cap));
+            if (a.N == 128 && f16) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2, 2>), grid, dim3(1024), 0, s, k);
+            else if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2, 3>), grid, dim3(1024), 0, s, k);
+            else if (f16) hipLaunchKernelGGL((k_gemm_split_p<true, 2, 4, 2>), grid, dim3(1024), 0, s, k);
+            else hipLaunchKernelGGL((k_gemm_split_p<true, 2, 4, 3>), grid, dim3(1024), 0, s, k);
         } else {
             // a launch that would leave more than half of the CUs without a tile walks 64-row half tiles: half the MFMA chain per workgroup
             const int half_on = gm_knob().gemm_half_tiles;
-            if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<false, 1, 2>), dim3(std::min(a.n_tiles, gm_knob().gemm_plain_rounds * grid_cap)), dim3(1024), 0, s, k);
-            else if (half_on && 2 * a.n_tiles <= grid_cap) hipLaunchKernelGGL((k_gemm_split_p<false, 1>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
-            else {
-                const int mult_p = gm_knob().gemm_plain_rounds;
-                hipLaunchKernelGGL((k_gemm_split_p<false, 2>), dim3(std::min(a.n_tiles, mult_p * grid_cap)), dim3(1024), 0, s, k);
-            }
+            const dim3 grid_r(std::min(a.n_tiles, gm_knob().gemm_plain_rounds * grid_cap));
+            if (a.N == 128 && f16) hipLaunchKernelGGL((k_gemm_split_p<false, 1, 2, 2>), grid_r, dim3(1024), 0, s, k);
+            else if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<false, 1, 2, 3>), grid_r, dim3(1024), 0, s, k);
+            else if (half_on && 2 * a.n_tiles <= grid_cap) {
+                if (f16) hipLaunchKernelGGL((k_gemm_split_p<false, 1, 4, 2>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
+                else hipLaunchKernelGGL((k_gemm_split_p<false, 1, 4, 3>), dim3(2 * a.n_tiles), dim3(1024), 0, s, k);
+            } else if (f16) hipLaunchKernelGGL((k_gemm_split_p<false, 2, 4, 2>), grid_r, dim3(1024), 0, s, k);
+            else hipLaunchKernelGGL((k_gemm_split_p<false, 2, 4, 3>), grid_r, dim3(1024), 0, s, k);
         }
         GM_HIP(hipGetLastError());
         return GM_OK;
@@ -622,6 +645,7 @@ struct WgradK {
     const float* A; int64_t lda; int K; const int32_t* a_row;   // optional row indirection for A (feature gather)
     const float* G; int64_t ldg; int N; const float* Gb; int64_t ldgb;
     const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN; int vec;
+    gm_bound a_bound, g_bound;               // k_wgrad_split<., ., 2>: bounds of the A / G rows (two fp16 pieces per operand)
 };
 
 #define WG_PF 2     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 2 * 1024 * 4 floats per stage
@@ -891,13 +915,17 @@ static int launch_wgrad_fast(const WgradK& w, hipStream_t s) {
 // scale with ONE load per item and stage, read back with v_readlane.  db = column sums of G from the loader registers.
 // Output: the same per-chunk partial [(K+1) x N] as k_wgrad_fast (reduced by k_wgrad_reduce).
 #define WGS_THREADS 512
+__device__ __forceinline__ gm_f32x16 wgs_mfma(gm_bf16x8 a, gm_bf16x8 b, gm_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ gm_f32x16 wgs_mfma(gm_f16x8 a, gm_f16x8 b, gm_f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 __device__ const float gm_wgs_ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // the row "scales" of an unscaled operand
-template <int KT, int NT>
+// NP = 3: three bf16 pieces per operand, six products;  NP = 2: two fp16 pieces under the per-set power-of-two scales of w.a_bound / w.g_bound
+// (gemm_split.h), three products, the partial leaves multiplied by 1 / (s_a s_g).
+template <int KT, int NT, int NP = 3>
 __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     constexpr int K = KT * 128, N = NT * 128, COLS = K + N;
     constexpr int NTK = KT, NTN = 2 * NT;                                           // 32 x 32 tiles per wave: (K / 32) / 4 x (N / 32) / 2
     constexpr int A_PLANE = 2 * K * 16, G_PLANE = 2 * N * 16;                       // bytes: [2 octets][cols][8 rows] bf16
-    constexpr int STAGE = 3 * A_PLANE + 3 * G_PLANE;                                // 96 * (K + N) bytes: 48 KiB at 256 + 256
+    constexpr int STAGE = NP * A_PLANE + NP * G_PLANE;                              // 32 NP (K + N) bytes: 48 KiB at 256 + 256, three pieces
     constexpr int ITEMS = 2 * COLS;                                                 // (octet, column) items per stage: 512 .. 1024
     static_assert(2 * K <= WGS_THREADS && 2 * N <= WGS_THREADS && K % 64 == 0 && N % 64 == 0, "one wave-uniform item per operand and thread");
     extern __shared__ __attribute__((aligned(16))) float sm_f[];
@@ -933,7 +961,7 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
         valid[it] = wave_u * 64 < 2 * W;                                            // (wave-uniform)
         const int oct = valid[it] ? (wave_u * 64) / W : 0, c = valid[it] ? tid - oct * W : 0;
         oct8[it] = oct * 8;
-        dst[it] = (it == 0 ? 0 : 3 * A_PLANE) + oct * W * 16 + c * 16;
+        dst[it] = (it == 0 ? 0 : NP * A_PLANE) + oct * W * 16 + c * 16;
         if (it == 1) gcol = oct * N + c;
         const int64_t ld = it == 0 ? w.lda : w.ldg;
         // addresses: a wave-uniform 64-bit base (the operand at the chunk's first row / the scale vector) in SGPRs + ONE 32-bit byte
@@ -947,6 +975,8 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     const uint64_t sscale = uni64(scaled ? (const void*)(w.a_scale + row0) : (const void*)gm_wgs_ones);
     float pf[2][2][8], ps[2];                                                       // [slot = stage parity][item][row], [slot]
     float bsum = 0.f;
+    float op_scale[2] = {1.f, 1.f};                                                 // NP == 2: s_a, s_g of this chunk's set
+    if constexpr (NP == 2) { const int set = w.chunks[chunk * 3]; op_scale[0] = gs_bound_scale(w.a_bound, set); op_scale[1] = gs_bound_scale(w.g_bound, set); }
     // Stage R0 / 16 -> slot SL: 17 loads per thread, ALWAYS issued (rows are clamped to the chunk, so a stage past the end re-reads the
     // last row and is never stored): every wait is the same vmcnt(17) and the loop body has no control flow around the asm
 #define WGS_ISSUE(R0, SL)                                                                                                  \
@@ -976,7 +1006,19 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
                 if (it == 0) v_ *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ps[SL]), j));                   \
                 x[j] = r < nrows ? v_ : 0.f;                                        /* rows past the chunk end contribute zeros */ \
                 if (it == 1) bsum += x[j];                                                                                 \
+                if constexpr (NP == 2) x[j] *= op_scale[it];                                                               \
             }                                                                                                              \
+            if constexpr (NP == 2) {                                                                                       \
+                typedef _Float16 h2_ __attribute__((ext_vector_type(2)));                                                  \
+                uint4 vh, vm; unsigned* ph = &vh.x; unsigned* pm = &vm.x;                                                  \
+                _Pragma("unroll") for (int j = 0; j < 8; j += 2) {                                                         \
+                    const _Float16 h0 = (_Float16)x[j], h1 = (_Float16)x[j + 1];                                           \
+                    const h2_ hh = {h0, h1}, mm = {(_Float16)(x[j] - (float)h0), (_Float16)(x[j + 1] - (float)h1)};        \
+                    ph[j >> 1] = __builtin_bit_cast(unsigned, hh); pm[j >> 1] = __builtin_bit_cast(unsigned, mm);          \
+                }                                                                                                          \
+                *reinterpret_cast<uint4*>((S_) + dst[it]) = vh;                                                            \
+                *reinterpret_cast<uint4*>((S_) + dst[it] + plane[it]) = vm;                                                \
+            } else                                                                                                         \
             _Pragma("unroll") for (int pl_ = 0; pl_ < 3; ++pl_) {                                                          \
                 uint4 v;                                                            /* hi16 of eight values, packed pairwise */ \
                 v.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u);                    \
@@ -989,7 +1031,7 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
         }                                                                                                                  \
     } while (0)
 #define WGS_STORE(R0, SL, S_) do { WGS_STORE_IT(R0, SL, S_, 0); WGS_STORE_IT(R0, SL, S_, 1); } while (0)
-    const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = 3 * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
+    const int a_lane = kh * K * 16 + (wy * NTK * 32 + li) * 16, g_lane = NP * A_PLANE + kh * N * 16 + (wx * NTN * 32 + li) * 16;
     // One stage: the MFMAs over LDS buffer SCUR with the split + store of the NEXT stage (register slot SLN -> LDS buffer SNEXT, last read
     // before the previous barrier) interleaved between the tile columns, so that the VALU work of the split runs under the matrix pipe
     // instead of after it (two waves per SIMD reach the end of their MFMAs together: as a separate phase the split left the pipe idle
@@ -997,19 +1039,21 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     // six products is the 16-wave kernel's (l*h, h*l, m*m, m*h, h*m, h*h).  A stage past the chunk end is all zeros: its MFMAs add +0.
 #define WGS_STAGE(SCUR, R0N, SLN, SNEXT)                                                                                   \
     do {                                                                                                                   \
-        gm_bf16x8 af[NTK][3];                                                                                              \
+        frag_t af[NTK][NP];                                                                                                \
         _Pragma("unroll") for (int a = 0; a < NTK; ++a)                                                                    \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) af[a][p] = *reinterpret_cast<const gm_bf16x8*>((SCUR) + a_lane + p * A_PLANE + a * 512); \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) af[a][p] = *reinterpret_cast<const frag_t*>((SCUR) + a_lane + p * A_PLANE + a * 512); \
         WGS_WAIT(SLN);                                                                                                     \
         _Pragma("unroll") for (int b = 0; b < NTN; ++b) {                                                                  \
-            gm_bf16x8 gf[3];                                                                                               \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) gf[p] = *reinterpret_cast<const gm_bf16x8*>((SCUR) + g_lane + p * G_PLANE + b * 512); \
-            WGS_PROD(2, 0) WGS_PROD(0, 2) WGS_PROD(1, 1) WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0)                      \
+            frag_t gf[NP];                                                                                                 \
+            _Pragma("unroll") for (int p = 0; p < NP; ++p) gf[p] = *reinterpret_cast<const frag_t*>((SCUR) + g_lane + p * G_PLANE + b * 512); \
+            if constexpr (NP == 3) { WGS_PROD(2, 0) WGS_PROD(0, 2) WGS_PROD(1, 1) WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0) } \
+            else { WGS_PROD(1, 0) WGS_PROD(0, 1) WGS_PROD(0, 0) }                                                          \
             if (b == 0) WGS_STORE_IT(R0N, SLN, SNEXT, 0);                                                                  \
             if (b == NTN / 2) WGS_STORE_IT(R0N, SLN, SNEXT, 1);                                                            \
         }                                                                                                                  \
     } while (0)
-#define WGS_PROD(PA, PB) _Pragma("unroll") for (int a = 0; a < NTK; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][PA], gf[PB], acc[a][b], 0, 0, 0);
+    typedef typename std::conditional<NP == 3, gm_bf16x8, gm_f16x8>::type frag_t;
+#define WGS_PROD(PA, PB) _Pragma("unroll") for (int a = 0; a < NTK; ++a) acc[a][b] = wgs_mfma(af[a][PA], gf[PB], acc[a][b]);
     // Stage s lives in LDS buffer s & 1 and came through register slot s & 1.  Half-iteration of stage s: issue stage s + 2 (its slot was
     // emptied into LDS one half-iteration ago), then the stage.  Two half-iterations per loop trip so that the slots are compile-time
     // registers; no control flow around the asm (a copy the compiler inserted on one arm of a branch read a register before its wait).
@@ -1039,13 +1083,18 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
 #undef WGS_STAGE
 #undef WGS_PROD
     float* out = w.partial + (int64_t)chunk * (K + 1) * N;
+    const float inv_a = 1.f / op_scale[0], inv_g = 1.f / op_scale[1];               // powers of two (1 when NP == 3)
 #pragma unroll
     for (int a = 0; a < NTK; ++a)
 #pragma unroll
         for (int b = 0; b < NTN; ++b) {
             const int tk = wy * NTK + a, tn = wx * NTN + b;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * N + tn * 32 + li] = acc[a][b][e];
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[a][b][e];
+                if constexpr (NP == 2) v = v * inv_a * inv_g;
+                out[(int64_t)(tk * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh) * N + tn * 32 + li] = v;
+            }
         }
     // db: the two octet threads of a G column add up through LDS (fixed order)
     float* red = reinterpret_cast<float*>(sm);
@@ -1055,16 +1104,24 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
 }
 
 template <int KT, int NT>
-static int launch_wgrad_split(const WgradK& w, hipStream_t s) {
+static int launch_wgrad_split(const WgradK& w, hipStream_t s, int np) {
     constexpr int K = KT * 128, N = NT * 128;
-    const size_t lds = 2 * 96 * (size_t)(K + N);
-    GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT>));
-    hipLaunchKernelGGL((k_wgrad_split<KT, NT>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
+    const size_t lds = 2 * 32 * (size_t)np * (size_t)(K + N);
+    if (np == 2) {
+        GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT, 2>));
+        hipLaunchKernelGGL((k_wgrad_split<KT, NT, 2>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
+    } else {
+        GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT, 3>));
+        hipLaunchKernelGGL((k_wgrad_split<KT, NT, 3>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
+    }
     return GM_OK;
 }
 
 // out_t[j] = sum over the set's chunks of partial[c][j];  j < K*N -> dW, else db.
-struct WgradSgd { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; uint16_t* pl_fwd; uint16_t* pl_dz; };
+struct WgradSgd {
+    const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; int64_t w_off, b_off; float* wt; uint16_t* pl_fwd; uint16_t* pl_dz;
+    int pl_np; gm_bound pl_bound;       // planes as two fp16 pieces under pl_bound (pl_np == 2) or three bf16 pieces
+};
 
 __device__ __forceinline__ void wgrad_reduce_body(const float* partial, const int32_t* set_chunk_off, int KN, int N, float* dW, int64_t dw_stride,
                                                   float* db, int64_t db_stride, const WgradSgd& u, const int bx, const int gx) {
@@ -1089,17 +1146,24 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* partial, const in
                 if (u.wt) { const int k = j / N, n = j - k * N; u.wt[(int64_t)set * KN + (int64_t)n * (KN / N) + k] = wn; }
                 if (u.pl_fwd || u.pl_dz) {          // exact 3-way bf16 split of the new weight, straight into the next step's GEMM operand planes
                     const int K = KN / N, k = j / N, n = j - k * N;
-                    const uint32_t bx = __float_as_uint(wn), bh = bx & 0xffff0000u;
-                    const float r1 = wn - __uint_as_float(bh);
-                    const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
-                    const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
+                    uint32_t bh, bm, bl = 0;
+                    if (u.pl_np == 2) {             // two fp16 pieces under the set's scale (bit patterns in the high halves, as below)
+                        const float xs = wn * gs_bound_scale_v(u.pl_bound, set);
+                        const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
+                        bh = (uint32_t)__builtin_bit_cast(uint16_t, h) << 16; bm = (uint32_t)__builtin_bit_cast(uint16_t, m) << 16;
+                    } else {
+                        const uint32_t bx = __float_as_uint(wn); bh = bx & 0xffff0000u;
+                        const float r1 = wn - __uint_as_float(bh);
+                        bm = __float_as_uint(r1) & 0xffff0000u;
+                        bl = __float_as_uint(r1 - __uint_as_float(bm));
+                    }
                     if (u.pl_fwd) {                 // B[k][n] = W[k][n]  ->  [k/8][n][8]
                         uint16_t* o = u.pl_fwd + (int64_t)set * 3 * KN + ((int64_t)(k >> 3) * N + n) * 8 + (k & 7);
-                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
+                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); if (u.pl_np != 2) o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
                     }
                     if (u.pl_dz) {                  // B[k'][n'] = W[n'][k'] (k' = n, n' = k)  ->  [n/8][k][8]
                         uint16_t* o = u.pl_dz + (int64_t)set * 3 * KN + ((int64_t)(n >> 3) * K + k) * 8 + (n & 7);
-                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
+                        o[0] = (uint16_t)(bh >> 16); o[KN] = (uint16_t)(bm >> 16); if (u.pl_np != 2) o[2 * (int64_t)KN] = (uint16_t)(bl >> 16);
                     }
                 }
             }
@@ -1148,20 +1212,27 @@ __device__ __forceinline__ void wgrad_reduce_pl_body(const float* partial, const
     u.next[(int64_t)set * u.next_stride + u.w_off + j] = wn;
     if (u.wt) u.wt[(int64_t)set * KN + (int64_t)n * K + k] = wn;
     if (!(u.pl_fwd || u.pl_dz)) return;                     // (uniform)
-    const uint32_t bits = __float_as_uint(wn), bh = bits & 0xffff0000u;
-    const float r1 = wn - __uint_as_float(bh);
-    const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
-    const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
-    pl[0][tk][tn] = (uint16_t)(bh >> 16); pl[1][tk][tn] = (uint16_t)(bm >> 16); pl[2][tk][tn] = (uint16_t)(bl >> 16);
+    const int np = u.pl_np == 2 ? 2 : 3;
+    if (np == 2) {                                          // two fp16 pieces under the set's scale
+        const float xs = wn * gs_bound_scale_v(u.pl_bound, set);
+        const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
+        pl[0][tk][tn] = __builtin_bit_cast(uint16_t, h); pl[1][tk][tn] = __builtin_bit_cast(uint16_t, m);
+    } else {
+        const uint32_t bits = __float_as_uint(wn), bh = bits & 0xffff0000u;
+        const float r1 = wn - __uint_as_float(bh);
+        const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
+        const uint32_t bl = __float_as_uint(r1 - __uint_as_float(bm));
+        pl[0][tk][tn] = (uint16_t)(bh >> 16); pl[1][tk][tn] = (uint16_t)(bm >> 16); pl[2][tk][tn] = (uint16_t)(bl >> 16);
+    }
     __syncthreads();
-    if (tid < 96 && u.pl_fwd) {                             // forward planes: unit (plane, n) = the patch's 8 k of column n
+    if (tid < 32 * np && u.pl_fwd) {                             // forward planes: unit (plane, n) = the patch's 8 k of column n
         const int p = tid >> 5, c = tid & 31;
         uint16_t v[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = pl[p][q][c];
         uint4 w4 = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
         *reinterpret_cast<uint4*>(u.pl_fwd + (int64_t)set * 3 * KN + (int64_t)p * KN + ((int64_t)kb * N + nb * 32 + c) * 8) = w4;
-    } else if (tid >= 128 && tid < 224 && u.pl_dz) {        // dZ planes: unit (plane, k, n-octet) = 8 consecutive n of row k
+    } else if (tid >= 128 && tid < 128 + 32 * np && u.pl_dz) {        // dZ planes: unit (plane, k, n-octet) = 8 consecutive n of row k
         const int t = tid - 128, p = t >> 5, r = t & 31, kk = r >> 2, no = r & 3;
         uint16_t v[8];
 #pragma unroll
@@ -1198,7 +1269,7 @@ static bool wgrad_takes_split(const gm_wgrad_args& a) {
     return a.n_chunks > 0 && wgrad_fast_ok(a) && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= gm_num_cus() / 4 && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256);
 }
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
-    const int cat = wgrad_takes_split(a) ? GM_PROF_WGRAD_SPLIT : GM_PROF_WGRAD;
+    const int cat = wgrad_takes_split(a) ? ((a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? GM_PROF_WGRAD_SPLIT16 : GM_PROF_WGRAD_SPLIT) : GM_PROF_WGRAD;
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
     const int rc = launch_wgrad(a, s);
     gm_prof_end(cat, s);
@@ -1206,7 +1277,8 @@ int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
 }
 static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const WgradSgd sgd{a.sgd_cur, a.sgd_cur_stride, a.sgd_next, a.sgd_next_stride, a.sgd_lr, a.w_off, a.b_off, a.sgd_next ? a.wt_next : nullptr,
-                       a.sgd_next ? a.pl_fwd : nullptr, a.sgd_next ? a.pl_dz : nullptr};
+                       a.sgd_next ? a.pl_fwd : nullptr, a.sgd_next ? a.pl_dz : nullptr, a.pl_np, a.pl_bound};
+    GM_REQUIRE(!(a.pl_np == 2 && (a.pl_fwd || a.pl_dz)) || a.pl_bound.amax, GM_EINVAL, "wgrad: two-piece planes need a bound");
     // the reduction of this call's partials: launched now, or held back and launched together with a later call's (gm_wgrad_hold)
     auto reduce = [&](bool want_pl) -> int {
         RedK r{a.partial, a.set_chunk_off, a.K, a.N, a.dW, a.dw_stride, a.db, a.db_stride, sgd, 0, 0};
@@ -1237,10 +1309,12 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     bool launched = false;
     const bool fast_ok = wgrad_fast_ok(a);
     if (wgrad_takes_split(a)) {
-        if (a.K == 256 && a.N == 256) GM_TRY((launch_wgrad_split<2, 2>(w, s)));
-        else if (a.K == 128 && a.N == 256) GM_TRY((launch_wgrad_split<1, 2>(w, s)));
-        else if (a.K == 256 && a.N == 128) GM_TRY((launch_wgrad_split<2, 1>(w, s)));
-        else GM_TRY((launch_wgrad_split<1, 1>(w, s)));
+        const int np = (a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? 2 : 3;
+        w.a_bound = a.a_bound; w.g_bound = a.g_bound;
+        if (a.K == 256 && a.N == 256) GM_TRY((launch_wgrad_split<2, 2>(w, s, np)));
+        else if (a.K == 128 && a.N == 256) GM_TRY((launch_wgrad_split<1, 2>(w, s, np)));
+        else if (a.K == 256 && a.N == 128) GM_TRY((launch_wgrad_split<2, 1>(w, s, np)));
+        else GM_TRY((launch_wgrad_split<1, 1>(w, s, np)));
         launched = true;
     }
     if (fast_ok && !launched) {

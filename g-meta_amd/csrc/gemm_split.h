@@ -15,8 +15,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "gm_bound.h"
 
 typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gm_f16x8 __attribute__((ext_vector_type(8)));
 typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
 
 #define GS_BM 128
@@ -37,6 +39,16 @@ __device__ __forceinline__ GsTile gs_tile(const int32_t* tiles, int lt) {
     return GsTile{a, b, c};
 }
 
+// one dword through the scalar cache (same reason)
+__device__ __forceinline__ unsigned gs_sload(const void* q) {
+    const uint64_t p = (uint64_t)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+    const uint64_t sp = ((uint64_t)hi << 32) | lo;
+    unsigned a;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a) : "s"(sp) : "memory");
+    return a;
+}
+
 struct SplitGemmK {
     const float* A; int64_t lda;
     const uint16_t* Bt; int64_t bt_stride;     // split weights [set][3][K/8][N][8] bf16 (k_split_w), per-set stride in ELEMENTS (0 = shared)
@@ -50,6 +62,10 @@ struct SplitGemmK {
     // flagged GM_SPLIT_FUSE_SELF read their finished aggregate from zside (row stride ldz), rows without a source read zeros
     float* zero_out;                           // optional [rows, ldc]: the epilogue also zero-fills this buffer's tile (dQ of the backward pass that follows)
     const int4* f2; const float* zside; int64_t ldz; const float* zrow;     // zrow: >= K zero floats (rows flagged GM_SPLIT_FUSE_ZERO)
+    // two-piece fp16 operands (NP == 2): per-set magnitude bounds of the A rows and of the weights (gm_bound.h), from which both sides
+    // derive the same power-of-two scales (gs_scale_of);  amax_out[set * GM_BOUND_PAD] (NP == 2 kernels only): the epilogue records the largest |C| it stores
+    // (atomicMax on the bit pattern) -- the bound of whoever consumes C
+    gm_bound a_bound, b_bound; unsigned* amax_out;
 };
 #define GM_SPLIT_FUSE_SELF 0x40000000
 #define GM_SPLIT_FUSE_ZERO 0x20000000
@@ -74,11 +90,54 @@ __device__ __forceinline__ void gs_split4(const float4 v, uint2& h, uint2& m, ui
     l.x = __builtin_amdgcn_perm(xl[1], xl[0], 0x07060302u); l.y = __builtin_amdgcn_perm(xl[3], xl[2], 0x07060302u);
 }
 
+// Two-piece fp16 split (NP == 2): with s a power of two such that |x| s <= 2^15,  x s = h + m + r,  h = fp16(x s) (11 significant bits,
+// round to nearest), m = fp16(x s - h) (the next 11 bits; the subtraction is exact), |r| <= max(2^-23 |x s|, 2^-25): fp16 keeps 2^-24
+// absolute (subnormals), i.e. 2^-39 of the bound.  a b ~= (a_h b_h + a_h b_m + a_m b_h) / (s_a s_b): the dropped terms are bounded by
+// ~2^-21.4 |a||b| -- three fp32 roundings' worth, against the K roundings of an fp32 dot product.
+__device__ __forceinline__ float gs_scale_of(float bound) {
+    // largest power of two s with bound * s <= 2^15, clamped to [2^-40, 2^40]; bound = 0 (or not finite) -> 1
+    const unsigned e = (__float_as_uint(bound) >> 23) & 0xffu;               // bound < 2^(e - 126)
+    if (e == 0u || e == 0xffu) return 1.f;
+    int se = 15 - ((int)e - 126);                                            // bound * 2^se < 2^15
+    se = se < -40 ? -40 : (se > 40 ? 40 : se);
+    return __uint_as_float((unsigned)(se + 127) << 23);
+}
+// the scale of a set under a recorded bound, through the scalar cache (wave-uniform); no bound -> 1
+__device__ __forceinline__ float gs_bound_scale(const gm_bound& b, int set) {
+    if (!b.amax) return 1.f;
+    const float gain = b.gain ? __uint_as_float(gs_sload(b.gain)) : 1.f;
+    return gs_scale_of(__uint_as_float(gs_sload(b.amax + (int64_t)set * b.stride)) * gain * b.hgain);
+}
+// the same from an ordinary (vector) load, for kernels that do not hand-count their vmcnt
+__device__ __forceinline__ float gs_bound_scale_v(const gm_bound& b, int set) {
+    if (!b.amax) return 1.f;
+    const float gain = b.gain ? b.gain[0] : 1.f;
+    return gs_scale_of(__uint_as_float(b.amax[(int64_t)set * b.stride]) * gain * b.hgain);
+}
+// slot = max(slot, bits) for bit patterns of non-negative floats.  Device-scope atomics on one address are executed one at a time at the
+// memory side (~0.2 us each on gfx950: a thousand of them were 0.25 ms of a reduction launch), so look first: the slot only grows, and a
+// stale look costs one redundant atomic.
+__device__ __forceinline__ void gs_note_max(unsigned* slot, unsigned bits) {
+    if (bits == 0u) return;
+    if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < bits) atomicMax(slot, bits);
+}
+__device__ __forceinline__ void gs_split4_f16(const float4 v, const float s, uint2& h, uint2& m) {
+    const float x[4] = {v.x * s, v.y * s, v.z * s, v.w * s};
+    _Float16 xh[4], xm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { xh[i] = (_Float16)x[i]; xm[i] = (_Float16)(x[i] - (float)xh[i]); }
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 h0 = {xh[0], xh[1]}, h1 = {xh[2], xh[3]}, m0 = {xm[0], xm[1]}, m1 = {xm[2], xm[3]};
+    h.x = __builtin_bit_cast(unsigned, h0); h.y = __builtin_bit_cast(unsigned, h1);
+    m.x = __builtin_bit_cast(unsigned, m0); m.y = __builtin_bit_cast(unsigned, m1);
+}
+
 // Weights -> split planes.  W_t = params + t*pstride + w_off.  trans = 0: the GEMM's B is W itself, W stored [K][N]
 // (forward, B[k][n] = W[k][n]); trans = 1: B = W^T with W stored [N][K] (dZ = dQ W^T), i.e. Bt[n][k] = W[n][k] as stored.
 // Output Bt[t][p][k/8][n][8] (bf16 bits; K % 8 == 0), p = 0 h, 1 m, 2 l: the 8 k of one MFMA operand lane are contiguous and
 // 64 consecutive n of one k-octet form a contiguous 1-KiB DMA piece.  grid (ceil(K/32), ceil(N/32), sets), block 256.
-__global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, uint16_t* Bt) {
+// np = 2: two fp16 planes of W * s, s = the scale under `bound` (the bound recorded for this set's weights); the per-set stride stays 3 planes.
+__global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, uint16_t* Bt, int np, gm_bound bound) {
     __shared__ float tile[32][33];
     const int t = blockIdx.z, k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
     const float* W = params + (int64_t)t * pstride + w_off;
@@ -91,10 +150,19 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
     }
     __syncthreads();
     uint16_t* O = Bt + (int64_t)t * 3 * N * K;
+    const float sb = np == 2 ? gs_bound_scale_v(bound, t) : 1.f;
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
         if (n >= N || k >= K) continue;
         const float x = tile[tx][r];
+        if (np == 2) {
+            const int64_t plane = (int64_t)N * K, at = ((int64_t)(k >> 3) * N + n) * 8 + (k & 7);
+            const float xs = x * sb;
+            const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
+            O[at] = __builtin_bit_cast(uint16_t, h);
+            O[plane + at] = __builtin_bit_cast(uint16_t, m);
+            continue;
+        }
         const uint32_t b = __float_as_uint(x), bh = b & 0xffff0000u;
         const float r1 = x - __uint_as_float(bh);
         const uint32_t bm = __float_as_uint(r1) & 0xffff0000u;
@@ -106,6 +174,16 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
     }
 }
 
+
+// out[t * out_stride] = max(out[..], max |x[t * stride + off + i]|, i < n) as fp32 bit patterns (zero the slots first).  grid (blocks, sets).
+__global__ __launch_bounds__(256) void k_amax(const float* x, int64_t stride, int64_t off, int64_t n, unsigned* out, int64_t out_stride) {
+    const float* p = x + (int64_t)blockIdx.y * stride + off;
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) gs_note_max(out + (int64_t)blockIdx.y * out_stride, __float_as_uint(m));
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 or 128 (one 128 x N tile per step, 16-k chunks):
@@ -121,7 +199,8 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
 #ifndef PF_DA
 #define PF_DA 4
 #endif
-template <bool GATHER, int MI, int WC = 4>
+//   NP = 3: three bf16 pieces per operand, six products (exact);  NP = 2: two fp16 pieces under per-set power-of-two scales, three products
+template <bool GATHER, int MI, int WC = 4, int NP = 3>
 __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     // The eight compute waves form a (8 / WC) x WC grid of (32 MI) x 64 blocks: N = 64 WC columns, tile height BM = 32 MI (8 / WC).
     //   <., 2, 4>  N = 256, 128-row tiles (each compute wave a 64 x 64 block)
@@ -134,12 +213,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     // LDS: two A stages (12 KiB each), NB = 3 B stages (24 KiB each: the weight planes are DMA-ed TWO chunks ahead -- in the meta-step the
     // part runs this kernel at ~2 GHz, where one chunk of MFMAs (1536 cycles) no longer covers the issue cost of six DMA pieces plus an L2
     // round trip, and every chunk's barrier waited for the B feeders), epilogue staging of 16 rows x 64 columns per compute wave
-    constexpr int A_ST = 3 * A_PLANE, B_ST = 3 * B_PLANE, NB = 3;
+    constexpr int A_ST = NP * A_PLANE, B_ST = NP * B_PLANE, NB = 3;
+    static_assert(NP == 2 || NP == 3, "pieces per operand");
     constexpr int OFF_B = 2 * A_ST;
     constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
     constexpr int OFF_E = OFF_B + NB * B_ST, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
     constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
-    constexpr int B_PPW = (3 * 2 * (BN / 64)) / 4;                                    // DMA pieces per B-feeder wave and chunk: 6 (N = 256) / 3
+    constexpr int B_PPW = (NP * 2 * (BN / 64)) / 4;                                   // DMA pieces per B-feeder wave and chunk: 6 (N = 256) / 3
     __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = g.K / BK;
@@ -152,6 +232,15 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int lt = logical(w);
         if constexpr (SPLIT == 1) return gs_tile(g.tiles, lt);
         else { GsTile t = gs_tile(g.tiles, lt >> 1); const int h = (lt & 1) * 64; t.row0 += h; t.nrows = max(0, min(64, t.nrows - h)); return t; }
+    };
+    // NP == 2: the power-of-two operand scales of a set, from the recorded bounds (scalar loads)
+    auto a_scale_of = [&](int set) -> float {
+        if constexpr (NP == 3) return 1.f;
+        else return gs_bound_scale(g.a_bound, set);
+    };
+    auto b_scale_of = [&](int set) -> float {
+        if constexpr (NP == 3) return 1.f;
+        else return gs_bound_scale(g.b_bound, set);
     };
     const int total = ntb * nchunks;                                                  // flattened chunk count
     const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)smem);
@@ -231,6 +320,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
         for (int p = 0; p < A_PER; ++p) { w_next[p][0] = w_cur[p][0] = 1.f; w_next[p][1] = w_cur[p][1] = 0.f; fq[p] = i4v{0, 0, 0, 0}; }
         float rc_sc = 1.f, rc_b = 0.f;
+        float as_next = 1.f, as_cur = 1.f, inv_next = 1.f, inv_cur = 1.f;             // NP == 2: A scale of the tile being loaded / stored; 1 / (s_a s_b) for the epilogue
         auto fq_prefetch = [&](int ti) {                                              // table entries of tile ti (if any) -> fq, counted loads
             if (ti >= ntb) return;
             const GsTile t = tile_of(b + ti * G);
@@ -242,6 +332,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         };
         auto la_tile = [&](int ti, bool consts) {
             const GsTile t = tile_of(b + ti * G);
+            if constexpr (NP == 2) { as_next = a_scale_of(t.set); inv_next = (1.f / as_next) * (1.f / b_scale_of(t.set)); }
             if constexpr (GATHER) {
                 if constexpr (A_PER == 2) asm volatile("" : "+v"(fq[0]), "+v"(fq[A_PER - 1]) :: "memory");   // fetched a tile ago; every wait since then covered them
                 else asm volatile("" : "+v"(fq[0]) :: "memory");
@@ -271,6 +362,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             else asm volatile("s_waitcnt vmcnt(0)" : "+v"(fq[0]) :: "memory");
         }
         la_tile(0, false);
+        as_cur = as_next; inv_cur = inv_next;
         if constexpr (GATHER) {
 #pragma unroll
             for (int p = 0; p < A_PER; ++p) { w_cur[p][0] = w_next[p][0]; w_cur[p][1] = w_next[p][1]; }
@@ -290,6 +382,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         auto store_a = [&](int gc, int slot) {
             if (sa_c == nchunks) {
                 sa_c = 0; ++sa_ti;
+                as_cur = as_next; inv_cur = inv_next;
                 if constexpr (GATHER) {                                                // the loads of this tile were issued with w_next's table entries
 #pragma unroll
                     for (int p = 0; p < A_PER; ++p) { w_cur[p][0] = w_next[p][0]; w_cur[p][1] = w_next[p][1]; }
@@ -297,7 +390,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             }
             if (sa_c == 0 && sa_ti > 0 && fast_consts) {                               // first chunk of a later tile: its consts arrived with (before) this chunk's loads
                 asm volatile("" : "+v"(rc_sc), "+v"(rc_b) :: "memory");
-                if (ft < BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc;
+                if (ft < BM) scales[(sa_ti & 1) * GS_BM + ft] = rc_sc * inv_cur;
                 if (ft < BN) biasl[(sa_ti & 1) * BN + ft] = rc_b;
             }
             ++sa_c;
@@ -312,10 +405,16 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     v.x = __fmaf_rn(v1.x, w1, __fmaf_rn(v.x, w0, 0.f)); v.y = __fmaf_rn(v1.y, w1, __fmaf_rn(v.y, w0, 0.f));
                     v.z = __fmaf_rn(v1.z, w1, __fmaf_rn(v.z, w0, 0.f)); v.w = __fmaf_rn(v1.w, w1, __fmaf_rn(v.w, w0, 0.f));
                 }
-                gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
-                *reinterpret_cast<uint2*>(As + adst[p]) = h;
-                *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
-                *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+                if constexpr (NP == 3) {
+                    gs_split4(make_float4(v.x, v.y, v.z, v.w), h, m, l);
+                    *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                    *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                    *reinterpret_cast<uint2*>(As + 2 * A_PLANE + adst[p]) = l;
+                } else {
+                    gs_split4_f16(make_float4(v.x, v.y, v.z, v.w), as_cur, h, m);
+                    *reinterpret_cast<uint2*>(As + adst[p]) = h;
+                    *reinterpret_cast<uint2*>(As + A_PLANE + adst[p]) = m;
+                }
             }
         };
         // row scales + bias of tile ti -> LDS (parity ti & 1); ordinary loads, completed with the vmcnt(0) below
@@ -326,6 +425,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             if (g.row_scale) sc = g.row_scale[row0 + min(ft & (BM - 1), nrows - 1)];
             float b0 = 0.f;
             if (g.bias) b0 = (g.bias + (int64_t)set * g.bias_stride)[min(ft, BN - 1)];
+            if constexpr (NP == 2) sc *= (1.f / a_scale_of(set)) * (1.f / b_scale_of(set));
             if (ft < BM) scales[(ti & 1) * GS_BM + ft] = sc;
             if (ft < BN) biasl[(ti & 1) * BN + ft] = b0;
         };
@@ -377,6 +477,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
         int gc = 0;
+        float vmax = 0.f; int vmax_set = -1;                      // amax_out: running bound of this wave's blocks, flushed when the set changes
+        auto vmax_flush = [&]() {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0) gs_note_max(g.amax_out + (int64_t)vmax_set * GM_BOUND_PAD, __float_as_uint(vmax));
+            vmax = 0.f;
+        };
         for (int ti = 0; ti < ntb; ++ti) {
             gm_f32x16 acc[MI][2];
 #pragma unroll
@@ -389,20 +496,37 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 const char* S = smem + (gc & 1) * A_ST;
                 const char* SB = smem + b_st * B_ST;
                 b_st = b_st + 1 == NB ? 0 : b_st + 1;
-                gm_bf16x8 af[MI][3], bf[2][3];
+                if constexpr (NP == 3) {
+                    gm_bf16x8 af[MI][3], bf[2][3];
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
+                        for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const gm_bf16x8*>(S + a_lane + p * A_PLANE + i * 512);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(SB + b_lane + p * B_PLANE + j * 512);
+                        for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const gm_bf16x8*>(SB + b_lane + p * B_PLANE + j * 512);
 #define PF_PROD(PA, PB)                                                                                                  \
-                _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)              \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
-                PF_PROD(2, 0) PF_PROD(0, 2) PF_PROD(1, 1) PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)
+                    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+                    PF_PROD(2, 0) PF_PROD(0, 2) PF_PROD(1, 1) PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)
 #undef PF_PROD
+                } else {
+                    gm_f16x8 af[MI][2], bf[2][2];
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) af[i][p] = *reinterpret_cast<const gm_f16x8*>(S + a_lane + p * A_PLANE + i * 512);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) bf[j][p] = *reinterpret_cast<const gm_f16x8*>(SB + b_lane + p * B_PLANE + j * 512);
+#define PF_PROD(PA, PB)                                                                                                  \
+                    _Pragma("unroll") for (int i = 0; i < MI; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)          \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i][PA], bf[j][PB], acc[i][j], 0, 0, 0);
+                    PF_PROD(1, 0) PF_PROD(0, 1) PF_PROD(0, 0)                       // smallest terms first
+#undef PF_PROD
+                }
                 GS_BARRIER();
             }
             // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
@@ -411,6 +535,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             const float* sc_t = scales + (ti & 1) * GS_BM;
             const int col = wc * 64 + ec;
             const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
+            if constexpr (NP == 2) { if (g.amax_out && tl.set != vmax_set) { if (vmax_set >= 0) vmax_flush(); vmax_set = tl.set; } }
 #pragma unroll
             for (int ih = 0; ih < 2 * MI; ++ih) {                  // 16 rows of the wave's block at a time: accumulator registers e with (e >> 3) == ih & 1
                 const int i = ih >> 1, h = ih & 1;
@@ -428,6 +553,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
                     v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
                     if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                    if constexpr (NP == 2) { if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
                     if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
                     if (g.nt_store) {
                         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -446,6 +572,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
+        if constexpr (NP == 2) { if (g.amax_out && vmax_set >= 0) vmax_flush(); }     // (bit patterns of non-negative floats order as integers)
     }
 }
 

@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libgmeta_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "gm_bound.h"
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +49,7 @@ struct gm_store {
     int64_t* d_out_ptr = nullptr;    // by-source CSR of the same edges (for the transposed induce)
     int32_t* d_out_idx = nullptr;    // destination node, LOCAL to its graph
     float* d_feat = nullptr;         // [total_nodes, feat_ld]
+    unsigned* d_feat_amax = nullptr; // [1] bit pattern of max |feature| (gm_bound.h: the bound of every layer-1 operand)
 };
 
 // Receptive-field tables (cone.hip): level l = rows whose layer-l activation reaches a centre.
@@ -116,6 +118,9 @@ struct gm_batch {
     // per-edge tables (gm_batch_finalize): the source's norm for both CSR orientations (enorm[o][e] = norm[indices_o[e]]) and the source's
     // feature row (efeat[e] = feat_row[indices[e]]): what the aggregate would otherwise fetch with a dependent 4-byte gather per edge
     float* d_enorm[2] = {nullptr, nullptr}; int32_t* d_efeat = nullptr;
+    // row gains of the two aggregates (gm_bound.h): |out| <= gain * max |in| -- [0] forward: max_i sum_{u->i} norm[u]; [1] transposed with the
+    // destination's norm on the output (the backward of an aggregate-first layer): max_i norm[i] * outdeg(i)
+    float* d_gain = nullptr;
     // fused aggregate + GEMM (forward passes nobody differentiates): per row {u0, u1, bits(w0), bits(w1)} -- the row's one or two sources
     // (batch rows in d_fuse2, feature rows in d_fuse2_feat) and their norms; rows without a source carry {GM_FUSE_ZERO, same, 1, 0}, rows of any other degree {row | GM_FUSE_SELF, same, 1, 0}:
     // their aggregate is written by the ordinary kernel (gm_agg_args::skip_lo/hi) and picked up as is
@@ -151,6 +156,7 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
 };
@@ -260,6 +266,9 @@ struct gm_gemm_args {
     // with Bsplit: fused aggregate + GEMM.  fuse2 = gm_batch::d_fuse2 / d_fuse2_feat; A / lda then address the aggregate's INPUT rows
     // (previous layer's output or the feature table) and rows the table flags GM_FUSE_SELF read their finished aggregate from zside
     const void* fuse2; const float* zside; int64_t ldz;
+    // split kernel with two fp16 pieces per operand (np = 2; 0 / 3 = three bf16 pieces): Bsplit then holds fp16 planes made under b_bound, and
+    // a_bound bounds the A rows (gm_bound.h).  amax_out (np = 2 only): per-set slots that receive the largest |C| stored (atomicMax on zeroed slots)
+    int np; gm_bound a_bound, b_bound; unsigned* amax_out;
     float* zero_out;                    // also zero-fill this [rows, ldc] buffer (dQ of the backward pass that follows): in the epilogue of the split / DMA kernels, a memset on the other paths
     const int32_t* tiles;               // device [n_tiles*3]: set, row0, nrows  (nrows <= BM)
     int n_tiles;
@@ -271,7 +280,12 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
 // gm_gemm_mode(): 0 = exact-fp32 MFMA kernels only, 1 = split-bf16 kernel where eligible (env GM_GEMM_MODE=f32|split, gm_set_gemm_mode).
 int gm_gemm_mode();
 bool gm_gemm_split_ok(int n_tiles, int K, int N);
-int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s);
+// np = 3: three bf16 planes; np = 2: two fp16 planes under `bound` (per-set stride 3 planes either way)
+int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K, int N, int trans, int sets, uint16_t* out, hipStream_t s, int np = 3,
+                     gm_bound bound = gm_no_bound());
+// out[t * out_stride] = max(out[...], max_i |x[t * stride + off + i]|), i < n, as fp32 bit patterns (the slots must have been zeroed)
+int gm_amax(const float* x, int64_t stride, int64_t off, int64_t n, int sets, unsigned* out, int64_t out_stride, hipStream_t s);
+int gm_split_np();                      // pieces per operand of the split kernels where bounds are available: 2 (fp16, default) or 3 (bf16); env GM_SPLIT_PIECES
 
 // Grouped transposed-A GEMM for weight gradients:
 //   dW_t[K,N] = sum_{rows of set t} a_scale[row] * A[row,:]^T  G[row,:]   and   db_t[N] = sum G[row,:]
@@ -296,6 +310,9 @@ struct gm_wgrad_args {
     // optional fused inner-loop SGD (meta.py:126,151): next_t[off + j] = cur_t[off + j] - lr * grad, written together with the gradient
     const float* sgd_cur; int64_t sgd_cur_stride; float* sgd_next; int64_t sgd_next_stride; float sgd_lr;
     int64_t w_off, b_off;               // offsets of this layer's W and b inside a parameter vector
+    // two fp16 pieces per operand (np = 2) in the split weight-gradient kernel: bounds of A and G.  With planes: pl_np = 2 writes fp16 planes
+    // under pl_bound
+    int np; gm_bound a_bound, g_bound; int pl_np; gm_bound pl_bound;
     uint16_t* pl_fwd; uint16_t* pl_dz;  // optional (with sgd_next): the updated W also written as split-bf16 planes for the NEXT step's GEMMs
                                         // ([set][3][K/8][N][8] for X @ W, [set][3][N/8][K][8] for dQ @ W^T; gemm_split.h layouts): no k_split_w launches
     float* wt_next;                     // optional (with sgd_next): the updated W also written transposed, [set][N][K] -- what the NEXT
@@ -344,7 +361,9 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_AGG_STRICT 3   // work-only shadow of GM_PROF_AGG: compulsory HBM bytes (a layer-1 gather reads at most the feature table)
 #define GM_PROF_GEMM_SPLIT 4   // grouped GEMM launches that ran on the split-bf16 kernel (6 bf16 MFMA flops per fp32 flop; work = fp32 flops)
 #define GM_PROF_WGRAD_SPLIT 5  // weight gradients on the split-bf16 kernel
-#define GM_PROF_CATS 6
+#define GM_PROF_GEMM_SPLIT16 6 // grouped GEMMs on the two-piece fp16 split kernel (3 fp16 MFMA flops per fp32 flop)
+#define GM_PROF_WGRAD_SPLIT16 7
+#define GM_PROF_CATS 8
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
 void gm_prof_reset();

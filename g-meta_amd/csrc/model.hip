@@ -21,6 +21,7 @@ struct HeadK {
     const int32_t* sub_off; const int32_t* centre; int nc; const int32_t* sub_set; const int32_t* set_sub_off;
     const float* params; int64_t pstride; int64_t wl_off, bl_off; int hc, C; int subs;
     int compact;                                    // 1: H holds only the centre rows, [subs*nc, Hd] in centre order (cone schedule)
+    unsigned* dq_amax;                              // optional [sets * GM_BOUND_PAD] (zeroed): receives max |dQ| written for the set (gm_bound.h)
 };
 
 __device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) {
@@ -82,6 +83,7 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
         if (u.next) u.next[(int64_t)set * u.next_stride + k.bl_off + c] = u.cur[(int64_t)set * u.cur_stride + k.bl_off + c] - u.lr * acc;
     }
     // one thread per (subgraph, column); both centres of a pair stay in one thread (they may share a row)
+    float dq_max = 0.f;
     for (int id = tid; id < (s1 - s0) * k.Hd; id += NT) {
         const int s = s0 + id / k.Hd, col = id % k.Hd;
         float vv[2] = {0.f, 0.f};
@@ -98,10 +100,16 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
             const int64_t r0 = crow_s ? crow_s[(s - s0) * k.nc] : centre_row(k, s, 0);
             if (k.nc == 2) {
                 const int64_t r1 = crow_s ? crow_s[(s - s0) * k.nc + 1] : centre_row(k, s, 1);
-                if (r1 == r0) vv[0] = vv[0] + vv[1]; else dQ[r1 * k.ldh + col] = vv[1];
+                if (r1 == r0) vv[0] = vv[0] + vv[1]; else { dQ[r1 * k.ldh + col] = vv[1]; dq_max = fmaxf(dq_max, fabsf(vv[1])); }
             }
             dQ[r0 * k.ldh + col] = vv[0];
+            dq_max = fmaxf(dq_max, fabsf(vv[0]));
         }
+    }
+    if (k.dq_amax && !Gc) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dq_max = fmaxf(dq_max, __shfl_xor(dq_max, o));
+        if ((tid & 63) == 0 && dq_max > 0.f) atomicMax(k.dq_amax + (int64_t)set * GM_BOUND_PAD, __float_as_uint(dq_max));      // (a handful per set)
     }
 }
 __global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ, float* Gc) {
@@ -375,6 +383,7 @@ struct Carver {
 // Split-bf16 operand planes of the fast weights fw_1..fw_K, written by the weight-gradient reduction that produces each vector
 // (gm_wgrad_args::pl_fwd / pl_dz) and looked up by the GEMMs that consume it -- on either stream; the vector's own ready event
 // orders them.  One slot per (k, layer, orientation); theta (shared by all tasks) is split on the fly: one set, one tiny launch.
+#define GM_W_HEADROOM 1024.f
 struct PlaneDir {
     const float* fw0 = nullptr; int64_t TP = 0; int K = 0;                  // fw_k = fw0 + (k-1) * TP, k = 1..K
     uint16_t* base = nullptr; int64_t per_k = 0;                            // planes of fw_k at base + (k-1) * per_k
@@ -389,6 +398,16 @@ struct PlaneDir {
     }
     uint16_t* slot(int k, int l, int o) const { return (k && off[l][o] >= 0) ? base + (int64_t)(k - 1) * per_k + off[l][o] : nullptr; }
     uint16_t* lookup(const float* params, int l, int o) const { const int k = index_of(params); return (k && off[l][o] >= 0 && valid[k][l][o]) ? slot(k, l, o) : nullptr; }
+    // Weight bound for the two-piece fp16 planes (gm_bound.h): wam[l * GM_BOUND_PAD] = bit pattern of max |W_l| of THETA, taken once per
+    // meta-step; every weight vector of the step (theta and the fast weights fw_1..fw_K of every task) is split under GM_W_HEADROOM x that
+    // bound -- the planes of fw_k are written by the reduction that produces fw_k, before its own maximum could be known.  A weight that
+    // outgrows theta's largest by that factor inside one inner loop turns into inf / NaN losses, which the caller sees.
+    unsigned* wam = nullptr; const float* theta = nullptr;
+    bool w_bound(const float* params, int l, gm_bound& bd) const {
+        if (!wam || !(index_of(params) || params == theta)) return false;
+        bd.amax = wam + (int64_t)l * GM_BOUND_PAD; bd.stride = 0; bd.gain = nullptr; bd.hgain = GM_W_HEADROOM;
+        return true;
+    }
 };
 
 struct GcnCtx {
@@ -407,7 +426,54 @@ struct GcnCtx {
     int zw[GM_MAX_GCN];
     const gm_cone* cone;       // non-NULL: receptive-field schedule, every buffer is compact (gm_hparams_t.cone)
     SgdK sgd;                  // next != NULL: the backward also writes the SGD-updated parameters (inner loop)
+    // Two-piece fp16 split kernels (np == 2, gm_meta_step's dense schedule; gm_bound.h): per-pass slots am[pass][2 Lg + 1][sets] (zeroed once per
+    // meta-step) receive the per-set maxima of H_l (forward GEMM epilogues), T_l (dZ GEMM epilogues) and dQ_L (head backward); hv / tv / dqv:
+    // recorded in the current pass.  A launch whose bounds are not all there runs the three-piece bf16 kernels.
+    int np = 3; unsigned* am = nullptr; int am_passes = 0, am_pass = -1;
+    bool hv[GM_MAX_GCN] = {}, tv[GM_MAX_GCN] = {}; bool dqv = false;
+    unsigned* am_slot(int i) const { return am + ((int64_t)am_pass * (2 * L.n_gcn + 1) + i) * b->sets * GM_BOUND_PAD; }
+    unsigned* amH(int l) const { return am_slot(l); }
+    unsigned* amT(int l) const { return am_slot(L.n_gcn + l); }
+    unsigned* amdQ() const { return am_slot(2 * L.n_gcn); }
 };
+// bound of Z_l, the aggregate of layer l's input (features or H_{l-1}): the A operand of the forward GEMM and of the weight gradient
+static bool in_bound(const GcnCtx& c, int l, gm_bound& bd) {
+    if (c.np != 2 || c.am_pass < 0 || !c.b->d_gain) return false;
+    if (l == 0) {
+        if (c.x0_user || !c.b->store->d_feat_amax) return false;
+        bd.amax = c.b->store->d_feat_amax; bd.stride = 0;
+    } else {
+        if (!c.hv[l - 1]) return false;
+        bd.amax = c.amH(l - 1); bd.stride = GM_BOUND_PAD;
+    }
+    bd.gain = c.b->d_gain; bd.hgain = 1.f;
+    return true;
+}
+// bound of dQ_l (the gradient at layer l's output): from the head for the last layer, else relu' * norm * A^T T_{l+1}
+static bool dq_bound(const GcnCtx& c, int l, gm_bound& bd) {
+    if (c.np != 2 || c.am_pass < 0 || !c.b->d_gain) return false;
+    if (l == c.L.n_gcn - 1) { if (!c.dqv) return false; bd.amax = c.amdQ(); bd.gain = nullptr; }
+    else { if (!c.tv[l + 1]) return false; bd.amax = c.amT(l + 1); bd.gain = c.b->d_gain + 1; }
+    bd.stride = GM_BOUND_PAD; bd.hgain = 1.f;
+    return true;
+}
+// The weight planes of a split GEMM of layer l (o = 0: X @ W, 1: dQ @ W^T) and their bound: the planes a reduction left for `params`, else
+// split now into c.Wsplit.  want16: the launch has its A bound and would take two-piece planes.  *np = the pieces (2 / 3) of *pl.
+static int weight_planes(GcnCtx& c, const float* params, int64_t pstride, int l, int o, int K, int N, bool want16, hipStream_t st, const uint16_t** pl, gm_bound* bb, int* np) {
+    const gm_layout& L = c.L;
+    uint16_t* have = (c.pd && pstride) ? c.pd->lookup(params, l, o) : nullptr;
+    *bb = gm_no_bound();
+    if (have && c.np == 2) {                                               // stored planes are two-piece in this context
+        if (want16 && c.pd->w_bound(params, l, *bb)) { *pl = have; *np = 2; return GM_OK; }
+        have = nullptr;
+    }
+    if (have) { *pl = have; *np = 3; return GM_OK; }
+    const bool f16 = want16 && c.pd && c.pd->w_bound(params, l, *bb);
+    if (!f16) *bb = gm_no_bound();
+    GM_TRY(gm_split_weights(params, pstride, L.w_off[l], K, N, o, pstride ? c.b->sets : 1, c.Wsplit, st, f16 ? 2 : 3, *bb));
+    *pl = c.Wsplit; *np = f16 ? 2 : 3;
+    return GM_OK;
+}
 
 static void wgrad_sgd(gm_wgrad_args& w, const GcnCtx& c, int l) {
     w.sgd_cur = c.sgd.cur; w.sgd_cur_stride = c.sgd.cur_stride; w.sgd_next = c.sgd.next; w.sgd_next_stride = c.sgd.next_stride; w.sgd_lr = c.sgd.lr;
@@ -472,6 +538,7 @@ static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
     k.sub_off = b->d_sub_off; k.centre = c.centre ? c.centre : b->d_centre; k.nc = b->centres; k.sub_set = b->d_sub_set;
     k.set_sub_off = b->d_set_sub_off; k.params = params; k.pstride = pstride; k.wl_off = L.wl_off; k.bl_off = L.bl_off;
     k.hc = L.hc; k.C = L.n_out; k.subs = b->subs; k.compact = c.cone ? 1 : 0;
+    k.dq_amax = (c.np == 2 && c.am_pass >= 0) ? c.amdQ() : nullptr;
     return k;
 }
 
@@ -494,6 +561,12 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
     GM_REQUIRE(L.dims[0] == b->store->feat_dim || L.dims[0] == b->store->feat_ld || c.x0_user, GM_EINVAL, "forward: dims[0]=%d but the store has %d features", L.dims[0], b->store->feat_dim);
     GM_REQUIRE((L.link != 0) == (b->centres == 2), GM_EINVAL, "forward: link_pred model needs a 2-centre batch and vice versa");
     const float* xin = c.x0_user;           // NULL = gather rows of the store through feat_row
+    if (c.np == 2) {                        // a new pass: its own bound slots
+        ++c.am_pass;
+        GM_REQUIRE(c.am_pass < c.am_passes, GM_EINVAL, "forward: more passes than bound slots (%d)", c.am_passes);
+        for (int l = 0; l < GM_MAX_GCN; ++l) c.hv[l] = c.tv[l] = false;
+        c.dqv = false;
+    }
     for (int l = 0; l < L.n_gcn; ++l) {
         const int fi = L.dims[l], fo = L.dims[l + 1];
         const bool gather = (l == 0 && !c.x0_user);
@@ -546,9 +619,14 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             g.relu_bits = fwd_only == 1 ? nullptr : c.M[l];
             if (split_ok) {
-                uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 0) : nullptr;      // left by the reduction that wrote these weights
-                if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fi, fo, 0, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
+                gm_bound ab = gm_no_bound(), bb;
+                const bool want16 = in_bound(c, l, ab);
+                const uint16_t* pl = nullptr;                                                 // left by the reduction that wrote these weights, else split now
+                int np = 3;
+                GM_TRY(weight_planes(c, params, pstride, l, 0, fi, fo, want16, st, &pl, &bb, &np));
                 g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+                g.np = np; g.a_bound = ab; g.b_bound = bb;
+                if (np == 2) { g.amax_out = c.amH(l); c.hv[l] = true; }        // (the two-piece kernels record it)
             }
             // fwd_only == 2: the head + loss + backward follow (gm_meta_step): the last layer's GEMM zero-fills dQ on its way out instead of a memset launch
             if (fwd_only == 2 && l == L.n_gcn - 1 && fo == L.dims[L.n_gcn]) { g.zero_out = c.bufA; c.dq_zeroed = 1; }
@@ -585,6 +663,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         HeadK k = make_head(c, params, pstride);
         hipLaunchKernelGGL(k_head_bwd, dim3(b->sets), dim3(256), 0, st, k, dlogits, dparams, dstride, dQ, (float*)nullptr);
         GM_HIP(hipGetLastError());
+        if (k.dq_amax) c.dqv = true;
     }
     for (int l = Lg - 1; l >= 0; --l) {
         const int fi = L.dims[l], fo = L.dims[l + 1];
@@ -626,9 +705,13 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
                 const bool use_wt = !use_split && dz_glds && c.WTl[l] && fi % 64 == 0 && fo % 16 == 0;
                 if (use_split) {
                     // B = W^T with W stored [fi][fo]: the planes are W's own rows (no transpose), K = fo, N = fi
-                    uint16_t* pl = (c.pd && pstride) ? c.pd->lookup(params, l, 1) : nullptr;
-                    if (!pl) { GM_TRY(gm_split_weights(params, pstride, L.w_off[l], fo, fi, 1, pstride ? b->sets : 1, c.Wsplit, st)); pl = c.Wsplit; }
+                    gm_bound ab = gm_no_bound(), bb;
+                    const bool want16 = dq_bound(c, l, ab);
+                    const uint16_t* pl = nullptr; int np = 3;
+                    GM_TRY(weight_planes(c, params, pstride, l, 1, fo, fi, want16, st, &pl, &bb, &np));
                     g.Bsplit = pl; g.bsplit_stride = pstride ? (int64_t)3 * fi * fo : 0;
+                    g.np = np; g.a_bound = ab; g.b_bound = bb;
+                    if (np == 2) { g.amax_out = c.amT(l); c.tv[l] = true; }
                     g.B = params + L.w_off[l]; g.b_stride = pstride; g.transB = 1;
                 } else if (use_wt) {
                     // dZ = dQ @ W^T through the direct-to-LDS kernel on transposed weights: left there by the previous step's
@@ -646,6 +729,13 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             }
             int kn = 0;
             if (c.pd && c.sgd.next && (kn = c.pd->index_of(c.sgd.next)) != 0) { w.pl_fwd = c.pd->slot(kn, l, 0); w.pl_dz = c.pd->slot(kn, l, 1); }
+            if (c.np == 2) {
+                gm_bound ab, gb;
+                if (in_bound(c, l, ab) && dq_bound(c, l, gb)) { w.np = 2; w.a_bound = ab; w.g_bound = gb; }
+                if (kn) {                                                  // two-piece planes of the updated weights, under the step's weight bound
+                    if (c.pd->w_bound(c.sgd.next, l, w.pl_bound)) w.pl_np = 2; else { w.pl_fwd = nullptr; w.pl_dz = nullptr; }
+                }
+            }
             GM_TRY(gm_launch_wgrad(w, st));
             if (kn) { c.pd->valid[kn][l][0] = w.pl_fwd != nullptr; c.pd->valid[kn][l][1] = w.pl_dz != nullptr; }
             if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
@@ -963,6 +1053,7 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
                        bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f}, stage_h, (int)(proto_bytes / sizeof(float)));
     GM_HIP(hipGetLastError());
+    if (bwd && dQ && hk.dq_amax) c.dqv = true;
     return GM_OK;
 }
 
@@ -1066,6 +1157,7 @@ struct MetaPlan {
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
     int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q]
     int Ct, ns, nq;
+    unsigned* bound_ws; int64_t bound_words;      // gm_bound.h slots of this step ([S passes | Q passes | weights]), zeroed by ONE memset; NULL: three-piece kernels
 };
 
 static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, const gm_model_t* m, const gm_hparams_t* hp, void* ws, int64_t ws_bytes,
@@ -1112,6 +1204,20 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
             p.pd.base = cv.take<uint16_t>(per_k * p.K); p.pd.per_k = per_k; p.pd.fw0 = p.fw; p.pd.TP = TP; p.pd.K = p.K;
             if (!p.pd.base) p.pd.base = reinterpret_cast<uint16_t*>(1);      // sizing pass (no workspace yet): keep the layout decisions identical
         }
+    }
+    // two-piece fp16 split kernels: when the weight planes are kept, every GCN layer is aggregate-first and the dense schedule runs
+    p.bound_ws = nullptr; p.bound_words = 0;
+    bool agg_first = true;
+    for (int l = 0; l < p.L.n_gcn; ++l) agg_first = agg_first && p.L.dims[l] <= p.L.dims[l + 1];
+    if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->d_gain && qry->d_gain && spt->store->d_feat_amax) {
+        const int per_pass = 2 * p.L.n_gcn + 1;
+        const int64_t ws_s = (int64_t)p.K * per_pass * p.T * GM_BOUND_PAD, ws_q = (int64_t)K1 * per_pass * p.T * GM_BOUND_PAD, ws_w = (int64_t)p.L.n_gcn * GM_BOUND_PAD;
+        p.bound_words = ws_s + ws_q + ws_w;
+        p.bound_ws = cv.take<unsigned>(p.bound_words);
+        if (!p.bound_ws) p.bound_ws = reinterpret_cast<unsigned*>(16);       // sizing pass
+        p.S.np = p.Q.np = 2;
+        p.S.am = p.bound_ws; p.S.am_passes = p.K; p.Q.am = p.bound_ws + ws_s; p.Q.am_passes = K1;
+        p.pd.wam = p.bound_ws + ws_s + ws_q;
     }
     p.Ct = Ct; p.ns = ns; p.nq = nq;
     if (need) *need = cv.used + 256;
@@ -1177,6 +1283,12 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         memcpy(hp32 + spt->subs + qry->subs + 3 * (size_t)T, cq.tab.data(), 4 * cq.tab.size());
         GM_HIP(hipMemcpyAsync(p.rows_s, h, 4 * n_tab, hipMemcpyHostToDevice, st));
         GM_TRY(ring.release_after(slot, st));
+    }
+    if (p.bound_ws) {
+        // bound slots of this step: zero (the producers use atomicMax), then the maxima of theta's weight matrices (slot k = 0)
+        GM_HIP(hipMemsetAsync(p.bound_ws, 0, sizeof(unsigned) * p.bound_words, st));
+        p.pd.theta = theta;
+        for (int l = 0; l < L.n_gcn; ++l) GM_TRY(gm_amax(theta, 0, L.w_off[l], (int64_t)L.dims[l] * L.dims[l + 1], 1, p.pd.wam + (int64_t)l * GM_BOUND_PAD, 0, st));
     }
     gm_prof_reset();
     tm.lap("plan");
@@ -1289,18 +1401,30 @@ extern "C" int gm_dense_update(const gm_batch_t* b, const float* x, int32_t K, c
     gm_gemm_args g{};
     g.A = x; g.lda = K; g.B = W; g.b_stride = w_stride; g.C = out; g.ldc = N; g.K = K; g.N = N;
     g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
-    uint16_t* planes = nullptr;
-    const bool split = mode == 1 || (mode < 0 && gm_gemm_split_ok(b->n_tiles, K, N));
+    uint16_t* planes = nullptr; unsigned* slots = nullptr;
+    const bool split = mode == 1 || mode == 2 || (mode < 0 && gm_gemm_split_ok(b->n_tiles, K, N));
     if (split) {
-        GM_REQUIRE((N == 256 || N == 128) && K % 16 == 0 && K >= 32, GM_EINVAL, "dense_update: the split-bf16 kernel needs N = 128 or 256 and K a multiple of 16 (>= 32)");
+        GM_REQUIRE((N == 256 || N == 128) && K % 16 == 0 && K >= 32, GM_EINVAL, "dense_update: the split kernels need N = 128 or 256 and K a multiple of 16 (>= 32)");
         const int sets = w_stride ? b->sets : 1;
         GM_TRY(gm_alloc(&planes, (size_t)sets * 3 * K * N, st));
-        int rc = gm_split_weights(W, w_stride, 0, K, N, 0, sets, planes, st);
-        if (rc != GM_OK) { gm_dev_free(planes, st); return rc; }
+        int rc = GM_OK;
+        gm_bound wb = gm_no_bound();
+        if (mode == 2) {
+            // two fp16 pieces per operand: bounds taken here -- one for all of x (slot 0), one per weight matrix (slots 1..)
+            rc = gm_alloc(&slots, (size_t)(sets + 1) * GM_BOUND_PAD, st);
+            if (rc == GM_OK && hipMemsetAsync(slots, 0, sizeof(unsigned) * (sets + 1) * GM_BOUND_PAD, st) != hipSuccess) { gm_set_error("dense_update: memset failed"); rc = GM_EHIP; }
+            if (rc == GM_OK) rc = gm_amax(x, 0, 0, (int64_t)b->rows * K, 1, slots, 0, st);
+            if (rc == GM_OK) rc = gm_amax(W, w_stride, 0, (int64_t)K * N, sets, slots + GM_BOUND_PAD, GM_BOUND_PAD, st);
+            wb.amax = slots + GM_BOUND_PAD; wb.stride = w_stride ? GM_BOUND_PAD : 0;
+            g.np = 2; g.a_bound = gm_no_bound(); g.a_bound.amax = slots; g.b_bound = wb;
+        }
+        if (rc == GM_OK) rc = gm_split_weights(W, w_stride, 0, K, N, 0, sets, planes, st, mode == 2 ? 2 : 3, wb);
+        if (rc != GM_OK) { gm_dev_free(planes, st); if (slots) gm_dev_free(slots, st); return rc; }
         g.Bsplit = planes; g.bsplit_stride = w_stride ? (int64_t)3 * K * N : 0;
     }
     const int rc = gm_launch_gemm_nn(g, st);
     if (planes) gm_dev_free(planes, st);
+    if (slots) gm_dev_free(slots, st);
     gm_batch_mark_use(b, st);
     return rc;
 }

@@ -79,6 +79,10 @@ extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const i
             gm_set_error("gm_store_create: feature upload failed"); rc = GM_EHIP;
         }
     }
+    if (rc == GM_OK) rc = gm_dev_alloc((void**)&s->d_feat_amax, sizeof(unsigned), st);
+    if (rc == GM_OK && hipMemset(s->d_feat_amax, 0, sizeof(unsigned)) != hipSuccess) { gm_set_error("gm_store_create: memset failed"); rc = GM_EHIP; }
+    if (rc == GM_OK) rc = gm_amax(s->d_feat, 0, 0, (int64_t)s->total_nodes * s->feat_ld, 1, s->d_feat_amax, 0, st);
+    if (rc == GM_OK && hipStreamSynchronize(st) != hipSuccess) { gm_set_error("gm_store_create: feature bound failed"); rc = GM_EHIP; }
     if (rc != GM_OK) { gm_store_destroy(s); return rc; }
     *out = s;
     return GM_OK;
@@ -88,6 +92,6 @@ extern "C" void gm_store_destroy(gm_store_t* s) {
     if (!s) return;
     (void)hipDeviceSynchronize();
     gm_dev_free(s->d_node_off, nullptr); gm_dev_free(s->d_in_ptr, nullptr); gm_dev_free(s->d_in_idx, nullptr);
-    gm_dev_free(s->d_out_ptr, nullptr); gm_dev_free(s->d_out_idx, nullptr); gm_dev_free(s->d_feat, nullptr);
+    gm_dev_free(s->d_out_ptr, nullptr); gm_dev_free(s->d_out_idx, nullptr); gm_dev_free(s->d_feat, nullptr); gm_dev_free(s->d_feat_amax, nullptr);
     delete s;
 }

@@ -161,7 +161,8 @@ int gm_gcn_backward(const gm_batch_t* b, const gm_model_t* m, const float* param
 
 /* torch.matmul(feat, weight) of GraphConv.forward (learner.py:36,47) over the rows of a batch: out[rows, N] = x[rows, K] @ W_t with
  * W_t = W + set * w_stride ([K, N] row-major; w_stride = 0: one matrix for every set).  Exported for numerics tests of the GEMM kernels.
- * mode -1: what the library would pick (gm_set_gemm_mode + launch size), 0: exact-fp32 MFMA kernels, 1: split-bf16 kernel (N = 256). */
+ * mode -1: what the library would pick (gm_set_gemm_mode + launch size), 0: exact-fp32 MFMA kernels, 1: split-bf16 kernel (three pieces, N = 128 / 256),
+ * 2: split-fp16 kernel (two pieces; the bounds of x and of every W_t are taken by the call itself). */
 int gm_dense_update(const gm_batch_t* b, const float* x, int32_t K, const float* W, int64_t w_stride, int32_t N, float* out, int32_t mode,
                     void* stream);
 
@@ -203,9 +204,16 @@ int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float*
 /* Update-GEMM arithmetic.  mode 0: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere.  mode 1 (default): large N = 256 launches run
  * on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 pieces and the six products of weight >= 2^-16
  * accumulated in fp32 (dropped terms <= 1.2e-7 |a||b|: the result is within one fp32 rounding per product of the exact one;
- * measured error against fp64 <= the fmaf chain's).  Also settable with the environment variable GM_GEMM_MODE=f32|split. */
+ * measured error against fp64 <= the fmaf chain's).  Also settable with the environment variable GM_GEMM_MODE=f32|split.
+ * Inside gm_meta_step (dense schedule, aggregate-first layers) the split kernels take TWO fp16 pieces per operand instead -- three
+ * products a_h b_h + a_h b_m + a_m b_h under per-task power-of-two scales derived from magnitude bounds that the producing kernels
+ * record on the device (csrc/gm_bound.h): 22 significand bits per operand, dropped terms <= ~2^-21 |a||b| per product against the
+ * K roundings of 2^-24 |sum| an fp32 dot product of length K makes; measured error against fp64 below the fp32 fmaf chain's
+ * (tests/test_hip_gemm_numerics.py).  GM_SPLIT_PIECES=3 keeps the three-piece bf16 kernels everywhere; gm_get_split_pieces() = 2 or 3. */
 void gm_set_gemm_mode(int32_t mode);
 int32_t gm_get_gemm_mode(void);
+void gm_set_split_pieces(int32_t pieces);   /* 2, 3, or -1 = back to the environment variable */
+int32_t gm_get_split_pieces(void);
 
 /* Fused aggregate + update for forward passes nobody differentiates (the query evaluations of the inner steps in gm_meta_step,
  * i.e. meta.py:129-141,152-154 before the last step, and every query pass of finetunning): rows with one or two sources are
@@ -224,7 +232,8 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
  * priced at their COMPULSORY HBM bytes (a layer-1 launch that gathers from the store's feature table reads at most the
  * whole table, not rows*width; total_ms is 0 for this category -- use category 0's), 4 / 5 = the grouped GEMMs / weight
  * gradients that ran on the split-bf16 kernels (work = flops of the fp32 product; the kernels issue 6 bf16 MFMA flops per
- * fp32 flop) -- categories 1 / 2 then hold only the launches on the exact-fp32 MFMA kernels. */
+ * fp32 flop) -- categories 1 / 2 then hold only the launches on the exact-fp32 MFMA kernels; 6 / 7 = the grouped GEMMs / weight
+ * gradients on the two-piece fp16 split kernels (3 fp16 MFMA flops per fp32 flop). */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 
 #ifdef __cplusplus

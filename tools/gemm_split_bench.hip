@@ -33,7 +33,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dBt, (size_t)3 * N * K * 2)); CK(hipMalloc(&dT, tiles.size() * 4));
     CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dBias, bias.data(), N * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dT, tiles.data(), tiles.size() * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, 1), dim3(256), 0, 0, dW, 0, 0, K, N, 0, dBt);
+    hipLaunchKernelGGL(k_split_w, dim3((K + 31) / 32, (N + 31) / 32, 1), dim3(256), 0, 0, dW, 0, 0, K, N, 0, dBt, 3, gm_no_bound());
     SplitGemmK g{};
     g.A = dA; g.lda = K; g.Bt = dBt; g.bt_stride = 0; g.C = dC; g.ldc = N; g.K = K; g.N = N; g.bias = dBias; g.relu = 0;
     unsigned long long* dDbg; CK(hipMalloc(&dDbg, 3 * 64 * 4 * 8)); CK(hipMemset(dDbg, 0, 3 * 64 * 4 * 8)); g.dbg = dDbg;
