@@ -174,6 +174,7 @@ const gm_knobs& gm_knob() {
         k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
         k.wgrad_round_bias = env("GM_WGRAD_ROUND_BIAS", 25);
         k.split_pieces = env("GM_SPLIT_PIECES", 2);
+        k.split16_min_rows = env("GM_SPLIT16_MIN_ROWS", 65536);
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
     });
     return k;

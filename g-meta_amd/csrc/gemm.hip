@@ -514,6 +514,14 @@ int gm_amax(const float* x, int64_t stride, int64_t off, int64_t n, int sets, un
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
+int gm_amax_segs(const float* x, const int64_t* off, const int64_t* n, int segs, unsigned* out, int64_t out_stride, hipStream_t s) {
+    GM_REQUIRE(segs >= 1 && segs <= 8, GM_EINVAL, "amax_segs: 1..8 segments");
+    AmaxSegs sg{}; int64_t nmax = 1;
+    for (int i = 0; i < segs; ++i) { sg.off[i] = off[i]; sg.n[i] = n[i]; nmax = std::max(nmax, n[i]); }
+    hipLaunchKernelGGL(k_amax_segs, dim3((int)std::min<int64_t>(32, (nmax + 2047) / 2048), segs), dim3(256), 0, s, x, sg, out, out_stride);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
 int gm_split_np() {
     const int o = g_split_pieces.load(std::memory_order_relaxed);
     return o > 0 ? o : (gm_knob().split_pieces == 3 ? 3 : 2);

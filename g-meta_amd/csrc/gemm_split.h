@@ -185,6 +185,17 @@ __global__ __launch_bounds__(256) void k_amax(const float* x, int64_t stride, in
     if ((threadIdx.x & 63) == 0) gs_note_max(out + (int64_t)blockIdx.y * out_stride, __float_as_uint(m));
 }
 
+// the same for up to 8 segments of one vector in ONE launch (blockIdx.y = segment): out[y * out_stride] <- max |x[off[y] + i]|, i < n[y]
+struct AmaxSegs { int64_t off[8]; int64_t n[8]; };
+__global__ __launch_bounds__(256) void k_amax_segs(const float* x, AmaxSegs sg, unsigned* out, int64_t out_stride) {
+    const float* p = x + sg.off[blockIdx.y]; const int64_t n = sg.n[blockIdx.y];
+    float m = 0.f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) gs_note_max(out + (int64_t)blockIdx.y * out_stride, __float_as_uint(m));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 or 128 (one 128 x N tile per step, 16-k chunks):
 //   waves 0..7    COMPUTE  64x64 sub-tiles: LDS fragments -> 24 bf16 MFMAs per chunk; at the end of a tile the accumulators go
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     constexpr int OFF_E = OFF_B + NB * B_ST, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
     constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
     constexpr int B_PPW = (NP * 2 * (BN / 64)) / 4;                                   // DMA pieces per B-feeder wave and chunk: 6 (N = 256) / 3
-    __shared__ __attribute__((aligned(16))) char smem[OFF_BIAS + 2 * BN * 4];
+    constexpr int OFF_MAX = OFF_BIAS + 2 * BN * 4;                                    // {max bits, arrivals} of the compute waves' amax_out flush
+    __shared__ __attribute__((aligned(16))) char smem[OFF_MAX + 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nchunks = g.K / BK;
     const int G = gridDim.x, b = blockIdx.x;
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     float* scales = reinterpret_cast<float*>(smem + OFF_SC);                          // [2][128] by tile parity
     float* biasl = reinterpret_cast<float*>(smem + OFF_BIAS);                         // [2][256]
     if (total == 0) return;
+    if (NP == 2 && tid < 2) reinterpret_cast<unsigned*>(smem + OFF_MAX)[tid] = 0u;     // (visible to the compute waves after their first barrier)
     if (wave >= 12) {
         // ================= B feeder
         __builtin_amdgcn_s_setprio(2);            // feeders ahead of the MFMA-heavy compute waves in VALU / LDS arbitration
@@ -478,10 +491,24 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         GS_BARRIER();
         int gc = 0;
         float vmax = 0.f; int vmax_set = -1;                      // amax_out: running bound of this wave's blocks, flushed when the set changes
+        // The eight compute waves walk the same tiles, so they flush at the same points: they meet in LDS and the last one to arrive makes the
+        // ONE global request of the workgroup (a wave cannot reach the next flush before the last arrival has reset the pair: at least one
+        // chunk barrier lies in between).
         auto vmax_flush = [&]() {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-            if (lane == 0) gs_note_max(g.amax_out + (int64_t)vmax_set * GM_BOUND_PAD, __float_as_uint(vmax));
+            if (lane == 0) {
+                unsigned* mx = reinterpret_cast<unsigned*>(smem + OFF_MAX);
+                atomicMax(mx, __float_as_uint(vmax));
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");              // the maximum before the arrival
+                const unsigned ticket = atomicAdd(mx + 1, 1u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (ticket == 7u) {
+                    const unsigned all = atomicExch(mx, 0u);
+                    mx[1] = 0u;
+                    gs_note_max(g.amax_out + (int64_t)vmax_set * GM_BOUND_PAD, all);
+                }
+            }
             vmax = 0.f;
         };
         for (int ti = 0; ti < ntb; ++ti) {

@@ -156,6 +156,7 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
     int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
@@ -285,6 +286,7 @@ int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K,
                      gm_bound bound = gm_no_bound());
 // out[t * out_stride] = max(out[...], max_i |x[t * stride + off + i]|), i < n, as fp32 bit patterns (the slots must have been zeroed)
 int gm_amax(const float* x, int64_t stride, int64_t off, int64_t n, int sets, unsigned* out, int64_t out_stride, hipStream_t s);
+int gm_amax_segs(const float* x, const int64_t* off, const int64_t* n, int segs, unsigned* out, int64_t out_stride, hipStream_t s);   // up to 8 segments of x, one launch
 int gm_split_np();                      // pieces per operand of the split kernels where bounds are available: 2 (fp16, default) or 3 (bf16); env GM_SPLIT_PIECES
 
 // Grouped transposed-A GEMM for weight gradients:

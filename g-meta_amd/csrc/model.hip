@@ -1209,7 +1209,8 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     p.bound_ws = nullptr; p.bound_words = 0;
     bool agg_first = true;
     for (int l = 0; l < p.L.n_gcn; ++l) agg_first = agg_first && p.L.dims[l] <= p.L.dims[l + 1];
-    if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->d_gain && qry->d_gain && spt->store->d_feat_amax) {
+    if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->d_gain && qry->d_gain && spt->store->d_feat_amax &&
+        spt->rows + qry->rows >= gm_knob().split16_min_rows) {
         const int per_pass = 2 * p.L.n_gcn + 1;
         const int64_t ws_s = (int64_t)p.K * per_pass * p.T * GM_BOUND_PAD, ws_q = (int64_t)K1 * per_pass * p.T * GM_BOUND_PAD, ws_w = (int64_t)p.L.n_gcn * GM_BOUND_PAD;
         p.bound_words = ws_s + ws_q + ws_w;
@@ -1288,7 +1289,9 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         // bound slots of this step: zero (the producers use atomicMax), then the maxima of theta's weight matrices (slot k = 0)
         GM_HIP(hipMemsetAsync(p.bound_ws, 0, sizeof(unsigned) * p.bound_words, st));
         p.pd.theta = theta;
-        for (int l = 0; l < L.n_gcn; ++l) GM_TRY(gm_amax(theta, 0, L.w_off[l], (int64_t)L.dims[l] * L.dims[l + 1], 1, p.pd.wam + (int64_t)l * GM_BOUND_PAD, 0, st));
+        int64_t off[GM_MAX_GCN], n[GM_MAX_GCN];
+        for (int l = 0; l < L.n_gcn; ++l) { off[l] = L.w_off[l]; n[l] = (int64_t)L.dims[l] * L.dims[l + 1]; }
+        GM_TRY(gm_amax_segs(theta, off, n, L.n_gcn, p.pd.wam, GM_BOUND_PAD, st));
     }
     gm_prof_reset();
     tm.lap("plan");

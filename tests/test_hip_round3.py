@@ -134,3 +134,50 @@ def test_aggregate_of_one_batch_from_two_streams_is_ordered():
     torch.cuda.synchronize()
     for k, o in outs:
         assert torch.equal(o, want[k])
+
+
+def test_two_piece_kernels_match_three_piece_and_report_outgrown_weights():
+    """gm_meta_step with the two-piece fp16 split kernels (default) against the exact three-piece bf16 ones on the same step: accuracies equal,
+    losses / meta-gradient within 1e-5 of the gradient scale (both are fp32-accurate; BASELINE's bar is 1e-4).  And the documented limit of
+    the weight bound: fast weights that outgrow 1024 x theta's largest weight inside one inner loop come back as a NaN query loss -- which
+    Meta.forward treats like the reference treats torch.isnan(loss_q): no optimiser step -- never as silently wrong numbers."""
+    import gmeta_amd
+    from gmeta_amd import _lib, synth
+    lib = _lib.lib()
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=4)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=4, args=args,
+                             adjs=store, h=cfg['h'], tables=data['tables'], verbose=False)
+    batch = db.get_batch([0, 1, 2, 3])
+    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
+
+    def run(pieces, update_lr=None):
+        torch.manual_seed(5)
+        a = argparse.Namespace(**vars(args))
+        if update_lr is not None:
+            a.update_lr = update_lr
+        m = gmeta_amd.Meta(a, config).to('cuda')
+        theta0 = [p.detach().clone() for p in m.net.parameters()]
+        lib.gm_set_split_pieces(pieces)
+        try:
+            accs = m(*batch, data['feats'])
+            torch.cuda.synchronize()
+        finally:
+            lib.gm_set_split_pieces(-1)
+        grads = [p.grad.detach().clone() if p.grad is not None else None for p in m.net.parameters()]
+        moved = max(float((p.detach() - q).abs().max()) for p, q in zip(m.net.parameters(), theta0))
+        return np.asarray(accs), grads, moved, m
+
+    acc3, g3, moved3, _ = run(3)
+    acc2, g2, moved2, _ = run(2)
+    assert moved3 > 0 and moved2 > 0
+    np.testing.assert_allclose(acc2, acc3, atol=1e-6, rtol=0)
+    for a, b in zip(g2[:-1], g3[:-1]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * max(scale, 1e-12), (float((a - b).abs().max()), scale)
+    # an inner learning rate that throws the fast weights ~1e5 x beyond theta's range in one step
+    acc_big, _, moved_big, m_big = run(2, update_lr=3e4)
+    assert np.isnan(m_big.last_stats['loss_q'])
+    assert moved_big == 0.0                                                # NaN loss -> the step was skipped (meta.py:163-169)
