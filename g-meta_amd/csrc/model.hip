@@ -1337,14 +1337,19 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
         return head_loss(p.Q, w, wstride, p.logit_q, pk, grad ? 1 : 0, p.gq, Pp, sparse, sq);
     };
-    // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq
+    // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq.  Host enqueue order matters at the
+    // start of a step (the GPU is idle and a launch costs the host ~5 us): the first query forward needs nothing but theta and is the head
+    // of the longer chain on small shards, so it goes out first -- behind the support step's ~17 launches it started ~110 us late.
+    // (Where the support chain is the longer one -- small query batches: the FirstMM shape lost 2.5 % -- its launches keep the lead.)
+    const bool query_first = qry->rows >= 100000;
+    if (query_first) GM_TRY(qry_fwd(theta, 0, 1));
     GM_TRY(spt_step(0, theta, 0, fw(1)));
     hipEvent_t e_proto0 = signal(st);
-    GM_TRY(spt_step_bwd(theta, 0));
-    hipEvent_t e_fw = signal(st);                          // fw_1 ready
-    GM_TRY(qry_fwd(theta, 0, 1));
+    if (!query_first) GM_TRY(qry_fwd(theta, 0, 1));
     wait(sq, e_proto0);
     GM_TRY(qry_loss(theta, 0, 0, 0, false));
+    GM_TRY(spt_step_bwd(theta, 0));
+    hipEvent_t e_fw = signal(st);                          // fw_1 ready
     wait(sq, e_fw);
     GM_TRY(qry_fwd(fw(1), Pp, 1));
     GM_TRY(qry_loss(fw(1), Pp, 1, 0, false));
