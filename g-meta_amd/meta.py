@@ -48,7 +48,7 @@ class Meta(nn.Module):
         self._flat_theta_buf = None
         self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -149,10 +149,19 @@ class Meta(nn.Module):
             raise ValueError('label count does not match the number of subgraphs')
         hp = _lib.HParams(float(self.update_lr), int(K), int(self.k_spt), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd),
                           int(self.cone))
-        n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
-        ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
-        if ws_bytes < 0 or n_out < 0:
-            _lib.check(-1, 'gm_meta_ws_bytes')
+        # output / workspace sizes depend on the batches' shapes and the hyper-parameters only: remembered per (batch pair, hparams) -- two FFI
+        # calls (one of them a full planning pass) less on the host path between the read-back of one step and the first launch of the next
+        key = (id(S), id(Q), S.rows, Q.rows, S.subs, Q.subs, int(K), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd), int(self.cone),
+               int(lib.gm_get_gemm_mode()), int(lib.gm_get_split_pieces()))
+        sizes = getattr(self, '_sizes', None)
+        if sizes is None or sizes[0] != key:
+            n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
+            ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
+            if ws_bytes < 0 or n_out < 0:
+                _lib.check(-1, 'gm_meta_ws_bytes')
+            self._sizes = (key, n_out, ws_bytes)
+        else:
+            n_out, ws_bytes = sizes[1], sizes[2]
         ws = self._workspace(ws_bytes, dev)
         out = torch.empty(n_out, dtype=torch.float32, device=dev)
         _lib.check(lib.gm_meta_step(S.handle, Q.handle, _lib.ptr(ys), _lib.ptr(yq), C.byref(model), C.byref(hp), _lib.ptr(theta),
