@@ -565,7 +565,9 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
             // a whole GEMM for a CU (head/loss: 26 us of work, 680 us in the two-stream timeline).  `mult` workgroups per CU, each walking
             // 1/mult of the tiles, give the dispatcher a yield point every ~0.65/mult ms (default 4: 27.7 -> 27.4 ms at task_num 32, 5.12 -> 4.86 ms
             // for the 4-task shard, where the support chain is the critical path; 8 and more lose to the per-workgroup prologue).
-            const int mult_f = gm_knob().gemm_fused_rounds;
+            // With the two-piece kernels (shorter tiles) the optimum moved from 4 to 3, and to 2 for the launches of 16 and more tiles per CU:
+            // 4-task shard 4.36 -> 4.25 ms, task_num 32 24.86 -> 24.50 (three runs each, same box).
+            const int mult_f = gm_knob().gemm_fused_rounds > 0 ? gm_knob().gemm_fused_rounds : (a.n_tiles >= 16 * grid_cap ? 2 : 3);
             const dim3 grid(std::min(a.n_tiles, mult_f * grid_cap));
             if (a.N == 128 && f16) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2, 2>), grid, dim3(1024), 0, s, k);
             else if (a.N == 128) hipLaunchKernelGGL((k_gemm_split_p<true, 1, 2, 3>), grid, dim3(1024), 0, s, k);
