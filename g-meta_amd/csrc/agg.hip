@@ -359,8 +359,14 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     }
 }
 
-int gm_agg_window(int64_t rows) {
-    const int min_waves = gm_knob().agg_min_waves, min_win = gm_knob().agg_min_win;
+// Rows per wave window: 64, halved until the launch has enough waves to fill the chip.  "Enough" depends on the work a row carries: sparse
+// batches (the arxiv / FirstMM shapes, ~2 in-edges per row) want >= 32k waves and may go down to 2-row windows; dense ones (Tissue shape,
+// ~30 in-edges per row) are better off with half as many, larger windows (4 rows at least) -- measured with the two-piece GEMMs in place:
+// 65536 / 2 -> these rules: 4-task arxiv shard 4.31 -> 4.17 ms, task_num 32 24.43 -> 24.25, Tissue shape 3.65 -> 3.36.
+int gm_agg_window(int64_t rows, int64_t edges) {
+    const bool dense = edges > 8 * rows;
+    const int min_waves = gm_knob().agg_min_waves > 0 ? gm_knob().agg_min_waves : (dense ? 16384 : 32768);
+    const int min_win = gm_knob().agg_min_win > 0 ? gm_knob().agg_min_win : (dense ? 4 : 2);
     int win = 64;
     while (win > min_win && rows / win < min_waves) win >>= 1;
     return win;
@@ -428,7 +434,7 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     // keep the rows in flight on an XCD within reach of its 4-MiB L2 -- a source row is gathered by ~2 destination rows
     // of the same subgraph, and the second gather only hits if it follows the first closely (measured on the 1.1 M-row
     // query batch: 4.2 -> 4.6 TB/s) -- and spread small batches (support sets, a 4-task shard) over the whole chip.
-    a.win = a.sched ? a0.win : gm_agg_window(a.rows);
+    a.win = a.sched ? a0.win : gm_agg_window(a.rows, 0);
     const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
     a.nblocks = (int)((a.rows + RPB - 1) / RPB);
     int grid = a.nblocks;

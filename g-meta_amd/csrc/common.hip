@@ -143,8 +143,8 @@ const gm_knobs& gm_knob() {
     static std::once_flag once;
     std::call_once(once, [] {
         auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-        k.agg_min_waves = env("GM_AGG_MIN_WAVES", 65536);
-        k.agg_min_win = std::max(1, env("GM_AGG_MIN_WIN", 2));
+        k.agg_min_waves = env("GM_AGG_MIN_WAVES", 0);                   // 0: by batch density (gm_agg_window)
+        k.agg_min_win = std::max(0, env("GM_AGG_MIN_WIN", 0));          // 0: by batch density
         k.agg_sched = env("GM_AGG_SCHED", 1);
         k.agg_hub_part = env("GM_AGG_HUB_PART", 128);                  // 0: one block per hub row
         k.agg_unr = env("GM_AGG_UNR", 24);

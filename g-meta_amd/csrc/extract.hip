@@ -481,7 +481,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     GM_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
     GM_HIP(hipStreamSynchronize(s));
     gm_dev_free(d_cnt, s);
-    b->sched_win = gm_agg_window(b->rows);
+    b->sched_win = gm_agg_window(b->rows, b->edges);
     for (int o = 0; o < 2; ++o) {
         b->n_heavy[o] = std::min(cnt[o], cap);
         if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)

@@ -240,7 +240,7 @@ template <class A> inline void gm_agg_hub(A& a, const gm_batch* b, int o, hipStr
     if (a.hub) (void)gm_batch_hub_order(b, o, s);
 }
 // Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
-int gm_agg_window(int64_t rows);
+int gm_agg_window(int64_t rows, int64_t edges);
 // Block schedule for the window aggregate over `rows` rows with the given (ascending, host) hub-row list: 8 per-XCD lists of
 // equal length out->len; entry >= 0: window block id, <= -2: hub part -(entry) - 2 (hub row heavy[..] itself when the rows are not
 // split: out->d_hub == NULL), -1: nothing.  A hub row's blocks follow the window block that contains the row, on the XCD whose L2 is
