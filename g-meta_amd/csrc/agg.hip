@@ -455,14 +455,20 @@ static void launch_one(const AggK& a0, hipStream_t s) {
     hipLaunchKernelGGL((k_agg<VEC, LPR>), dim3(a.nblocks), dim3(AGG_BLOCK), 0, s, a);
 }
 
-static int agg_nt() { return gm_knob().agg_nt; }
+// Non-temporal stores of the output: 0 never, 2 always, 1 (default) from 128 MB of output upwards -- a small output stays in the caches for
+// the GEMM that reads it next (Tissue shape -1.3 %, FirstMM shape -1 %); at 146 MB (the support batch at task_num 32, the query batch of a
+// 4-task shard) the two are within noise of each other, at 572k rows ordinary stores lose 1.5 %.
+static int agg_nt(int64_t rows, int width) {
+    const int k = gm_knob().agg_nt;
+    return k == 1 ? (rows * (int64_t)width * 4 >= ((int64_t)128 << 20) ? 1 : 0) : (k ? 1 : 0);
+}
 static int agg_variant() { return gm_knob().agg_variant; }
 
 int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     if (g.rows <= 0) return GM_OK;
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
            g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
-           g.sched, g.sched_len, agg_nt(), g.sched ? g.sched_win : 64,
+           g.sched, g.sched_len, agg_nt(g.rows, g.width), g.sched ? g.sched_win : 64,
            g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx, g.skip_on ? g.skip_lo : 1, g.skip_on ? g.skip_hi : 0};
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));

@@ -545,7 +545,7 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         SplitGemmK k{};
         k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
         k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
-        k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;
+        k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;      // (ordinary C stores lose at every size: 4-task shard +3 %, task_num 32 +1.3 %)
         const bool f16 = a.np == 2;
         GM_REQUIRE(!f16 || (a.a_bound.amax && a.b_bound.amax), GM_EINVAL, "gemm: the two-piece split kernel needs bounds for both operands");
         k.a_bound = f16 ? a.a_bound : gm_no_bound(); k.b_bound = f16 ? a.b_bound : gm_no_bound(); k.amax_out = a.amax_out;
