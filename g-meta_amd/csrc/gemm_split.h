@@ -12,6 +12,12 @@
 // at 6/16 of the f32-MFMA cost.  Splitting costs ~5.5 VALU ops per element and is done ONCE per block tile when the A
 // rows are staged into LDS; the (small, per-task) weights are split once per launch by k_split_w into three bf16 planes
 // stored [n][k] (k contiguous), so the B tiles are DMA-ed straight into LDS in MFMA fragment order.
+//
+// Second arithmetic (template parameter NP = 2, what gm_meta_step runs where magnitude bounds are recorded): two fp16
+// pieces per operand under per-set power-of-two scales (gm_bound.h, gs_scale_of) and THREE products a_h b_h + a_h b_m + a_m b_h on
+// v_mfma_f32_32x32x16_f16 -- 22 significand bits per operand, measured error vs fp64 below the three-piece kernel's; half the matrix work,
+// two thirds of the LDS / weight-plane traffic.  Same kernel body: plane counts, the split in the feeders and the MFMA type are the only
+// differences, plus the epilogue's running max |C| that feeds the next consumer's bound.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
