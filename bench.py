@@ -510,6 +510,13 @@ def main():
                       'products, fp32 accumulation (error vs fp64 <= the fp32 fmaf chain\'s; DESIGN.md section 4); other launches exact fp32')
                      if lib.gm_get_gemm_mode() == 1 else 'exact fp32 (v_mfma_f32_32x32x2_f32) everywhere')
         fused = lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1 and not (a.cone or a.hoist_z1)
+        if fused:                           # the library fuses only where at least half of the query batch's rows have one or two sources (model.hip)
+            try:
+                ip = batches[0][2][0].view_of.csr()[0]
+                deg = np.diff(np.asarray(ip, np.int64))
+                fused = 2 * int((deg > 2).sum()) <= len(deg)
+            except Exception:
+                pass
         out = {
             'metric': 'meta-tasks/sec (inner-loop fwd+bwd) at task_num=%d' % T, 'value': round(T / (ms_per_step * 1e-3), 3),
             'unit': 'meta-tasks/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_per_step, 3),
