@@ -51,12 +51,13 @@ PROTOTYPES = {
     'gm_proto_loss_qry': (C.c_int, [vp, vp, i32, vp, vp, i32, vp, vp, vp, vp, vp]),
     'gm_meta_ws_bytes': (i64, [vp, vp, vp, vp]),
     'gm_meta_out_floats': (i64, [vp, vp, vp]),
-    'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp]),
+    'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     'gm_meta_finish': (C.c_int, [vp, i64, i32, vp, vp, vp]),
     'gm_set_gemm_mode': (None, [i32]),
     'gm_get_gemm_mode': (i32, []),
     'gm_get_split_pieces': (i32, []),
     'gm_set_split_pieces': (None, [i32]),
+    'gm_set_tuning': (C.c_int, [C.c_char_p, i32]),
     'gm_set_fuse_agg': (None, [i32]),
     'gm_get_fuse_agg': (i32, []),
     'gm_profile_enable': (None, [i32]),

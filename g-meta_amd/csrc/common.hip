@@ -138,10 +138,12 @@ extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t
     return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);
 }
 
+static gm_knobs g_knobs;
+static std::once_flag g_knobs_once;
 const gm_knobs& gm_knob() {
-    static gm_knobs k;
-    static std::once_flag once;
-    std::call_once(once, [] {
+    gm_knobs& k = g_knobs;
+    std::call_once(g_knobs_once, [] {
+        gm_knobs& k = g_knobs;
         auto env = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
         k.agg_min_waves = env("GM_AGG_MIN_WAVES", 0);                   // 0: by batch density (gm_agg_window)
         k.agg_min_win = std::max(0, env("GM_AGG_MIN_WIN", 0));          // 0: by batch density
@@ -173,11 +175,30 @@ const gm_knobs& gm_knob() {
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
         k.wgrad_round_bias = env("GM_WGRAD_ROUND_BIAS", 25);
-        k.split_pieces = env("GM_SPLIT_PIECES", 2);
+        k.split_pieces = env("GM_SPLIT_PIECES", 3);                   // 3: every operand carries its full 24 significand bits (the reference multiplies in fp32, learner.py:36,47); 2 = opt-in fast mode
         k.split16_min_rows = env("GM_SPLIT16_MIN_ROWS", 65536);
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
     });
     return k;
+}
+
+// Tuning knobs by the name of their environment variable, after start-up (tests force the large-launch kernels onto small fixtures with this;
+// bench.py times variants in one process).  Not synchronised with concurrent library calls: set knobs while no other thread is inside the library.
+extern "C" int gm_set_tuning(const char* name, int32_t value) {
+    GM_REQUIRE(name, GM_EINVAL, "set_tuning: NULL name");
+    (void)gm_knob();
+    static const struct { const char* name; int gm_knobs::*field; } tab[] = {
+        {"GM_AGG_MIN_WAVES", &gm_knobs::agg_min_waves}, {"GM_AGG_MIN_WIN", &gm_knobs::agg_min_win}, {"GM_AGG_UNR", &gm_knobs::agg_unr}, {"GM_AGG_NT", &gm_knobs::agg_nt},
+        {"GM_AGG_VARIANT", &gm_knobs::agg_variant}, {"GM_GEMM_SPLIT_MIN_TILES", &gm_knobs::gemm_split_min_tiles}, {"GM_GEMM_SPLIT_GRID", &gm_knobs::gemm_split_grid},
+        {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
+        {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
+        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage},
+        {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
+    };
+    for (const auto& e : tab)
+        if (!strcmp(name, e.name)) { g_knobs.*(e.field) = value; return GM_OK; }
+    gm_set_error("set_tuning: unknown or start-up-only knob %s", name);
+    return GM_EINVAL;
 }
 
 int gm_heavy_deg() { return gm_knob().heavy_deg > 0 ? std::max(2, gm_knob().heavy_deg) : 64; }

@@ -414,9 +414,15 @@ int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     if (b->hub_used[o] && b->hub_stream[o] != s) {
-        if (!b->hub_ev[o]) GM_HIP(hipEventCreateWithFlags(&b->hub_ev[o], hipEventDisableTiming));
-        GM_HIP(hipEventRecord(b->hub_ev[o], b->hub_stream[o]));
-        GM_HIP(hipStreamWaitEvent(s, b->hub_ev[o], 0));
+        // The remembered stream may have been destroyed by its owner since: a failed record / wait must neither drop the ordering nor leave a
+        // sticky error for the next hipGetLastError() -- fall back to draining the device before the scratch is reused.
+        bool ordered = false;
+        if (b->hub_ev[o] || hipEventCreateWithFlags(&b->hub_ev[o], hipEventDisableTiming) == hipSuccess)
+            ordered = hipEventRecord(b->hub_ev[o], b->hub_stream[o]) == hipSuccess && hipStreamWaitEvent(s, b->hub_ev[o], 0) == hipSuccess;
+        if (!ordered) {
+            (void)hipGetLastError();
+            GM_HIP(hipDeviceSynchronize());
+        }
     }
     b->hub_used[o] = true; b->hub_stream[o] = s;
     return GM_OK;

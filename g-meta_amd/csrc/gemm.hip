@@ -478,7 +478,7 @@ int gm_gemm_mode() {
 }
 extern "C" void gm_set_gemm_mode(int32_t mode) { g_gemm_mode.store(mode ? 1 : 0, std::memory_order_relaxed); }
 extern "C" int32_t gm_get_gemm_mode(void) { return gm_gemm_mode(); }
-static std::atomic<int> g_split_pieces{-1};     // gm_set_split_pieces override (-1: GM_SPLIT_PIECES / default 2)
+static std::atomic<int> g_split_pieces{-1};     // gm_set_split_pieces override (-1: GM_SPLIT_PIECES / default 3)
 extern "C" void gm_set_split_pieces(int32_t pieces) { g_split_pieces.store(pieces == 3 ? 3 : (pieces == 2 ? 2 : -1), std::memory_order_relaxed); }
 extern "C" int32_t gm_get_split_pieces(void) { return gm_split_np(); }
 // The persistent kernel walks 128 x 256 tiles, one workgroup per CU: worth it from about one tile per CU upwards.
@@ -524,7 +524,7 @@ int gm_amax_segs(const float* x, const int64_t* off, const int64_t* n, int segs,
 }
 int gm_split_np() {
     const int o = g_split_pieces.load(std::memory_order_relaxed);
-    return o > 0 ? o : (gm_knob().split_pieces == 3 ? 3 : 2);
+    return o > 0 ? o : (gm_knob().split_pieces == 2 ? 2 : 3);
 }
 
 static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s);
@@ -1159,6 +1159,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* partial, const in
                     uint32_t bh, bm, bl = 0;
                     if (u.pl_np == 2) {             // two fp16 pieces under the set's scale (bit patterns in the high halves, as below)
                         const float xs = wn * gs_bound_scale_v(u.pl_bound, set);
+                        if (u.pl_bound.viol && fabsf(xs) > 65504.f && fabsf(wn) < INFINITY) atomicOr(u.pl_bound.viol, GM_VIOL_WEIGHT);
                         const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
                         bh = (uint32_t)__builtin_bit_cast(uint16_t, h) << 16; bm = (uint32_t)__builtin_bit_cast(uint16_t, m) << 16;
                     } else {
@@ -1225,6 +1226,7 @@ __device__ __forceinline__ void wgrad_reduce_pl_body(const float* partial, const
     const int np = u.pl_np == 2 ? 2 : 3;
     if (np == 2) {                                          // two fp16 pieces under the set's scale
         const float xs = wn * gs_bound_scale_v(u.pl_bound, set);
+        if (u.pl_bound.viol && fabsf(xs) > 65504.f && fabsf(wn) < INFINITY) atomicOr(u.pl_bound.viol, GM_VIOL_WEIGHT);      // the fast weight outgrew the step's bound
         const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
         pl[0][tk][tn] = __builtin_bit_cast(uint16_t, h); pl[1][tk][tn] = __builtin_bit_cast(uint16_t, m);
     } else {

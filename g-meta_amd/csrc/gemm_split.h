@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k_split_w(const float* params, int64_t ps
         if (np == 2) {
             const int64_t plane = (int64_t)N * K, at = ((int64_t)(k >> 3) * N + n) * 8 + (k & 7);
             const float xs = x * sb;
+            if (bound.viol && fabsf(xs) > 65504.f && fabsf(x) < INFINITY) atomicOr(bound.viol, GM_VIOL_WEIGHT);      // (a finite weight whose pieces are not)
             const _Float16 h = (_Float16)xs, m = (_Float16)(xs - (float)h);
             O[at] = __builtin_bit_cast(uint16_t, h);
             O[plane + at] = __builtin_bit_cast(uint16_t, m);
@@ -498,8 +499,13 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         int gc = 0;
         float vmax = 0.f; int vmax_set = -1;                      // amax_out: running bound of this wave's blocks, flushed when the set changes
         // The eight compute waves walk the same tiles, so they flush at the same points: they meet in LDS and the last one to arrive makes the
-        // ONE global request of the workgroup (a wave cannot reach the next flush before the last arrival has reset the pair: at least one
-        // chunk barrier lies in between).
+        // ONE global request of the workgroup.  Only flushes BETWEEN two tiles go through the LDS pair: a wave cannot reach the next of those
+        // before the last arrival has reset the pair (a whole tile of chunk barriers lies in between).  The flush after the last tile is
+        // separated from a preceding set-change flush by the barrier-free epilogue only, so there every wave makes its own request.
+        auto vmax_note = [&](unsigned bits) {
+            gs_note_max(g.amax_out + (int64_t)vmax_set * GM_BOUND_PAD, bits);
+            if (g.b_bound.viol && bits > 0x58800000u && bits < 0x7f800000u) atomicOr(g.b_bound.viol, GM_VIOL_RANGE);      // > 2^50: beyond the scale clamp's reach
+        };
         auto vmax_flush = [&]() {
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
@@ -512,10 +518,15 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 if (ticket == 7u) {
                     const unsigned all = atomicExch(mx, 0u);
                     mx[1] = 0u;
-                    gs_note_max(g.amax_out + (int64_t)vmax_set * GM_BOUND_PAD, all);
+                    vmax_note(all);
                 }
             }
             vmax = 0.f;
+        };
+        auto vmax_flush_last = [&]() {
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+            if (lane == 0) vmax_note(__float_as_uint(vmax));
         };
         for (int ti = 0; ti < ntb; ++ti) {
             gm_f32x16 acc[MI][2];
@@ -605,7 +616,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
-        if constexpr (NP == 2) { if (g.amax_out && vmax_set >= 0) vmax_flush(); }     // (bit patterns of non-negative floats order as integers)
+        if constexpr (NP == 2) { if (g.amax_out && vmax_set >= 0) vmax_flush_last(); }     // (bit patterns of non-negative floats order as integers)
     }
 }
 

@@ -8,5 +8,10 @@
 // Slots of different sets sit GM_BOUND_PAD words (256 B) apart: device-scope atomics / coherent loads on one cache line are served one at a
 // time by that line's memory channel (thousands of them per launch were measured as 10-250 us), different lines go to different channels.
 #define GM_BOUND_PAD 64
-struct gm_bound { const unsigned* amax; int64_t stride; const float* gain; float hgain; };
-static inline gm_bound gm_no_bound() { gm_bound b; b.amax = nullptr; b.stride = 0; b.gain = nullptr; b.hgain = 1.f; return b; }
+// viol (optional): a device word that receives GM_VIOL_* bits when a producer finds the bound broken -- a weight that outgrew the head-room of
+// its bound (its fp16 pieces would be inf), a recorded maximum beyond the scale range.  gm_meta_step reports the word in the last float of `out`;
+// the reference's fp32 path has no such limits, so the host re-runs such a step with the three-piece kernels instead of returning its numbers.
+#define GM_VIOL_WEIGHT 1u      // |w| * scale > fp16 max: a fast weight outgrew GM_W_HEADROOM x max |theta_W|
+#define GM_VIOL_RANGE 2u       // a recorded operand maximum above 2^50 (scales are clamped to [2^-40, 2^40])
+struct gm_bound { const unsigned* amax; int64_t stride; const float* gain; float hgain; unsigned* viol; };
+static inline gm_bound gm_no_bound() { gm_bound b; b.amax = nullptr; b.stride = 0; b.gain = nullptr; b.hgain = 1.f; b.viol = nullptr; return b; }

@@ -49,7 +49,12 @@ struct gm_store {
     int64_t* d_out_ptr = nullptr;    // by-source CSR of the same edges (for the transposed induce)
     int32_t* d_out_idx = nullptr;    // destination node, LOCAL to its graph
     float* d_feat = nullptr;         // [total_nodes, feat_ld]
-    unsigned* d_feat_amax = nullptr; // [1] bit pattern of max |feature| (gm_bound.h: the bound of every layer-1 operand)
+    unsigned* d_feat_amax = nullptr; // [1] bit pattern of max |feature| over the whole table
+    // per graph (host): max |x| and mean |x| over the non-zero entries.  The two-piece fp16 kernels (opt-in, gm_bound.h) bound the layer-1 operand
+    // of a task by the largest feature of the graphs the task draws from, and keep the three-piece kernels for a pass whose table is LOOSE: an
+    // entry 2^r below its bound keeps min(22, 39 - r) bits, so a table whose largest entry sits more than 2^14 above its typical one (or is
+    // not finite / above 2^50) would lose precision silently
+    std::vector<float> h_feat_amax, h_feat_mean;
 };
 
 // Receptive-field tables (cone.hip): level l = rows whose layer-l activation reaches a centre.
@@ -235,9 +240,9 @@ const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current de
 #define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
 struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; };
 int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s);
-template <class A> inline void gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s) {
+template <class A> inline int gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s) {
     a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o];
-    if (a.hub) (void)gm_batch_hub_order(b, o, s);
+    return a.hub ? gm_batch_hub_order(b, o, s) : GM_OK;
 }
 // Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
 int gm_agg_window(int64_t rows, int64_t edges);

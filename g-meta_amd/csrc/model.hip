@@ -353,13 +353,18 @@ __global__ void k_colsum_rows(const float* G, int64_t ldg, int N, const int32_t*
 // out = [ sum_t (gq+gp) | sum_t lq[t,:] | sum_t aq[t,:] | T | aq[t,:] ... ]
 // (cut, shift): the kernels' parameter layout has `shift` extra floats after position `cut` (zero-padded W_1 rows when the store pads
 // its feature columns); `out` uses the caller's layout.
+// The last float is the step's violation word (gm_bound.h GM_VIOL_*; 0 unless the opt-in two-piece kernels found one of their bounds broken).  A step
+// with a violation also reports losses_q[K] = NaN, so that every rank of a sharded meta-batch skips the optimiser step on the REDUCED loss
+// (meta.py:163) and the host mirror can re-run the step with the three-piece kernels.
 __global__ void k_finalize(const float* gq, const float* gp, int64_t stride, int64_t P, int T, const float* lq, const float* aq, int K1, float* out,
-                           int64_t cut, int64_t shift) {
+                           int64_t cut, int64_t shift, const unsigned* viol) {
     const int64_t tot = P + 2 * K1 + 1 + (int64_t)T * K1;
-    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < tot; id += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned vw = viol ? *viol : 0u;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id <= tot; id += (int64_t)gridDim.x * blockDim.x) {
         float s = 0.f;
+        if (id == tot) { out[id] = (float)vw; continue; }
         if (id < P) { const int64_t src = id < cut ? id : id + shift; if (gq) for (int t = 0; t < T; ++t) s += gq[t * stride + src] + gp[t * stride + src]; }
-        else if (id < P + K1) { for (int t = 0; t < T; ++t) s += lq[t * K1 + (id - P)]; }
+        else if (id < P + K1) { for (int t = 0; t < T; ++t) s += lq[t * K1 + (id - P)]; if (vw && id == P + K1 - 1) s = __uint_as_float(0x7fc00000u); }
         else if (id < P + 2 * K1) { for (int t = 0; t < T; ++t) s += aq[t * K1 + (id - P - K1)]; }
         else if (id == P + 2 * K1) s = (float)T;
         else s = aq[id - P - 2 * K1 - 1];
@@ -403,9 +408,11 @@ struct PlaneDir {
     // bound -- the planes of fw_k are written by the reduction that produces fw_k, before its own maximum could be known.  A weight that
     // outgrows theta's largest by that factor inside one inner loop turns into inf / NaN losses, which the caller sees.
     unsigned* wam = nullptr; const float* theta = nullptr;
+    unsigned* viol = nullptr;                                               // the step's violation word (gm_bound.h)
     bool w_bound(const float* params, int l, gm_bound& bd) const {
+        bd = gm_no_bound();
         if (!wam || !(index_of(params) || params == theta)) return false;
-        bd.amax = wam + (int64_t)l * GM_BOUND_PAD; bd.stride = 0; bd.gain = nullptr; bd.hgain = GM_W_HEADROOM;
+        bd.amax = wam + (int64_t)l * GM_BOUND_PAD; bd.stride = 0; bd.gain = nullptr; bd.hgain = GM_W_HEADROOM; bd.viol = viol;
         return true;
     }
 };
@@ -430,6 +437,7 @@ struct GcnCtx {
     // meta-step) receive the per-set maxima of H_l (forward GEMM epilogues), T_l (dZ GEMM epilogues) and dQ_L (head backward); hv / tv / dqv:
     // recorded in the current pass.  A launch whose bounds are not all there runs the three-piece bf16 kernels.
     int np = 3; unsigned* am = nullptr; int am_passes = 0, am_pass = -1;
+    const unsigned* feat_bound = nullptr;      // [sets] per-task bound of the layer-1 operand: the largest |feature| of the graphs the task draws from (NULL: loose table, three-piece)
     bool hv[GM_MAX_GCN] = {}, tv[GM_MAX_GCN] = {}; bool dqv = false;
     unsigned* am_slot(int i) const { return am + ((int64_t)am_pass * (2 * L.n_gcn + 1) + i) * b->sets * GM_BOUND_PAD; }
     unsigned* amH(int l) const { return am_slot(l); }
@@ -438,10 +446,11 @@ struct GcnCtx {
 };
 // bound of Z_l, the aggregate of layer l's input (features or H_{l-1}): the A operand of the forward GEMM and of the weight gradient
 static bool in_bound(const GcnCtx& c, int l, gm_bound& bd) {
+    bd = gm_no_bound();
     if (c.np != 2 || c.am_pass < 0 || !c.b->d_gain) return false;
     if (l == 0) {
-        if (c.x0_user || !c.b->store->d_feat_amax) return false;
-        bd.amax = c.b->store->d_feat_amax; bd.stride = 0;
+        if (c.x0_user || !c.feat_bound) return false;
+        bd.amax = c.feat_bound; bd.stride = 1;
     } else {
         if (!c.hv[l - 1]) return false;
         bd.amax = c.amH(l - 1); bd.stride = GM_BOUND_PAD;
@@ -451,6 +460,7 @@ static bool in_bound(const GcnCtx& c, int l, gm_bound& bd) {
 }
 // bound of dQ_l (the gradient at layer l's output): from the head for the last layer, else relu' * norm * A^T T_{l+1}
 static bool dq_bound(const GcnCtx& c, int l, gm_bound& bd) {
+    bd = gm_no_bound();
     if (c.np != 2 || c.am_pass < 0 || !c.b->d_gain) return false;
     if (l == c.L.n_gcn - 1) { if (!c.dqv) return false; bd.amax = c.amdQ(); bd.gain = nullptr; }
     else { if (!c.tv[l + 1]) return false; bd.amax = c.amT(l + 1); bd.gain = c.b->d_gain + 1; }
@@ -576,7 +586,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
-            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0, st); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st)); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
@@ -590,7 +600,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                               // row) nearly every row still goes through the ordinary aggregate and the gather feeders only cost (3.30 -> 3.21 ms)
                               2 * b->unfused_rows <= b->rows;
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 0, st); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 if (fuse) {
@@ -684,7 +694,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         if (l > 0) w.partial = c.partial_l[l];
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1, st); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st)); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -743,7 +753,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             if (kn) { c.pd->valid[kn][l][0] = w.pl_fwd != nullptr; c.pd->valid[kn][l][1] = w.pl_dz != nullptr; }
             if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
             if (l > 0) {
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; gm_agg_hub(a, b, 1, st); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st)); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
@@ -1158,7 +1168,9 @@ struct MetaPlan {
     float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq, *theta_p;
     PlaneDir pd;
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
-    int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q]
+    int32_t *rows_s, *rows_q, *tab_s, *tab_q;     // class tables: one contiguous block [rows_s | rows_q | tab_s | tab_q | featb_s | featb_q]
+    unsigned *featb_s, *featb_q;                  // [T] each: per-task bound of the layer-1 operand (fp32 bit patterns; rides in the class-table copy)
+    unsigned* viol;                               // the step's violation word (gm_bound.h), zeroed with the bound slots; NULL without two-piece kernels
     int Ct, ns, nq;
     unsigned* bound_ws; int64_t bound_words;      // gm_bound.h slots of this step ([S passes | Q passes | weights]), zeroed by ONE memset; NULL: three-piece kernels
 };
@@ -1185,9 +1197,10 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     p.ls = cv.take<float>((int64_t)p.T * K1); p.as_ = cv.take<float>((int64_t)p.T * K1);
     p.lq = cv.take<float>((int64_t)p.T * K1); p.aq = cv.take<float>((int64_t)p.T * K1);
     {   // rows of a set never exceed its subgraphs: [rows_s (spt->subs) | rows_q (qry->subs) | tab_s (3T) | tab_q (3T)]
-        int32_t* blk = cv.take<int32_t>((int64_t)spt->subs + qry->subs + 6 * (int64_t)p.T);
+        int32_t* blk = cv.take<int32_t>((int64_t)spt->subs + qry->subs + 8 * (int64_t)p.T);
         p.rows_s = blk; p.rows_q = blk ? blk + spt->subs : nullptr;
         p.tab_s = blk ? p.rows_q + qry->subs : nullptr; p.tab_q = blk ? p.tab_s + 3 * p.T : nullptr;
+        p.featb_s = blk ? reinterpret_cast<unsigned*>(p.tab_q + 3 * p.T) : nullptr; p.featb_q = blk ? p.featb_s + p.T : nullptr;
     }
     gcn_carve(p.S, cv); gcn_carve(p.Q, cv);
     // split-bf16 planes of every fast-weight vector (dense schedule, layers the split GEMM can take): forward planes for every such
@@ -1209,19 +1222,20 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
         }
     }
     // two-piece fp16 split kernels: when the weight planes are kept, every GCN layer is aggregate-first and the dense schedule runs
-    p.bound_ws = nullptr; p.bound_words = 0;
+    p.bound_ws = nullptr; p.bound_words = 0; p.viol = nullptr;
     bool agg_first = true;
     for (int l = 0; l < p.L.n_gcn; ++l) agg_first = agg_first && p.L.dims[l] <= p.L.dims[l + 1];
     if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->d_gain && qry->d_gain && spt->store->d_feat_amax &&
         spt->rows + qry->rows >= gm_knob().split16_min_rows) {
         const int per_pass = 2 * p.L.n_gcn + 1;
         const int64_t ws_s = (int64_t)p.K * per_pass * p.T * GM_BOUND_PAD, ws_q = (int64_t)K1 * per_pass * p.T * GM_BOUND_PAD, ws_w = (int64_t)p.L.n_gcn * GM_BOUND_PAD;
-        p.bound_words = ws_s + ws_q + ws_w;
+        p.bound_words = ws_s + ws_q + ws_w + GM_BOUND_PAD;                   // (+ the violation word, on a line of its own)
         p.bound_ws = cv.take<unsigned>(p.bound_words);
         if (!p.bound_ws) p.bound_ws = reinterpret_cast<unsigned*>(16);       // sizing pass
         p.S.np = p.Q.np = 2;
         p.S.am = p.bound_ws; p.S.am_passes = p.K; p.Q.am = p.bound_ws + ws_s; p.Q.am_passes = K1;
         p.pd.wam = p.bound_ws + ws_s + ws_q;
+        p.viol = p.pd.wam + ws_w; p.pd.viol = p.viol;
     }
     p.Ct = Ct; p.ns = ns; p.nq = nq;
     if (need) *need = cv.used + 256;
@@ -1240,12 +1254,14 @@ extern "C" int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry
 extern "C" int64_t gm_meta_out_floats(const gm_batch_t* spt, const gm_model_t* m, const gm_hparams_t* hp) {
     gm_layout L;
     if (!spt || !hp || gm_make_layout(m, &L) != GM_OK) return -1;
-    return L.P + 2 * (int64_t)(hp->update_step + 1) + 1 + (int64_t)spt->sets * (hp->update_step + 1);
+    return L.P + 2 * (int64_t)(hp->update_step + 1) + 1 + (int64_t)spt->sets * (hp->update_step + 1) + 1;
 }
 
 extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_spt, const int32_t* y_qry, const gm_model_t* m,
-                            const gm_hparams_t* hp, const float* theta, float* out, void* ws, int64_t ws_bytes, void* stream) {
+                            const gm_hparams_t* hp, const float* theta, float* out, int64_t out_floats, void* ws, int64_t ws_bytes, void* stream) {
     GM_REQUIRE(spt && qry && y_spt && y_qry && m && hp && theta && out && ws, GM_EINVAL, "meta_step: NULL argument");
+    GM_REQUIRE(out_floats >= gm_meta_out_floats(spt, m, hp), GM_ENOMEM, "meta_step: out holds %lld floats, the step writes %lld", (long long)out_floats,
+               (long long)gm_meta_out_floats(spt, m, hp));
     GM_REQUIRE(spt->sets == qry->sets, GM_EINVAL, "meta_step: %d support sets but %d query sets", spt->sets, qry->sets);
     GM_REQUIRE(spt->store == qry->store, GM_EINVAL, "meta_step: support and query batches come from different stores");
     const int K = hp->update_step;
@@ -1275,7 +1291,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         theta = p.theta_p;
     }
     {   // class tables -> pinned staging -> ONE asynchronous copy (no host synchronisation in the meta-step)
-        const size_t n_tab = (size_t)spt->subs + qry->subs + 6 * (size_t)T;
+        const size_t n_tab = (size_t)spt->subs + qry->subs + 8 * (size_t)T;
         void* h = nullptr; int slot = 0;
         StageRing& ring = stage_ring();
         GM_TRY(ring.acquire(4 * n_tab, &h, &slot));
@@ -1285,6 +1301,27 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         memcpy(hp32 + spt->subs, cq.rows.data(), 4 * cq.rows.size());
         memcpy(hp32 + spt->subs + qry->subs, cs.tab.data(), 4 * cs.tab.size());
         memcpy(hp32 + spt->subs + qry->subs + 3 * (size_t)T, cq.tab.data(), 4 * cq.tab.size());
+        if (p.bound_ws) {
+            // two-piece kernels: the layer-1 operand of task t is bounded by the largest feature of the graphs its subgraphs come from; a batch
+            // that touches a loose table (gm_store::h_feat_mean) keeps the three-piece kernels for every pass over it
+            const gm_store* sto = spt->store;
+            int k = 0;
+            for (const gm_batch* bb : {spt, qry}) {
+                float* fb = reinterpret_cast<float*>(hp32 + spt->subs + qry->subs + 6 * (size_t)T) + (size_t)(k++) * T;
+                bool loose = false;
+                for (int t = 0; t < T; ++t) {
+                    float mx = 0.f;
+                    for (int sg = bb->h_set_sub_off[t]; sg < bb->h_set_sub_off[t + 1]; ++sg) {
+                        const int gi = bb->h_graph[sg];
+                        const float a = sto->h_feat_amax[gi], mean = sto->h_feat_mean[gi];
+                        if (!(a <= 1.125899906842624e15f) || a > 16384.f * mean) loose = true;          // (2^50; 2^14 above the typical entry)
+                        mx = a > mx ? a : mx;
+                    }
+                    fb[t] = mx;
+                }
+                (bb == spt ? p.S : p.Q).feat_bound = loose ? nullptr : (bb == spt ? p.featb_s : p.featb_q);
+            }
+        }
         GM_HIP(hipMemcpyAsync(p.rows_s, h, 4 * n_tab, hipMemcpyHostToDevice, st));
         GM_TRY(ring.release_after(slot, st));
     }
@@ -1382,7 +1419,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     st = st0;
     const int64_t tot = Lu.P + 2 * K1 + 1 + (int64_t)T * K1;
     hipLaunchKernelGGL(k_finalize, dim3((int)std::min<int64_t>(1024, (tot + 255) / 256)), dim3(256), 0, st,
-                       have_grad ? p.gq : nullptr, p.gp, Pp, Lu.P, T, p.lq, p.aq, K1, out, cut, shift);
+                       have_grad ? p.gq : nullptr, p.gp, Pp, Lu.P, T, p.lq, p.aq, K1, out, cut, shift, p.viol);
     GM_HIP(hipGetLastError());
     gm_batch_mark_use(spt, st); gm_batch_mark_use(qry, st);
     return GM_OK;

@@ -1,5 +1,6 @@
 // GraphStore: parent graphs (in-edge CSR + derived out-edge CSR) and node features resident in HBM.
 // Replaces the pickled DGLGraph list and the `feat` list of train.py:41-44,63-65.
+#include <math.h>
 #include "gm_internal.h"
 
 extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const int64_t* const* indptr,
@@ -78,6 +79,17 @@ extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const i
                         (size_t)feat_dim * sizeof(float), (size_t)n_nodes[g], hipMemcpyHostToDevice) != hipSuccess) {
             gm_set_error("gm_store_create: feature upload failed"); rc = GM_EHIP;
         }
+    }
+    s->h_feat_amax.assign(n_graphs, 0.f); s->h_feat_mean.assign(n_graphs, 0.f);
+    for (int g = 0; g < n_graphs; ++g) {
+        float mx = 0.f; double sum = 0.0; int64_t nz = 0;
+        const float* f = feat[g];
+        for (int64_t i = 0, n = n_nodes[g] * (int64_t)feat_dim; i < n; ++i) {
+            const float a = fabsf(f[i]);
+            if (!(a <= 3.0e38f)) { mx = INFINITY; continue; }                  // inf / NaN entry: never the two-piece kernels
+            if (a > 0.f) { mx = a > mx ? a : mx; sum += a; ++nz; }
+        }
+        s->h_feat_amax[g] = mx; s->h_feat_mean[g] = nz ? (float)(sum / (double)nz) : 0.f;
     }
     if (rc == GM_OK) rc = gm_dev_alloc((void**)&s->d_feat_amax, sizeof(unsigned), st);
     if (rc == GM_OK && hipMemset(s->d_feat_amax, 0, sizeof(unsigned)) != hipSuccess) { gm_set_error("gm_store_create: memset failed"); rc = GM_EHIP; }

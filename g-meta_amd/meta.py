@@ -5,6 +5,7 @@ torch.distributed is initialised each rank passes ITS shard of the meta-batch an
 meta-gradient is summed by one all-reduce (RCCL over xGMI on MI355X) before the NaN guard and Adam."""
 import ctypes as C
 import copy
+import weakref
 
 import numpy as np
 import torch
@@ -128,7 +129,8 @@ class Meta(nn.Module):
         return self._ws
 
     def _run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
-        """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + 1 + T(K+1)], P, T)."""
+        """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + 1 + T(K+1) + 1], P, T); the last float is the
+        violation word of the opt-in two-piece kernels (0 = none, see include/gmeta_hip.h)."""
         _lib.require_gpu()
         lib = _lib.lib()
         theta = self._flat_theta()
@@ -138,7 +140,7 @@ class Meta(nn.Module):
         model = self.net.model
         P = int(lib.gm_model_param_count(C.byref(model)))
         if len(x_spt) == 0:               # an empty task shard (more ranks than tasks in a trailing meta-batch): contributes zeros
-            return torch.zeros(P + 2 * (K + 1) + 1, dtype=torch.float32, device=dev), P, 0
+            return torch.zeros(P + 2 * (K + 1) + 2, dtype=torch.float32, device=dev), P, 0
         for b in x_spt:
             if not isinstance(b, SubgraphBatch):
                 raise TypeError('x_spt / x_qry must be lists of gmeta_amd.SubgraphBatch (from gmeta_amd.Subgraphs)')
@@ -156,23 +158,25 @@ class Meta(nn.Module):
         if hpc is None or hpc[0] != hk:
             self._hp = hpc = (hk, _lib.HParams(*hk))
         hp = hpc[1]
-        # output / workspace sizes depend on the batches' shapes and the hyper-parameters only: remembered per (batch pair, hparams) -- two FFI
-        # calls (one of them a full planning pass) less on the host path between the read-back of one step and the first launch of the next
-        key = (id(S), id(Q), S.rows, Q.rows, S.subs, Q.subs, int(K), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd), int(self.cone),
-               int(lib.gm_get_gemm_mode()), int(lib.gm_get_split_pieces()))
-        sizes = getattr(self, '_sizes', None)
-        if sizes is None or sizes[0] != key:
+        # output / workspace sizes depend on the two batches (their launch tables, not only their shapes), the model and the hyper-parameters:
+        # remembered ON the support batch object, together with a weak reference to the query batch they were computed for (ids of freed
+        # objects are recycled; a dead or different partner recomputes) -- two FFI calls (one of them a full planning pass) less on the host
+        # path between the read-back of one step and the first launch of the next
+        key = (S.rows, Q.rows, S.subs, Q.subs, S.sets, Q.sets, P, int(K), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd),
+               int(self.cone), int(lib.gm_get_gemm_mode()), int(lib.gm_get_split_pieces()))
+        sizes = getattr(S, '_meta_sizes', None)
+        if sizes is None or sizes[0] != key or sizes[1]() is not Q:
             n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))
             ws_bytes = int(lib.gm_meta_ws_bytes(S.handle, Q.handle, C.byref(model), C.byref(hp)))
             if ws_bytes < 0 or n_out < 0:
                 _lib.check(-1, 'gm_meta_ws_bytes')
-            self._sizes = (key, n_out, ws_bytes)
+            S._meta_sizes = (key, weakref.ref(Q), n_out, ws_bytes)
         else:
-            n_out, ws_bytes = sizes[1], sizes[2]
+            n_out, ws_bytes = sizes[2], sizes[3]
         ws = self._workspace(ws_bytes, dev)
         out = torch.empty(n_out, dtype=torch.float32, device=dev)
         _lib.check(lib.gm_meta_step(S.handle, Q.handle, _lib.ptr(ys), _lib.ptr(yq), C.byref(model), C.byref(hp), _lib.ptr(theta),
-                                    _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'gm_meta_step')
+                                    _lib.ptr(out), out.numel(), _lib.ptr(ws), ws.numel(), _lib.stream_ptr()), 'gm_meta_step')
         self._keep = (S, Q)             # keep concatenated batches alive until the stream has consumed them
         return out, P, T
 
@@ -193,6 +197,9 @@ class Meta(nn.Module):
                              'so the reference cannot back-propagate with fewer steps')
         out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, True)
         K1 = K + 1
+        self._issued = getattr(self, '_issued', 0) + 1
+        two_piece = _lib.lib().gm_get_split_pieces() == 2    # opt-in fast mode: a violation of its bounds re-runs the step (see _Deferred.accs)
+        rerun = (self._issued, x_spt, y_spt, x_qry, y_qry) if two_piece else None
         head = out[:P + 2 * K1 + 1]                           # [grad | losses_q | corrects | task count], contiguous view
         if self._dist_on() and (torch.distributed.get_world_size() > 1 or getattr(self, 'force_allreduce', False)):
             # Round 2 drained the compute stream before the all-reduce (a +7 ms slow wait path when the collective was queued behind work on a
@@ -216,11 +223,11 @@ class Meta(nn.Module):
             self.meta_optim.found_inf = self._found_inf
             self.meta_optim.grad_scale = None
             self.meta_optim.step()
-            return _Deferred(self, head[P:], K1, applied=True)
+            return _Deferred(self, out[P:], K1, applied=True, rerun=rerun)
         # Non-fused Adam (optim.Adam(fused=True) unavailable) or CPU tensors: the NaN guard needs the loss on the host, so the update is
         # applied HERE -- every meta-batch steps the optimiser like meta.py:163-169, whether or not the caller ever reads the
         # accuracies (train.py only reads them on report steps); only the handle's bookkeeping is left for .accs()
-        d = _Deferred(self, head, K1, applied=False, P=P)
+        d = _Deferred(self, out, K1, applied=False, P=P, rerun=rerun)
         d.accs()
         return d
 
@@ -230,9 +237,24 @@ class Meta(nn.Module):
     # ---- meta.py:175-234
     def finetunning_ProtoMAML(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
         K = self.update_step_test
-        out, P, T = self._run(x_spt[:1], y_spt[:1], x_qry[:1], y_qry[:1], K, False)      # `[0]` of every argument (meta.py:182-191)
         K1 = K + 1
-        return out[P + 2 * K1 + 1:P + 3 * K1 + 1].cpu().numpy().astype(np.float64)
+        return self._eval_accs(x_spt[:1], y_spt[:1], x_qry[:1], y_qry[:1], K)[0]        # `[0]` of every argument (meta.py:182-191)
+
+    def _eval_accs(self, x_spt, y_spt, x_qry, y_qry, K):
+        """Per-task accuracies [T, K+1] of a forward-only gm_meta_step (host array).  With the opt-in two-piece kernels a step whose bounds
+        were violated (last float of `out`) is run again with the three-piece kernels: the reference's fp32 path has no such limit."""
+        K1 = K + 1
+        out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
+        tail = out[P + 2 * K1 + 1:].cpu().numpy().astype(np.float64)
+        if tail[-1] != 0.0:
+            lib = _lib.lib()
+            lib.gm_set_split_pieces(3)
+            try:
+                out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
+                tail = out[P + 2 * K1 + 1:].cpu().numpy().astype(np.float64)
+            finally:
+                lib.gm_set_split_pieces(2)
+        return tail[:T * K1].reshape(T, K1)
 
     def finetunning_batch(self, x_spt, y_spt, x_qry, y_qry, shard=False):
         """All given evaluation tasks in ONE call (the reference loops 100 val/test tasks one at a time,
@@ -244,13 +266,13 @@ class Meta(nn.Module):
         n = len(x_spt)
         world = torch.distributed.get_world_size() if (shard and self._dist_on()) else 1
         if world == 1 and not (shard and self._dist_on() and getattr(self, 'force_allreduce', False)):
-            out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, False)
-            return out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1).cpu().numpy().astype(np.float64)
+            return self._eval_accs(x_spt, y_spt, x_qry, y_qry, K)
         rank = torch.distributed.get_rank()
         bounds = np.linspace(0, n, world + 1).round().astype(int)
         lo, hi = int(bounds[rank]), int(bounds[rank + 1])
-        out, P, T = self._run(x_spt[lo:hi], y_spt[lo:hi], x_qry[lo:hi], y_qry[lo:hi], K, False)
-        mine = out[P + 2 * K1 + 1:P + 2 * K1 + 1 + T * K1].view(T, K1)
+        dev = self.net.parameters()[0].device
+        mine = torch.from_numpy(self._eval_accs(x_spt[lo:hi], y_spt[lo:hi], x_qry[lo:hi], y_qry[lo:hi], K)).to(dev, torch.float32) if hi > lo \
+            else torch.zeros(0, K1, dtype=torch.float32, device=dev)
         return gather_rows(mine, bounds, K1).cpu().numpy().astype(np.float64)
 
     def forward(self, x_spt, y_spt, x_qry, y_qry, c_spt, c_qry, n_spt, n_qry, g_spt, g_qry, feat):
@@ -284,23 +306,49 @@ def gather_rows(mine, bounds, width):
 
 class _Deferred:
     """Result handle of Meta.forward_deferred: .accs() reads losses/accuracies back (the only device->host sync of a
-    meta-step) and returns np.array(corrects) / task_num (meta.py:171)."""
+    meta-step) and returns np.array(corrects) / task_num (meta.py:171).
 
-    def __init__(self, meta, buf, K1, applied, P=0):
-        self._meta, self._buf, self._K1, self._applied, self._P = meta, buf, K1, applied, P
+    Opt-in two-piece kernels only (gm_set_split_pieces(2)): the read-back also carries the step's violation word.  A violated bound (a fast
+    weight that outgrew the step's weight bound, an operand maximum beyond the scale range) made gm_meta_step report a NaN query loss, so
+    the optimiser step was skipped on every rank; the step is then run AGAIN with the three-piece kernels (rerun = the step's inputs) --
+    the reference's fp32 arithmetic has no such limit and only skips on a true NaN (meta.py:163-169)."""
+
+    def __init__(self, meta, buf, K1, applied, P=0, rerun=None):
+        self._meta, self._buf, self._K1, self._applied, self._P, self._rerun = meta, buf, K1, applied, P, rerun
         self._accs = None
 
     def accs(self):
         if self._accs is not None:
             return self._accs
         m, K1 = self._meta, self._K1
-        if self._applied:                                     # device path: Adam already queued, buf = [losses_q | corrects | count]
+        if self._applied:                                     # device path: Adam already queued, buf = [losses_q | corrects | count | per-task | violation]
             tail = self._buf.cpu().numpy().astype(np.float64)
         else:                                                 # host path (non-fused Adam / CPU tensors): guard + step here
             head, P = self._buf, self._P
             tail = head[P:].cpu().numpy().astype(np.float64)
-        task_num = float(tail[-1])
+        task_num = float(tail[2 * K1])
         loss_q = tail[K1 - 1] / task_num                      # losses_q[-1] / task_num (meta.py:161)
+        if self._rerun is not None and np.isnan(loss_q):
+            viol = float(tail[-1])
+            if m._dist_on() and torch.distributed.get_world_size() > 1:      # every rank sees the NaN of the reduced loss: agree on its cause
+                v = torch.tensor([viol], dtype=torch.float32, device=self._buf.device)
+                torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
+                viol = float(v.item())
+            if viol != 0.0:
+                issued, x_spt, y_spt, x_qry, y_qry = self._rerun
+                self._rerun = None
+                if getattr(m, '_issued', 0) != issued:
+                    raise RuntimeError('gmeta_amd: a bound of the two-piece kernels was violated in a meta-step whose read-back was deferred past the next '
+                                       'step; re-run with GM_SPLIT_PIECES=3 (the default) or read .accs() before queueing the next step')
+                lib = _lib.lib()
+                lib.gm_set_split_pieces(3)
+                try:
+                    self._accs = m.forward_deferred(x_spt, y_spt, x_qry, y_qry).accs()
+                finally:
+                    lib.gm_set_split_pieces(2)
+                m.last_stats['rerun_three_piece'] = viol
+                self._buf = None
+                return self._accs
         m.last_stats = {'loss_q': loss_q, 'losses_q': tail[:K1] / task_num, 'task_num': task_num}
         if not self._applied and not np.isnan(loss_q):        # meta.py:163-169
             fg = m._bind_grads(head.device)
@@ -308,4 +356,5 @@ class _Deferred:
             m.meta_optim.step()
         self._accs = tail[K1:2 * K1] / task_num               # np.array(corrects) / task_num (meta.py:171)
         self._buf = None
+        self._rerun = None
         return self._accs

@@ -180,20 +180,22 @@ int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32_t n_out, c
  * Meta.finetunning_ProtoMAML (meta.py:175-234) when 0, for ALL sets (tasks) of spt/qry at once.
  * spt and qry must have the same number of sets; set t of each is task t.  y_spt / y_qry: HOST
  * int32 labels per subgraph.  theta: device fp32 [P] (read only).
- * out: device fp32 [P + 2*(K+1) + 1 + sets*(K+1)]:
+ * out: device fp32 [P + 2*(K+1) + 1 + sets*(K+1) + 1] (= gm_meta_out_floats; out_floats is the capacity the caller allocated, checked):
  *   [0,P)            SUM over tasks of the first-order meta-gradient (query path at fw_K + prototype
  *                    path through the support forward at fw_{K-1}); zeros when need_meta_grad = 0
  *   [P, P+K+1)       SUM over tasks of losses_q[k]   (meta.py:133,140,155)
  *   [P+K+1, P+2K+2)  SUM over tasks of corrects[k]   (meta.py:134,141,157)
  *   [P+2K+2]         the number of tasks (sets) in this call, as a float (rides along with the all-reduce)
  *   [P+2K+3, ...)    per-task query accuracy [sets, K+1]
+ *   [last]           violation word of the opt-in two-piece kernels as a float (0 = none; gm_set_split_pieces): when non-zero, losses_q[K]
+ *                    above is NaN -- the step is skipped like a NaN loss on every rank -- and the caller re-runs it with three pieces
  * The caller divides by the (global) task count, applies the NaN guard (meta.py:163) and the
  * optimiser -- after the RCCL all-reduce when tasks are sharded over GPUs. */
 int64_t gm_meta_ws_bytes(const gm_batch_t* spt, const gm_batch_t* qry, const gm_model_t* m, const gm_hparams_t* hp);
 int64_t gm_meta_out_floats(const gm_batch_t* spt, const gm_model_t* m, const gm_hparams_t* hp);
 int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_spt, const int32_t* y_qry,
-                 const gm_model_t* m, const gm_hparams_t* hp, const float* theta, float* out, void* ws,
-                 int64_t ws_bytes, void* stream);
+                 const gm_model_t* m, const gm_hparams_t* hp, const float* theta, float* out, int64_t out_floats,
+                 void* ws, int64_t ws_bytes, void* stream);
 
 /* After the (optional) all-reduce of out[0 .. P + 2*(K+1)] over the ranks: the mean meta-gradient and the NaN guard of
  * meta.py:161-163, on the device.  head: device, the reduced block; grad: device fp32 [P] <- head[0..P) / task count;
@@ -201,19 +203,25 @@ int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_
  * is the reference's `if torch.isnan(loss_q): pass`).  K1 = update_step + 1. */
 int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream);
 
-/* Update-GEMM arithmetic.  mode 0: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere.  mode 1 (default): large N = 256 launches run
- * on the bf16 matrix cores with every fp32 operand split EXACTLY into three bf16 pieces and the six products of weight >= 2^-16
- * accumulated in fp32 (dropped terms <= 1.2e-7 |a||b|: the result is within one fp32 rounding per product of the exact one;
- * measured error against fp64 <= the fmaf chain's).  Also settable with the environment variable GM_GEMM_MODE=f32|split.
- * Inside gm_meta_step (dense schedule, aggregate-first layers) the split kernels take TWO fp16 pieces per operand instead -- three
- * products a_h b_h + a_h b_m + a_m b_h under per-task power-of-two scales derived from magnitude bounds that the producing kernels
- * record on the device (csrc/gm_bound.h): 22 significand bits per operand, dropped terms <= ~2^-21 |a||b| per product against the
- * K roundings of 2^-24 |sum| an fp32 dot product of length K makes; measured error against fp64 below the fp32 fmaf chain's
- * (tests/test_hip_gemm_numerics.py).  GM_SPLIT_PIECES=3 keeps the three-piece bf16 kernels everywhere; gm_get_split_pieces() = 2 or 3. */
+/* Update-GEMM arithmetic (the reference multiplies in fp32: torch.matmul(feat, weight), learner.py:36,47).
+ * mode 0: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere.  mode 1 (default): large N = 128 / 256 launches run on the bf16 matrix cores
+ * with every fp32 operand split EXACTLY into three bf16 pieces (8 + 8 + 8 significand bits: all 24 bits of both operands enter the
+ * product) and the six products of weight >= 2^-16 accumulated in fp32 (dropped terms <= 1.2e-7 |a||b|: within one fp32 rounding per
+ * product of the exact one; measured error against fp64 <= the fmaf chain's).  Also settable with GM_GEMM_MODE=f32|split.
+ * gm_set_split_pieces(2) / GM_SPLIT_PIECES=2 is an OPT-IN fast mode, never the default: inside gm_meta_step (dense schedule,
+ * aggregate-first layers) the split kernels then take TWO fp16 pieces per operand -- 22 significand bits, i.e. NARROWER than the
+ * reference's fp32 operands -- with three products a_h b_h + a_h b_m + a_m b_h under per-task power-of-two scales derived from magnitude
+ * bounds that the producing kernels record on the device (csrc/gm_bound.h).  Its guards: a feature table whose largest entry sits more
+ * than 2^14 above its mean magnitude keeps the three-piece kernels for layer 1; a fast weight that outgrows the step's weight bound is
+ * detected on the device and reported in the last float of gm_meta_step's `out` (the host mirror then re-runs the step three-piece).
+ * gm_get_split_pieces() = 2 or 3. */
 void gm_set_gemm_mode(int32_t mode);
 int32_t gm_get_gemm_mode(void);
-void gm_set_split_pieces(int32_t pieces);   /* 2, 3, or -1 = back to the environment variable */
+void gm_set_split_pieces(int32_t pieces);   /* 2, 3, or -1 = back to the environment variable (default 3) */
 int32_t gm_get_split_pieces(void);
+/* Tuning knob by the name of its environment variable, after start-up; GM_EINVAL for unknown names.  Tests use it to
+ * force the large-launch kernels onto small fixtures (GM_GEMM_SPLIT_MIN_TILES, GM_SPLIT16_MIN_ROWS); not synchronised with concurrent calls. */
+int gm_set_tuning(const char* name, int32_t value);
 
 /* Fused aggregate + update for forward passes nobody differentiates (the query evaluations of the inner steps in gm_meta_step,
  * i.e. meta.py:129-141,152-154 before the last step, and every query pass of finetunning): rows with one or two sources are

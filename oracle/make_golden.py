@@ -18,6 +18,11 @@ Cases:
   g3_linkpred      Shared link-pred on directed graphs (captures the sdp.py:332 quirk)
   g5_in_gt_out     F0=96 > H=32: matmul-first branch of GraphConv (learner.py:34-40)
   g6_nan_skip      inf feature -> NaN query loss -> optimiser step skipped (meta.py:163-169)
+  g7_wide_h2       hidden 128 (F0 = 64), h=2, sample_nodes=60: layers wide enough for the split-MFMA update kernels (N = 128), which the
+                   GPU tests force onto this fixture (gm_set_tuning) -- the reference's own outputs for the arithmetic bench.py times
+  g8_wide_scales   Shared, 3 graphs whose features are scaled by 2^-20, 2^-8, 2^4 (hidden 128): tasks of very different magnitude in one
+                   meta-batch -- the case a per-tensor operand scale must not lose precision on
+  g9_wide_nan      hidden 128 with an inf feature table: NaN query loss -> no optimiser step, through the wide kernels
 Every case also records Meta.finetunning on task 0 (G4).
 """
 import sys
@@ -210,19 +215,18 @@ def node_case(name, n, m, F0, H, n_cls, args, T, seed, hub_inf=False):
     run_case(name, [(n, src, dst)], [feat], info, {'train.csv': (names, [str(l) for l in lab])}, args, config, T)
 
 
-def shared_case(name, T, seed):
+def shared_case(name, T, seed, F0=10, H=16, scales=None, update_lr=0.05):
     rng = np.random.default_rng(seed)
     graphs, feats, names, labels, info = [], [], [], [], {}
-    F0, H = 10, 16
     for g in range(3):
         n = 120 + 20 * g
         e = pa_edges(n, 2, rng)
         graphs.append((n, np.concatenate([e[:, 0], e[:, 1]]), np.concatenate([e[:, 1], e[:, 0]])))
-        feats.append(rng.standard_normal((n, F0)).astype(np.float32))
+        feats.append((rng.standard_normal((n, F0)) * (scales[g] if scales else 1.0)).astype(np.float32))
         lab = rng.integers(0, 2, size=n)
         for v in range(n):
             nm = '%d_%d' % (g, v); names.append(nm); labels.append(str(lab[v])); info[nm] = int(lab[v])
-    args = ns(task_setup='Shared', n_way=2, k_spt=3, k_qry=5, task_num=T, update_step=4, update_step_test=3, update_lr=0.05)
+    args = ns(task_setup='Shared', n_way=2, k_spt=3, k_qry=5, task_num=T, update_step=4, update_step_test=3, update_lr=update_lr)
     config = [('GraphConv', [F0, H]), ('GraphConv', [H, H]), ('Linear', [H, 2])]     # C = total_class (train.py:61)
     run_case(name, graphs, feats, info, {'train.csv': (names, labels)}, args, config, T)
 
@@ -261,11 +265,20 @@ def linkpred_case(name, T, seed):
 
 
 if __name__ == '__main__':
-    node_case('g0_disjoint_h1', 300, 3, 32, 64, 10,
-              ns(h=1, n_way=2, k_spt=1, k_qry=5, task_num=4, update_step=5, update_step_test=10, update_lr=0.001), 4, 1)
-    node_case('g1_sampled_h2', 400, 4, 16, 24, 6, ns(h=2, sample_nodes=30, update_step=3, update_lr=0.1), 2, 2)
-    node_case('g1_h3', 250, 2, 12, 16, 5, ns(h=3, update_step=2, update_step_test=2, update_lr=0.05), 2, 3)
-    shared_case('g2_shared', 3, 4)
-    linkpred_case('g3_linkpred', 2, 5)
-    node_case('g5_in_gt_out', 200, 3, 96, 32, 5, ns(h=2, update_step=3, update_lr=0.05), 2, 6)
-    node_case('g6_nan_skip', 150, 3, 8, 8, 5, ns(h=1, update_step=2, update_step_test=2), 2, 7, hub_inf=True)
+    only = set(sys.argv[1:])            # optional: names of the cases to (re)generate; default all
+    cases = [
+        ('g0_disjoint_h1', lambda nm: node_case(nm, 300, 3, 32, 64, 10,
+                                                ns(h=1, n_way=2, k_spt=1, k_qry=5, task_num=4, update_step=5, update_step_test=10, update_lr=0.001), 4, 1)),
+        ('g1_sampled_h2', lambda nm: node_case(nm, 400, 4, 16, 24, 6, ns(h=2, sample_nodes=30, update_step=3, update_lr=0.1), 2, 2)),
+        ('g1_h3', lambda nm: node_case(nm, 250, 2, 12, 16, 5, ns(h=3, update_step=2, update_step_test=2, update_lr=0.05), 2, 3)),
+        ('g2_shared', lambda nm: shared_case(nm, 3, 4)),
+        ('g3_linkpred', lambda nm: linkpred_case(nm, 2, 5)),
+        ('g5_in_gt_out', lambda nm: node_case(nm, 200, 3, 96, 32, 5, ns(h=2, update_step=3, update_lr=0.05), 2, 6)),
+        ('g6_nan_skip', lambda nm: node_case(nm, 150, 3, 8, 8, 5, ns(h=1, update_step=2, update_step_test=2), 2, 7, hub_inf=True)),
+        ('g7_wide_h2', lambda nm: node_case(nm, 500, 4, 64, 128, 6, ns(h=2, sample_nodes=60, update_step=3, update_lr=0.05), 2, 8)),
+        ('g8_wide_scales', lambda nm: shared_case(nm, 3, 9, F0=32, H=128, scales=(2.0 ** -20, 2.0 ** -8, 2.0 ** 4), update_lr=1e-3)),
+        ('g9_wide_nan', lambda nm: node_case(nm, 200, 3, 32, 128, 5, ns(h=2, update_step=2, update_step_test=2), 2, 10, hub_inf=True)),
+    ]
+    for nm, fn in cases:
+        if not only or nm in only:
+            fn(nm)

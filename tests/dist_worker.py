@@ -38,7 +38,7 @@ def main():
     def oracle_run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
         theta = [p.detach().numpy().copy() for p in self.net.parameters()]
         P = sum(t.size for t in theta); K1 = K + 1; T = len(x_spt)
-        out = np.zeros(P + 2 * K1 + 1 + T * K1, np.float32)             # T == 0 (empty shard): all zeros, like Meta._run
+        out = np.zeros(P + 2 * K1 + 1 + T * K1 + 1, np.float32)         # T == 0 (empty shard): all zeros, like Meta._run; last float = violation word (0)
         for t in range(T):
             with np.errstate(all='ignore'):
                 lq, aq, mg = orc.task_inner_loop(x_spt[t], x_qry[t], x_spt[t].features(fx.feats), x_qry[t].features(fx.feats), np.asarray(y_spt[t]),
