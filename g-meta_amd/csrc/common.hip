@@ -178,6 +178,7 @@ const gm_knobs& gm_knob() {
         k.split_pieces = env("GM_SPLIT_PIECES", 3);                   // 3: every operand carries its full 24 significand bits (the reference multiplies in fp32, learner.py:36,47); 2 = opt-in fast mode
         k.split16_min_rows = env("GM_SPLIT16_MIN_ROWS", 65536);
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
+        k.wgrad_split_min_chunks = env("GM_WGRAD_SPLIT_MIN_CHUNKS", -1);
     });
     return k;
 }
@@ -193,7 +194,7 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
         {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
         {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage},
-        {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
+        {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)
         if (!strcmp(name, e.name)) { g_knobs.*(e.field) = value; return GM_OK; }

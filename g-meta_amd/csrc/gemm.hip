@@ -1278,7 +1278,7 @@ static bool wgrad_fast_ok(const gm_wgrad_args& a) {
 // exact 3-way bf16 split of both operands, fp32 accumulation (k_wgrad_split): the same arithmetic as the split GEMM
 static bool wgrad_takes_split(const gm_wgrad_args& a) {
     const int wsplit = gm_knob().wgrad_split;
-    return a.n_chunks > 0 && wgrad_fast_ok(a) && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= gm_num_cus() / 4 && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256);
+    return a.n_chunks > 0 && wgrad_fast_ok(a) && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= (gm_knob().wgrad_split_min_chunks >= 0 ? gm_knob().wgrad_split_min_chunks : gm_num_cus() / 4) && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256);
 }
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const int cat = wgrad_takes_split(a) ? ((a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? GM_PROF_WGRAD_SPLIT16 : GM_PROF_WGRAD_SPLIT) : GM_PROF_WGRAD;

@@ -164,6 +164,7 @@ struct gm_knobs {
     int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
     int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
+    int wgrad_split_min_chunks;    // GM_WGRAD_SPLIT_MIN_CHUNKS: smallest launch (row chunks) that takes the split weight-gradient kernel; -1: a quarter of the CUs
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
 };
 const gm_knobs& gm_knob();

@@ -159,17 +159,25 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
     for (int q = tid; q < Q; q += NT) {
         const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
         const int tgt = q / n;
-        float m = -INFINITY, at = 0.f; int best = 0;
+        float m = -INFINITY, at = 0.f;
         for (int c = 0; c < Ct; ++c) {
             const float a = -sqdist(x, protos + c * D, D);                           // -dists (meta.py:44-45)
-            if (a > m) { m = a; best = c; }
+            m = fmaxf(m, a);
             if (c == tgt) at = a;
         }
         float se = 0.f;
         for (int c = 0; c < Ct; ++c) se += expf(-sqdist(x, protos + c * D, D) - m);
-        const float l = m + logf(se);
-        lse[q] = l;
-        lpart += -(at - l);                                                          // -log_p[q, class(q)]
+        const float lg = logf(se);
+        lse[q] = m + lg;
+        lpart += -((at - m) - lg);                                                   // -log_p[q, class(q)], log_softmax = (x - max) - log(sum exp(x - max))
+        // y_hat = log_p_y.max(2) (meta.py:52,76): the prediction is the FIRST maximum of the fp32 LOG-PROBABILITIES, not of the distances --
+        // when the logits are tiny (distances below one ulp of log(sum)) every class rounds to the same log-probability and the reference
+        // predicts class 0; reproduced (fixture g8_wide_scales)
+        float bl = -INFINITY; int best = 0;
+        for (int c = 0; c < Ct; ++c) {
+            const float lp = (-sqdist(x, protos + c * D, D) - m) - lg;
+            if (lp > bl) { bl = lp; best = c; }
+        }
         apart += (best == tgt) ? 1.f : 0.f;
     }
     // block sum of (loss, correct): wave shuffles, then the first wave adds the NT / 64 wave partials (two barriers instead of log2 NT)
@@ -1302,13 +1310,14 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         memcpy(hp32 + spt->subs + qry->subs, cs.tab.data(), 4 * cs.tab.size());
         memcpy(hp32 + spt->subs + qry->subs + 3 * (size_t)T, cq.tab.data(), 4 * cq.tab.size());
         if (p.bound_ws) {
-            // two-piece kernels: the layer-1 operand of task t is bounded by the largest feature of the graphs its subgraphs come from; a batch
-            // that touches a loose table (gm_store::h_feat_mean) keeps the three-piece kernels for every pass over it
+            // two-piece kernels: the layer-1 operand of task t is bounded by the largest feature of the graphs its subgraphs come from.  A step
+            // that touches a LOOSE table (gm_store::h_feat_mean: largest entry more than 2^14 above the typical one, or not finite) runs
+            // entirely on the three-piece kernels
             const gm_store* sto = spt->store;
+            bool loose = false;
             int k = 0;
             for (const gm_batch* bb : {spt, qry}) {
                 float* fb = reinterpret_cast<float*>(hp32 + spt->subs + qry->subs + 6 * (size_t)T) + (size_t)(k++) * T;
-                bool loose = false;
                 for (int t = 0; t < T; ++t) {
                     float mx = 0.f;
                     for (int sg = bb->h_set_sub_off[t]; sg < bb->h_set_sub_off[t + 1]; ++sg) {
@@ -1319,8 +1328,11 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
                     }
                     fb[t] = mx;
                 }
-                (bb == spt ? p.S : p.Q).feat_bound = loose ? nullptr : (bb == spt ? p.featb_s : p.featb_q);
             }
+            if (loose) {
+                p.S.np = p.Q.np = 3; p.S.am = p.Q.am = nullptr; p.S.am_passes = p.Q.am_passes = 0;
+                p.pd.wam = nullptr; p.pd.viol = nullptr; p.viol = nullptr; p.bound_ws = nullptr;
+            } else { p.S.feat_bound = p.featb_s; p.Q.feat_bound = p.featb_q; }
         }
         GM_HIP(hipMemcpyAsync(p.rows_s, h, 4 * n_tab, hipMemcpyHostToDevice, st));
         GM_TRY(ring.release_after(slot, st));

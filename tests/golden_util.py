@@ -8,7 +8,9 @@ import numpy as np
 import gmeta_oracle as orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ['g0_disjoint_h1', 'g1_sampled_h2', 'g1_h3', 'g2_shared', 'g3_linkpred', 'g5_in_gt_out', 'g6_nan_skip']
+CASES = ['g0_disjoint_h1', 'g1_sampled_h2', 'g1_h3', 'g2_shared', 'g3_linkpred', 'g5_in_gt_out', 'g6_nan_skip', 'g7_wide_h2', 'g8_wide_scales', 'g9_wide_nan']
+NAN_CASES = ('g6_nan_skip', 'g9_wide_nan')          # inf features: NaN query loss, no optimiser step (meta.py:163-169)
+WIDE_CASES = ('g7_wide_h2', 'g8_wide_scales', 'g9_wide_nan')      # hidden 128: the split-MFMA update kernels can be forced onto them (gm_set_tuning)
 
 
 class Fixture:

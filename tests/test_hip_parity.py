@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import gmeta_oracle as orc
-from golden_util import CASES, Fixture, call_sizes
+from golden_util import CASES, NAN_CASES, Fixture, call_sizes
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -135,7 +135,7 @@ def test_aggregate_gather_and_feature_gather():
     np.testing.assert_allclose(out.cpu().numpy(), ref, atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c != 'g6_nan_skip'])
+@pytest.mark.parametrize('case', [c for c in CASES if c not in NAN_CASES])
 def test_classifier_forward_backward_autograd(case):
     """a6/a7: gmeta_amd.Classifier under torch.autograd.grad (the way meta.py:125 uses it) vs the oracle."""
     hu = _imports()
@@ -173,7 +173,7 @@ def test_meta_step_matches_reference(case, hoist, sparse, cone):
     hu = _imports()
     fx = Fixture(case)
     res = hu.hip_meta_step(fx, replay=True, hoist=hoist, sparse_bwd=sparse, cone=cone)
-    if case == 'g6_nan_skip':
+    if case in NAN_CASES:
         # meta.py:163-164 `if torch.isnan(loss_q): pass`: the guard runs on the device (gm_meta_finish sets found_inf, the fused
         # Adam skips the update and rolls its step counter back) -- weights bit-identical, optimiser state untouched
         assert np.isnan(res['stats']['loss_q'])
@@ -191,7 +191,7 @@ def test_meta_step_matches_reference(case, hoist, sparse, cone):
         np.testing.assert_allclose(a[m], b[m], atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c != 'g6_nan_skip'])
+@pytest.mark.parametrize('case', [c for c in CASES if c not in NAN_CASES])
 def test_finetunning_matches_reference(case):
     """a11 / G4."""
     hu = _imports()

@@ -136,11 +136,10 @@ def test_aggregate_of_one_batch_from_two_streams_is_ordered():
         assert torch.equal(o, want[k])
 
 
-def test_two_piece_kernels_match_three_piece_and_report_outgrown_weights():
-    """gm_meta_step with the two-piece fp16 split kernels (default) against the exact three-piece bf16 ones on the same step: accuracies equal,
-    losses / meta-gradient within 1e-5 of the gradient scale (both are fp32-accurate; BASELINE's bar is 1e-4).  And the documented limit of
-    the weight bound: fast weights that outgrow 1024 x theta's largest weight inside one inner loop come back as a NaN query loss -- which
-    Meta.forward treats like the reference treats torch.isnan(loss_q): no optimiser step -- never as silently wrong numbers."""
+def test_two_piece_kernels_match_three_piece():
+    """gm_meta_step with the opt-in two-piece fp16 split kernels against the exact three-piece bf16 ones (the default) on the same step:
+    accuracies equal, losses / meta-gradient within 1e-5 of the gradient scale (BASELINE's bar is 1e-4).  What happens when a bound of the
+    two-piece mode is violated is covered by tests/test_hip_round4.py."""
     import gmeta_amd
     from gmeta_amd import _lib, synth
     lib = _lib.lib()
@@ -177,7 +176,3 @@ def test_two_piece_kernels_match_three_piece_and_report_outgrown_weights():
     for a, b in zip(g2[:-1], g3[:-1]):
         scale = float(b.abs().max())
         assert float((a - b).abs().max()) <= 1e-5 * max(scale, 1e-12), (float((a - b).abs().max()), scale)
-    # an inner learning rate that throws the fast weights ~1e5 x beyond theta's range in one step
-    acc_big, _, moved_big, m_big = run(2, update_lr=3e4)
-    assert np.isnan(m_big.last_stats['loss_q'])
-    assert moved_big == 0.0                                                # NaN loss -> the step was skipped (meta.py:163-169)

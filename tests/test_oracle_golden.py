@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import gmeta_oracle as orc
-from golden_util import CASES, Fixture, call_sizes
+from golden_util import CASES, NAN_CASES, Fixture, call_sizes
 
 TOL = 1e-4   # BASELINE.json north_star: "within 1e-4 on logits/meta-grads"
 
@@ -81,7 +81,7 @@ def test_meta_step_matches_reference(case):
         accs, grad, theta1, lq = orc.meta_step(graphs, fx.feats, spt, qry, fx.z['y_spt'], fx.z['y_qry'], fx.vars0,
                                                fx.config, fx.args['k_spt'], fx.args['update_lr'], fx.args['meta_lr'],
                                                fx.K, adam_state={}, trace=trace)
-    if case == 'g6_nan_skip':
+    if case in NAN_CASES:
         assert int(fx.z['stepped']) == 0 and np.isnan(lq[-1])
         for a, b in zip(theta1, fx.vars1):
             assert np.array_equal(a, b)          # parameters untouched (meta.py:163-164)
@@ -109,7 +109,7 @@ def test_meta_step_matches_reference(case):
         np.testing.assert_allclose(a[m], b[m], atol=TOL, rtol=0)
 
 
-@pytest.mark.parametrize('case', [c for c in CASES if c != 'g6_nan_skip'])
+@pytest.mark.parametrize('case', [c for c in CASES if c not in NAN_CASES])
 def test_finetune_matches_reference(case):
     """a11 / G4: Meta.finetunning on task 0 with the initial weights."""
     fx = Fixture(case)
