@@ -53,6 +53,47 @@ def cpu_quota():
     return float(n), False
 
 
+def extraction_bytes(store, db, idx, batch, h, link):
+    """ALGORITHMIC bytes of extracting one meta-batch (with the store's real index widths: int64 row bounds, int32 ids):
+      expand   per subgraph, every frontier node v of the h-hop expansion once: its two row bounds + its in-neighbour list = 16 + 4 deg_in(v)
+               (node classification: the centre and, for h >= 2, its distinct 1-hop in-neighbours, for h = 3 also the 2-hop ones;
+               link prediction: i side 2 hops, j side 1 hop -- sdp.py:327-333)
+      induce   per selected node v (batch row): row bounds + adjacency list in BOTH orientations (the by-source CSR the backward aggregate
+               needs is induced from the parent's out-edge lists) = 32 + 4 (deg_in(v) + deg_out(v)), read once
+      write    the batched CSR in both orientations, parents, feature rows, norms, centres
+    Node sets are whatever the GPU extraction produced (bit-exact vs the oracle's, tests/test_hip_parity.py); the sampling itself works on
+    the LDS bitmap and moves no HBM bytes."""
+    S, Q = batch[0][0].view_of or batch[0][0], batch[2][0].view_of or batch[2][0]
+    deg_in = [np.diff(p).astype(np.int64) for p, _ in store.host_csr]
+    deg_out = [np.bincount(ix.astype(np.int64), minlength=len(p) - 1).astype(np.int64) for p, ix in store.host_csr]
+    expand = 0
+    for t in idx:
+        a = db._task_arrays(t)
+        for seeds in (a[0], a[1]):
+            for g, i, j in seeds:
+                ptr, ix = store.host_csr[int(g)]; di = deg_in[int(g)]
+
+                def hop(front):
+                    return np.unique(np.concatenate([ix[ptr[v]:ptr[v + 1]] for v in front])) if len(front) else np.zeros(0, np.int64)
+                front = [np.array([int(i)], np.int64)]
+                hops = 2 if link else h
+                seen = front[0]
+                for _ in range(hops - 1):
+                    nxt = np.setdiff1d(hop(front[-1]), seen); seen = np.union1d(seen, nxt); front.append(nxt)
+                exp_nodes = np.concatenate(front)
+                if link:
+                    exp_nodes = np.concatenate([exp_nodes, np.array([int(j)], np.int64)])
+                expand += 16 * len(exp_nodes) + 4 * int(di[exp_nodes].sum())
+    induce = write = 0
+    for B in (S, Q):
+        par = np.asarray(B.parent(), np.int64); gid = np.repeat(np.asarray(B.graph_ids(), np.int64), np.diff(B.sub_off))
+        for g in np.unique(gid):
+            pv = par[gid == g]
+            induce += 32 * len(pv) + 4 * int(deg_in[int(g)][pv].sum() + deg_out[int(g)][pv].sum())
+        write += 2 * 4 * (B.rows + 1) + 2 * 4 * B.edges + 3 * 4 * B.rows + 4 * B.subs * (2 if link else 1)
+    return {'expand': int(expand), 'induce': int(induce), 'write': int(write)}
+
+
 def shard_bounds(T, world):
     """Contiguous task ranges of a meta-batch per rank (sizes differ by at most one)."""
     return np.linspace(0, T, world + 1).round().astype(int)
@@ -331,6 +372,7 @@ def main():
     MM_CATS = (1, 2, 4, 5, 6, 7)      # exact-fp32 GEMM / weight gradient, split-bf16 (three pieces) ditto, split-fp16 (two pieces) ditto (gm_profile_read categories)
     ov_mm = {c: [0.0, 0, 0] for c in MM_CATS}
     strict_bytes = 0
+    ov_gemm_bytes = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
         if a.defer or not a.serialize:
@@ -338,6 +380,7 @@ def main():
         ms, n, by = prof_read()
         ov_ms += ms; ov_n += n; ov_bytes += by
         strict_bytes += prof_read(3)[2]
+        ov_gemm_bytes += prof_read(11)[2]
         for cat in MM_CATS:
             ms, n, fl = prof_read(cat)
             ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
@@ -356,6 +399,7 @@ def main():
     # the GPU on two streams, which stretches every kernel; the kernel-alone duration is measured on extra steps with
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
+    gemm_bytes = ov_gemm_bytes
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
@@ -364,7 +408,7 @@ def main():
         ov_ms, ov_n, ov_bytes = prof_read()
         maml.serialize = 1
         step(0); drain()
-        agg_ms, agg_n, agg_bytes, strict_bytes = 0.0, 0, 0, 0
+        agg_ms, agg_n, agg_bytes, strict_bytes, gemm_bytes = 0.0, 0, 0, 0, 0
         for k in range(a.roofline_steps):
             step(k); drain()
             ms, n, by = prof_read()
@@ -373,6 +417,7 @@ def main():
             for cat in MM_CATS:
                 ms, n, fl = prof_read(cat)
                 mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
+            gemm_bytes += prof_read(11)[2]
         maml.serialize = 0
         ser_steps = a.roofline_steps
     lib.gm_profile_enable(0)
@@ -486,6 +531,35 @@ def main():
         e2e = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1), 'steps': a.e2e_steps,
                'what': 'Subgraphs.get_batch (h-hop extraction + sampling + induced batch on the GPU, prefetched one step ahead on a second '
                        'thread/stream) + Meta.forward per step; same schedule as `value`'}
+    # ---- extraction kernels against the HBM roofline (SURVEY 8(d) "k-hop expansion, induce: HBM bandwidth"): one more extraction of the first
+    # meta-batch with HIP events around k_nodes / k_fill / the finalisation (gm_profile_read categories 8-10), bytes from the actual batch
+    extraction = None
+    if world == 1 and not (a.serialize or a.cone or a.sparse_bwd or a.hoist_z1):
+        idx0 = list(range(lo, hi))
+        torch.cuda.synchronize()
+        lib.gm_profile_enable(1)
+        reps = 3
+        t_ex = time.perf_counter()
+        for _ in range(reps):
+            bx = db.get_batch(idx0)
+        torch.cuda.synchronize()
+        wall_ms = (time.perf_counter() - t_ex) / reps * 1e3
+        ex = [prof_read(c) for c in (8, 9, 10)]
+        lib.gm_profile_enable(0)
+        by = extraction_bytes(store, db, idx0, bx, cfg['h'], link)
+        k_ms = (ex[0][0] + ex[1][0]) / reps
+        tot = by['expand'] + by['induce'] + by['write']
+        extraction = {'bound': 'hbm', 'kernels': 'k_nodes (h-hop expansion + sampling + node lists + induced degrees) + k_fill (batched CSR, both orientations)',
+                      'algorithmic_bytes_per_meta_batch': tot, 'bytes': by, 'k_nodes_ms': round(ex[0][0] / reps, 4), 'k_fill_ms': round(ex[1][0] / reps, 4),
+                      'finalize_span_ms': round(ex[2][0] / reps, 4), 'launches_per_meta_batch': ex[0][1] // reps,
+                      'subgraphs': int(sum(x.subs for x in (bx[0][0].view_of, bx[2][0].view_of))),
+                      'achieved': round(tot / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': round(tot / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if k_ms > 0 else None,
+                      'host_wall_ms_per_meta_batch': round(wall_ms, 3), 'symmetric_parent_fast_path': bool(store.symmetric()),
+                      'measured': 'HIP events around the kernels on the extraction stream, %d extractions of the first meta-batch after the timed region' % reps,
+                      'note': 'latency-bound integer work: one workgroup per subgraph, adjacency lists walked through dependent loads; the induced '
+                              'subgraphs are built in two phases (count, then fill) so the lists are walked twice against the one pass priced here'}
+        del bx
     if use_dist:                           # tear the communicator down before printing: nothing follows the JSON line
         dist.barrier()
         dist.destroy_process_group()
@@ -555,7 +629,7 @@ def main():
                          'launch_mix': ('full launches (support chain, the differentiated query pass) AND the partial launches of the forward-only query passes, '
                                         'whose 0..2-source rows are aggregated inside the fused aggregate+GEMM kernel: those launches are priced with B_agg '
                                         'restricted to what they touch (every indptr entry; indices, norms and output rows of the >=3-source rows; their '
-                                        'sources read once = min(edges, rows) rows).  GM_FUSE_AGG=0 gives the all-full-launch sample of the earlier rounds.')
+                                        'DISTINCT source rows read once -- counted on the device per batch).  GM_FUSE_AGG=0 gives the all-full-launch sample of the earlier rounds.')
                                        if fused else 'full launches only (fused aggregate+GEMM off or not applicable to this schedule)'},
         }
         if mm[1][0] + mm[4][0] + mm[6][0] > 0:
@@ -582,6 +656,15 @@ def main():
                                       'ms_per_step': round(mm[exact][0] / max(ser_steps, 1), 3)}
                 return d, t_pk
             g_d, g_pk = pipe(1, 4, 6); w_d, w_pk = pipe(2, 5, 7)
+            sp_ms = mm[4][0] + mm[6][0]
+            if sp_ms > 0 and gemm_bytes > 0:
+                # the split update GEMMs against the HBM roofline: with the matrix work on the bf16 / fp16 pipes they stream A and C (the weight planes
+                # come from L2): compulsory bytes 4 rows (K + N) per launch / HIP-event time
+                gb = gemm_bytes / (sp_ms * 1e-3) / 1e9
+                g_d['hbm_roofline'] = {'bound': 'hbm', 'kernel': 'k_gemm_split_p (split update GEMMs, plain and fused aggregate+GEMM launches)', 'achieved': round(gb, 1),
+                                       'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gb / HBM_PEAK_GBS, 4), 'launches': mm[4][1] + mm[6][1],
+                                       'compulsory_bytes_per_step': gemm_bytes // max(ser_steps, 1), 'ms_per_step': round(sp_ms / max(ser_steps, 1), 3),
+                                       'what': 'A operand read once + C written once, 4 rows (K + N) bytes per launch (fused launches: the aggregate rows they form count as their A operand)'}
             g_d['what'] = 'forward X@W and backward dZ = dQ@W^T'; w_d['what'] = 'dW = (norm*Z)^T dQ, db, incl. the partial reduction'
             out['mfma'] = {'note': 'update GEMMs, HIP events around every launch of the same serialised steps as the roofline; flops counted as 2*rows*K*N of the '
                                    'fp32 product; `frac` = time those launches would take at the dense peak of the pipe each one ran on (fp32 MFMA 157.3 TFLOP/s for '
@@ -599,6 +682,8 @@ def main():
                                      'labelled_extra_ms_if_all_flops_ran_at_fp32_mfma_peak': round(t_f32, 2),
                                      'note': 'split launches priced at 6 (bf16, three pieces) or 3 (fp16, two pieces) MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
                                              'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
+        if extraction:
+            out['extraction'] = extraction
         if e2e:
             out['end_to_end'] = e2e
         if extra:

@@ -98,7 +98,7 @@ extern "C" void gm_profile_enable(int32_t on) {
     g_prof_on = on;
     gm_prof_reset();
 }
-void gm_prof_reset() { for (auto& c : g_prof) { c.used = 0; c.work = 0; c.launches = 0; c.open = false; } }
+void gm_prof_reset(int n_cats) { for (int k = 0; k < n_cats && k < GM_PROF_CATS; ++k) { ProfCat& c = g_prof[k]; c.used = 0; c.work = 0; c.launches = 0; c.open = false; } }
 
 void gm_prof_begin(int cat, hipStream_t s, int64_t work) {
     if (!g_prof_on) return;
@@ -111,6 +111,8 @@ void gm_prof_begin(int cat, hipStream_t s, int64_t work) {
     (void)hipEventRecord(c.ev[c.used], s);
     c.work += work; c.launches += 1; c.open = true;
 }
+bool gm_prof_enabled() { return g_prof_on != 0; }
+void gm_prof_reset_cat(int cat) { ProfCat& c = g_prof[cat]; c.used = 0; c.work = 0; c.launches = 0; c.open = false; }
 void gm_prof_note(int cat, int64_t work) { if (g_prof_on) g_prof[cat].work += work; }
 void gm_prof_end(int cat, hipStream_t s) {
     ProfCat& c = g_prof[cat];

@@ -85,7 +85,32 @@ struct ExStore {
     const int64_t* node_off;
     const int64_t* in_ptr; const int32_t* in_idx;
     const int64_t* out_ptr; const int32_t* out_idx;
+    int sym;       // the out-CSR is element for element the in-CSR (an undirected graph stored in both directions, rows ascending): the by-source
+                   // CSR of an induced subgraph then IS its by-destination CSR, so the adjacency lists are walked once instead of twice
 };
+
+// Adjacency walks are latency chains (row bounds -> neighbour ids -> bitmap word), so a wave takes EIGHT nodes at a time, one per group of eight
+// lanes (the median parent degree is below 16), two neighbour loads in flight per lane; nodes with more than EX_BIG_DEG neighbours are left to a
+// second pass in which a whole wave walks one node (a hub in one group would stall the other seven).
+#define EX_GL 8
+#define EX_GROUPS (GM_WAVE / EX_GL)
+#define EX_BIG_DEG 256
+__device__ __forceinline__ int group_sum(int v) {
+#pragma unroll
+    for (int o = EX_GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// number of neighbours of v (list ptr/idx) inside the bitmap; the eight lanes of a group call it together (gl = lane within the group)
+template <bool G>
+__device__ __forceinline__ int group_count(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, int gl) {
+    int c = 0;
+    for (int64_t q = a + gl; __any(q < b); q += 2 * EX_GL) {
+        const int u0 = q < b ? idx[q] : -1, u1 = q + EX_GL < b ? idx[q + EX_GL] : -1;
+        if (u0 >= 0) c += bit_test<G>(seen, u0);
+        if (u1 >= 0) c += bit_test<G>(seen, u1);
+    }
+    return group_sum(c);
+}
 
 // Marks every in-neighbour of v (graph-local id) in `seen`; called by a whole wave.
 __device__ __forceinline__ void wave_mark_preds(const ExStore& S, int64_t base, int v, uint32_t* seen, int lane) {
@@ -127,13 +152,34 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         for (int64_t q = p0 + tid; q < p1; q += EX_BLOCK) bit_set(seen, S.in_idx[q]);          // hop 1 (sdp.py:301,305,308)
         __syncthreads();
         if (H >= 2) {                                                                         // hop 2 (sdp.py:302,309)
-            for (int64_t q = p0 + wave; q < p1; q += EX_WAVES) {
-                const int v = S.in_idx[q];
-                int first = 0;
-                if (lane == 0) { const uint32_t bit = 1u << (v & 31); first = !(atomicOr(&pref[v >> 5], bit) & bit); }
-                first = __shfl(first, 0, 64);
-                if (first) wave_mark_preds(S, base, v, seen, lane);
+            // eight frontier nodes per wave at a time; frontier hubs go to the list in `part` and get a whole wave each afterwards
+            const int grp = lane / EX_GL, gl = lane % EX_GL;
+            int* big = part; int* nbig = &sc[5];
+            for (int64_t q0 = p0 + (int64_t)wave * EX_GROUPS; q0 < p1; q0 += (int64_t)EX_WAVES * EX_GROUPS) {
+                const int64_t q = q0 + grp;
+                int v = -1; int64_t a = 0, b = 0;
+                if (q < p1) {
+                    v = S.in_idx[q];
+                    int first = 0;
+                    if (gl == 0) { const uint32_t bit = 1u << (v & 31); first = !(atomicOr(&pref[v >> 5], bit) & bit); }
+                    first = __shfl(first, grp * EX_GL, 64);
+                    if (first) { a = S.in_ptr[base + v]; b = S.in_ptr[base + v + 1]; }
+                    if (b - a > EX_BIG_DEG) {
+                        int slot = EX_BLOCK;
+                        if (gl == 0) slot = atomicAdd(nbig, 1);
+                        slot = __shfl(slot, grp * EX_GL, 64);
+                        if (slot < EX_BLOCK) { if (gl == 0) big[slot] = v; b = a; }      // (list full: the group walks it itself)
+                    }
+                }
+                for (int64_t r = a + gl; __any(r < b); r += 2 * EX_GL) {
+                    const int u0 = r < b ? S.in_idx[r] : -1, u1 = r + EX_GL < b ? S.in_idx[r + EX_GL] : -1;
+                    if (u0 >= 0) bit_set(seen, u0);
+                    if (u1 >= 0) bit_set(seen, u1);
+                }
             }
+            __syncthreads();
+            const int nb = min(*nbig, EX_BLOCK);
+            for (int k = wave; k < nb; k += EX_WAVES) wave_mark_preds(S, base, big[k], seen, lane);
             __syncthreads();
         }
         if (H >= 3) {                                                                         // hop 3 (sdp.py:310)
@@ -220,18 +266,45 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; nodes[r++] = w * 32 + b; }
     }
     __syncthreads();
-    // ---- induced in/out degree of every selected node (wave per node)
-    int ein = 0, eout = 0;
-    for (int r = wave; r < ns; r += EX_WAVES) {
-        const int v = nodes[r];
-        int ci_ = 0, co_ = 0;
-        for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test<G>(seen, S.in_idx[q]);
-        for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test<G>(seen, S.out_idx[q]);
-        ci_ = wave_sum(ci_); co_ = wave_sum(co_);
-        if (lane == 0) { degi_slab[(int64_t)seed * cap + r] = ci_; dego_slab[(int64_t)seed * cap + r] = co_; }
-        ein += ci_; eout += co_;
+    // ---- induced in/out degree of every selected node (eight nodes per wave at a time, hubs by a whole wave afterwards)
+    {
+        const int grp = lane / EX_GL, gl = lane % EX_GL;
+        int* big = part; int* nbig = &sc[5];
+        if (tid == 0) *nbig = 0;
+        __syncthreads();
+        int ein = 0, eout = 0;
+        int32_t* degi = degi_slab + (int64_t)seed * cap; int32_t* dego = dego_slab + (int64_t)seed * cap;
+        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += EX_WAVES * EX_GROUPS) {
+            const int r = r0 + grp;
+            int64_t ia = 0, ib = 0, oa = 0, ob = 0;
+            bool later = false;                                                          // a hub: its degrees come from the second pass
+            if (r < ns) {
+                const int v = nodes[r];
+                ia = S.in_ptr[base + v]; ib = S.in_ptr[base + v + 1];
+                if (!S.sym) { oa = S.out_ptr[base + v]; ob = S.out_ptr[base + v + 1]; }
+                if (ib - ia > EX_BIG_DEG || ob - oa > EX_BIG_DEG) {
+                    int slot = EX_BLOCK;
+                    if (gl == 0) slot = atomicAdd(nbig, 1);
+                    slot = __shfl(slot, grp * EX_GL, 64);
+                    if (slot < EX_BLOCK) { if (gl == 0) big[slot] = r; later = true; ia = ib = oa = ob = 0; }      // (list full: the group walks it itself)
+                }
+            }
+            const int ci_ = group_count<G>(ia, ib, S.in_idx, seen, gl);
+            const int co_ = S.sym ? ci_ : group_count<G>(oa, ob, S.out_idx, seen, gl);
+            if (r < ns && gl == 0 && !later) { degi[r] = ci_; dego[r] = co_; ein += ci_; eout += co_; }
+        }
+        __syncthreads();
+        const int nb = min(*nbig, EX_BLOCK);
+        for (int k = wave; k < nb; k += EX_WAVES) {
+            const int r = big[k], v = nodes[r];
+            int ci_ = 0, co_ = 0;
+            for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test<G>(seen, S.in_idx[q]);
+            if (!S.sym) for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test<G>(seen, S.out_idx[q]);
+            ci_ = wave_sum(ci_); co_ = S.sym ? ci_ : wave_sum(co_);
+            if (lane == 0) { degi[r] = ci_; dego[r] = co_; ein += ci_; eout += co_; }
+        }
+        if (ein | eout) { atomicAdd(&sc[3], ein); atomicAdd(&sc[4], eout); }
     }
-    if (lane == 0) { atomicAdd(&sc[3], ein); atomicAdd(&sc[4], eout); }
     __syncthreads();
     if (tid == 0) { n_sub[seed] = ns; e_sub[seed] = (sc[3] == sc[4]) ? sc[3] : -1; }
 }
@@ -248,18 +321,34 @@ __device__ __forceinline__ void scan_degrees(const int32_t* deg, int ns, int32_t
     for (int r = r0; r < r1; ++r) { ptr_out[r] = run; run += deg[r]; }
 }
 
-// Ordered compaction of the neighbours of v that are inside the subgraph, remapped to batch rows.
+// Ordered compaction of the neighbours of v that are inside the subgraph, remapped to batch rows (out2: optional second copy -- the
+// by-source CSR of a symmetric parent).
 template <bool G>
 __device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t* idx, int64_t base, int v, const uint32_t* seen,
-                                              const uint32_t* pref, int row0, int32_t* out, int pos, int lane) {
+                                              const uint32_t* pref, int row0, int32_t* out, int32_t* out2, int pos, int lane) {
     const int64_t a = ptr[base + v], b = ptr[base + v + 1];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int64_t q = a; q < b; q += GM_WAVE) {
         int u = 0, hit = 0;
         if (q + lane < b) { u = idx[q + lane]; hit = bit_test<G>(seen, u); }
         const unsigned long long m = __ballot(hit);
-        if (hit) out[pos + __popcll(m & lt)] = row0 + bit_rank<G>(seen, pref, u);
+        if (hit) { const int x = row0 + bit_rank<G>(seen, pref, u), p = pos + __popcll(m & lt); out[p] = x; if (out2) out2[p] = x; }
         pos += __popcll(m);
+    }
+}
+// The same for one node per group of eight lanes (all lanes of the wave call it; a group without a node passes a == b)
+template <bool G>
+__device__ __forceinline__ void group_fill_row(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, const uint32_t* pref, int row0,
+                                               int32_t* out, int32_t* out2, int pos, int grp, int gl) {
+    const unsigned lt = (1u << gl) - 1u;
+    for (int64_t q = a + gl; __any(q < b); q += 2 * EX_GL) {
+        const int u0 = q < b ? idx[q] : -1, u1 = q + EX_GL < b ? idx[q + EX_GL] : -1;
+        const int h0 = u0 >= 0 && bit_test<G>(seen, u0), h1 = u1 >= 0 && bit_test<G>(seen, u1);
+        const unsigned b0 = (unsigned)(__ballot(h0) >> (grp * EX_GL)) & 0xffu, b1 = (unsigned)(__ballot(h1) >> (grp * EX_GL)) & 0xffu;
+        if (h0) { const int x = row0 + bit_rank<G>(seen, pref, u0), p = pos + __popc(b0 & lt); out[p] = x; if (out2) out2[p] = x; }
+        pos += __popc(b0);
+        if (h1) { const int x = row0 + bit_rank<G>(seen, pref, u1), p = pos + __popc(b1 & lt); out[p] = x; if (out2) out2[p] = x; }
+        pos += __popc(b1);
     }
 }
 
@@ -308,10 +397,38 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
         centre[seed * nc] = bit_rank<G>(seen, pref, seeds[seed].i);
         if (link) centre[seed * nc + 1] = bit_rank<G>(seen, pref, seeds[seed].j);
     }
-    for (int r = wave; r < ns; r += EX_WAVES) {
-        const int v = nodes[r];
-        wave_fill_row<G>(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, indptr[row0 + r], lane);
-        wave_fill_row<G>(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, indptr_t[row0 + r], lane);
+    // eight rows per wave at a time (one per group of eight lanes); hub nodes by a whole wave afterwards.  A symmetric parent fills both
+    // orientations from the one walk.
+    {
+        const int grp = lane / EX_GL, gl = lane % EX_GL;
+        int* big = part; int* nbig = &sc[2];
+        if (tid == 0) *nbig = 0;
+        __syncthreads();
+        int32_t* ind2 = S.sym ? indices_t : nullptr;
+        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += EX_WAVES * EX_GROUPS) {
+            const int r = r0 + grp;
+            int64_t ia = 0, ib = 0, oa = 0, ob = 0; int pi = 0, po = 0;
+            if (r < ns) {
+                const int v = nodes[r];
+                ia = S.in_ptr[base + v]; ib = S.in_ptr[base + v + 1]; pi = indptr[row0 + r];
+                if (!S.sym) { oa = S.out_ptr[base + v]; ob = S.out_ptr[base + v + 1]; po = indptr_t[row0 + r]; }
+                if (ib - ia > EX_BIG_DEG || ob - oa > EX_BIG_DEG) {
+                    int slot = EX_BLOCK;
+                    if (gl == 0) slot = atomicAdd(nbig, 1);
+                    slot = __shfl(slot, grp * EX_GL, 64);
+                    if (slot < EX_BLOCK) { if (gl == 0) big[slot] = r; ia = ib = oa = ob = 0; }      // (list full: the group walks it itself)
+                }
+            }
+            group_fill_row<G>(ia, ib, S.in_idx, seen, pref, row0, indices, ind2, pi, grp, gl);
+            if (!S.sym) group_fill_row<G>(oa, ob, S.out_idx, seen, pref, row0, indices_t, nullptr, po, grp, gl);
+        }
+        __syncthreads();
+        const int nb = min(*nbig, EX_BLOCK);
+        for (int k = wave; k < nb; k += EX_WAVES) {
+            const int r = big[k], v = nodes[r];
+            wave_fill_row<G>(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, ind2, indptr[row0 + r], lane);
+            if (!S.sym) wave_fill_row<G>(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, nullptr, indptr_t[row0 + r], lane);
+        }
     }
 }
 
@@ -374,6 +491,37 @@ __global__ void k_fuse2(const int32_t* indptr, const int32_t* indices, int64_t r
         const unsigned long long a = part[0][0] + part[0][1] + part[0][2] + part[0][3], e = part[1][0] + part[1][1] + part[1][2] + part[1][3];
         if (a) { atomicAdd(counts, a); atomicAdd(counts + 1, e); }
     }
+}
+// distinct sources of the rows with more than maxdeg in-edges: mark, then count
+__global__ void k_mark_sources(const int32_t* indptr, const int32_t* indices, int64_t rows, int maxdeg, uint32_t* bits) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int p = indptr[r], d = indptr[r + 1] - p;
+        if (d > maxdeg) for (int e = p; e < p + d; ++e) { const int u = indices[e]; atomicOr(&bits[u >> 5], 1u << (u & 31)); }
+    }
+}
+__global__ void k_count_bits(const uint32_t* bits, int64_t words, unsigned long long* out) {
+    unsigned long long c = 0;
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) c += __popc(bits[w]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_down(c, off, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+int64_t gm_batch_unfused_sources(const gm_batch* b, hipStream_t s) {
+    if (b->unfused_src >= 0) return b->unfused_src;
+    const int64_t fallback = std::min<int64_t>(b->unfused_edges, b->rows);
+    if (b->rows <= 0 || b->unfused_edges <= 0) return b->unfused_src = 0;
+    const int64_t words = (b->rows + 31) / 32;
+    uint32_t* bits = nullptr; unsigned long long* cnt = nullptr; unsigned long long h = 0;
+    if (gm_alloc(&bits, (size_t)words, s) != GM_OK || gm_alloc(&cnt, 1, s) != GM_OK) { gm_dev_free(bits, s); return fallback; }
+    bool ok = hipMemsetAsync(bits, 0, 4 * (size_t)words, s) == hipSuccess && hipMemsetAsync(cnt, 0, 8, s) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(k_mark_sources, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, GM_FUSE_MAXDEG, bits);
+        hipLaunchKernelGGL(k_count_bits, dim3((int)std::min<int64_t>(512, (words + 255) / 256)), dim3(256), 0, s, bits, words, cnt);
+        ok = hipMemcpyAsync(&h, cnt, 8, hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    }
+    if (!ok) (void)hipGetLastError();
+    gm_dev_free(bits, s); gm_dev_free(cnt, s);
+    return ok ? (b->unfused_src = (int64_t)h) : fallback;
 }
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
@@ -451,6 +599,28 @@ static void batch_free(gm_batch* b) {
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
 // fast weights); weight-gradient chunks are sized by gm_wgrad_chunk_rows.
+// Row gains of the two aggregates (gm_bound.h): only the opt-in two-piece kernels read them, so they are computed at first use (on `s`,
+// ordered behind the batch's build) instead of in every batch finalisation (k_gains was the longest finalisation kernel: 0.2 ms on the 1.14 M-row
+// query batch).  At least 1: an isolated row still passes its own magnitude on wherever a kernel adds a self term.
+int gm_batch_gains(const gm_batch* cb, hipStream_t s) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    gm_batch* b = const_cast<gm_batch*>(cb);
+    if (b->d_gain) return GM_OK;
+    float* g = nullptr;
+    GM_TRY(gm_alloc(&g, (size_t)2, b->stream));                                            // freed with the batch, on its own stream
+    if (s != b->stream) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); GM_HIP(hipEventRecord(e, b->stream)); GM_HIP(hipStreamWaitEvent(s, e, 0)); GM_HIP(hipEventDestroy(e)); }
+    GM_HIP(hipMemsetD32Async((hipDeviceptr_t)g, 0x3f800000, 2, s));                        // 1.0f, 1.0f
+    if (b->rows > 0) {
+        hipLaunchKernelGGL(k_gains, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, b->d_norm,
+                           (int64_t)b->rows, reinterpret_cast<unsigned*>(g));
+        GM_HIP(hipGetLastError());
+    }
+    b->d_gain = g;
+    gm_batch_mark_use(b, s);
+    return GM_OK;
+}
+
 int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     gm_phase_timer tm("finalize");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
@@ -506,15 +676,6 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
             gm_agg_sched sc;
             GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s));
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
-        }
-    }
-    {   // at least 1: an isolated row still passes its own magnitude on wherever a kernel adds a self term
-        GM_TRY(gm_alloc(&b->d_gain, (size_t)2, s));
-        GM_HIP(hipMemsetD32Async((hipDeviceptr_t)b->d_gain, 0x3f800000, 2, s));            // 1.0f, 1.0f
-        if (b->rows > 0) {
-            hipLaunchKernelGGL(k_gains, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, b->d_norm,
-                               (int64_t)b->rows, reinterpret_cast<unsigned*>(b->d_gain));
-            GM_HIP(hipGetLastError());
         }
     }
     const int edge_tables = gm_knob().agg_edge_tables;
@@ -649,7 +810,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     hipStream_t st = (hipStream_t)stream;
     GM_TRY(gm_func_full_lds((const void*)k_nodes<false>));
     GM_TRY(gm_func_full_lds((const void*)k_fill<false>));
-    ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx};
+    ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx, store->symmetric ? 1 : 0};
 
     gm_seed_t* d_seeds = nullptr; int32_t *d_nodes = nullptr, *d_degi = nullptr, *d_dego = nullptr, *d_nsub = nullptr, *d_esub = nullptr;
     int32_t* d_given = nullptr; int64_t* d_given_off = nullptr, *dummy = nullptr; (void)dummy;
@@ -676,6 +837,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
         EX_HIP(hipMemcpyAsync(d_given, nodes_flat, sizeof(int32_t) * tot, hipMemcpyHostToDevice, st));
         EX_HIP(hipMemcpyAsync(d_given_off, nodes_off, sizeof(int64_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
     }
+    gm_prof_begin(GM_PROF_EX_NODES, st, n_seeds);
     if (gpath) {
         EX_TRY(gm_alloc(&d_gbits, (size_t)n_seeds * 2 * Wmax, st));
         hipLaunchKernelGGL(k_nodes<true>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
@@ -684,6 +846,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
         hipLaunchKernelGGL(k_nodes<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
                            d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, (uint32_t*)nullptr);
     }
+    gm_prof_end(GM_PROF_EX_NODES, st);
     EX_HIP(hipGetLastError());
     std::vector<int32_t> nsub(n_seeds), esub(n_seeds);
     EX_HIP(hipMemcpyAsync(nsub.data(), d_nsub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
@@ -714,6 +877,7 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     EX_TRY(upload_small(b, st));
     EX_TRY(gm_alloc(&d_eoff, n_seeds + 1, st));
     EX_HIP(hipMemcpyAsync(d_eoff, eoff.data(), sizeof(int32_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
+    gm_prof_begin(GM_PROF_EX_FILL, st, n_seeds);
     if (gpath) {
         hipLaunchKernelGGL(k_fill<true>, dim3(n_seeds), dim3(EX_BLOCK), sizeof(uint32_t) * (EX_BLOCK + 16), st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap,
                            d_nodes, d_degi, d_dego, b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices,
@@ -724,10 +888,14 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
                            b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t,
                            b->d_indices_t, b->d_centre, Wmax, (uint32_t*)nullptr);
     }
+    gm_prof_end(GM_PROF_EX_FILL, st);
     EX_HIP(hipGetLastError());
     EX_HIP(hipStreamSynchronize(st));   // eoff (host vector) must outlive the async copy; also surfaces kernel faults here
     tm.lap("alloc+k_fill");
-    EX_TRY(gm_batch_finalize(b, st));
+    gm_prof_begin(GM_PROF_EX_FINAL, st, 1);
+    rc = gm_batch_finalize(b, st);
+    gm_prof_end(GM_PROF_EX_FINAL, st);
+    EX_TRY(rc);
     tm.lap("finalize");
     cleanup();
 #undef EX_TRY

@@ -532,6 +532,7 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
     const int cat = a.Bsplit ? (a.np == 2 ? GM_PROF_GEMM_SPLIT16 : GM_PROF_GEMM_SPLIT) : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
+    if (a.Bsplit) gm_prof_note(GM_PROF_GEMM_SPLIT_BYTES, 4 * a.rows * (int64_t)(a.K + a.N));
     const int rc = launch_gemm_nn(a, s);
     gm_prof_end(cat, s);
     return rc;

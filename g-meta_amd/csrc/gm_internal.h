@@ -48,6 +48,7 @@ struct gm_store {
     int32_t* d_in_idx = nullptr;     // [total_edges]     source node, LOCAL to its graph
     int64_t* d_out_ptr = nullptr;    // by-source CSR of the same edges (for the transposed induce)
     int32_t* d_out_idx = nullptr;    // destination node, LOCAL to its graph
+    bool symmetric = false;          // out-CSR == in-CSR element for element (extract.hip: adjacency lists walked once)
     float* d_feat = nullptr;         // [total_nodes, feat_ld]
     unsigned* d_feat_amax = nullptr; // [1] bit pattern of max |feature| over the whole table
     // per graph (host): max |x| and mean |x| over the non-zero entries.  The two-piece fp16 kernels (opt-in, gm_bound.h) bound the layer-1 operand
@@ -131,6 +132,7 @@ struct gm_batch {
     // their aggregate is written by the ordinary kernel (gm_agg_args::skip_lo/hi) and picked up as is
     void* d_fuse2 = nullptr; void* d_fuse2_feat = nullptr;
     int64_t unfused_rows = 0, unfused_edges = 0;     // rows (and their in-edges) the ordinary aggregate still writes in a fused pass
+    mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
@@ -147,6 +149,7 @@ struct gm_batch {
     mutable hipEvent_t used_ev = nullptr;   // last consumer on ANOTHER stream: the frees wait for it (gm_batch_mark_use)
 };
 int gm_batch_finalize(gm_batch* b, hipStream_t s);
+int gm_batch_gains(const gm_batch* b, hipStream_t s);     // d_gain at first use (two-piece kernels only)
 // A consumer that ran kernels over the batch on `st` calls this afterwards: gm_batch_destroy then orders its frees behind
 // that work instead of relying on the host having synchronised (deferred read-back, prefetch threads).
 void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
@@ -371,10 +374,20 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_WGRAD_SPLIT 5  // weight gradients on the split-bf16 kernel
 #define GM_PROF_GEMM_SPLIT16 6 // grouped GEMMs on the two-piece fp16 split kernel (3 fp16 MFMA flops per fp32 flop)
 #define GM_PROF_WGRAD_SPLIT16 7
-#define GM_PROF_CATS 8
+#define GM_PROF_STEP_CATS 8     // categories of gm_meta_step (reset at the start of every step)
+#define GM_PROF_EX_NODES 8      // extraction, phase A: k_nodes (BFS, sampling, node lists, induced degrees); work = subgraphs
+#define GM_PROF_EX_FILL 9       // extraction, phase B: k_fill (batched CSR in both orientations, parents, norms, centres); work = subgraphs
+#define GM_PROF_EX_FINAL 10     // batch finalisation (launch tables, hub schedule, gains, per-edge / per-row tables): GPU span incl. the host round trips inside it
+#define GM_PROF_GEMM_SPLIT_BYTES 11   // work-only shadow of the split GEMM launches (categories 4 and 6): compulsory HBM bytes 4 rows (K + N) -- the A operand read once, C written once
+#define GM_PROF_CATS 12
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
-void gm_prof_reset();
+void gm_prof_reset(int n_cats = GM_PROF_CATS);
+void gm_prof_reset_cat(int cat);
+bool gm_prof_enabled();
+// distinct source rows of the in-edges of the rows with more than GM_FUSE_MAXDEG sources (what a partial aggregate launch reads): counted on the
+// device at first use (a bitmap over the batch rows; synchronises the stream) -- only the launch accounting of bench.py asks for it
+int64_t gm_batch_unfused_sources(const gm_batch* b, hipStream_t s);
 void gm_prof_note(int cat, int64_t work);      // adds work to a category without timing events
 static inline void gm_prof_agg_begin(hipStream_t s, int64_t bytes) { gm_prof_begin(GM_PROF_AGG, s, bytes); }
 static inline void gm_prof_agg_end(hipStream_t s) { gm_prof_end(GM_PROF_AGG, s); }

@@ -617,7 +617,8 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                     // SURVEY 8(d)'s B_agg restricted to what this launch touches: every indptr entry, the indices / norms of the rows it writes,
                     // those rows (written once) and their sources (read once: the high-degree rows of a subgraph reach ~all of its rows)
                     const int64_t pb0 = 4 * (b->rows + 1) + 4 * b->unfused_edges + 4 * b->unfused_rows + 4 * b->unfused_rows * (int64_t)fi;
-                    const int64_t src = std::min<int64_t>(b->unfused_edges, b->rows);
+                    // (their DISTINCT sources when the launch accounting is on: counted once per batch; the bound min(edges, rows) otherwise -- nobody reads it then)
+                    const int64_t src = gm_prof_enabled() ? gm_batch_unfused_sources(b, st) : std::min<int64_t>(b->unfused_edges, b->rows);
                     const int64_t pb = pb0 + 4 * src * (int64_t)fi;
                     // strict HBM pricing as for the full launches: a gather launch reads at most the whole (cache-resident) feature table
                     const int64_t pbs = pb0 + 4 * (gather ? std::min<int64_t>(src, b->store->total_nodes) : src) * (int64_t)fi;
@@ -1233,7 +1234,7 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
     p.bound_ws = nullptr; p.bound_words = 0; p.viol = nullptr;
     bool agg_first = true;
     for (int l = 0; l < p.L.n_gcn; ++l) agg_first = agg_first && p.L.dims[l] <= p.L.dims[l + 1];
-    if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->d_gain && qry->d_gain && spt->store->d_feat_amax &&
+    if (p.pd.base && gm_split_np() == 2 && agg_first && !hp->sparse_bwd && !p.S.cone && spt->store->d_feat_amax &&
         spt->rows + qry->rows >= gm_knob().split16_min_rows) {
         const int per_pass = 2 * p.L.n_gcn + 1;
         const int64_t ws_s = (int64_t)p.K * per_pass * p.T * GM_BOUND_PAD, ws_q = (int64_t)K1 * per_pass * p.T * GM_BOUND_PAD, ws_w = (int64_t)p.L.n_gcn * GM_BOUND_PAD;
@@ -1338,6 +1339,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         GM_TRY(ring.release_after(slot, st));
     }
     if (p.bound_ws) {
+        GM_TRY(gm_batch_gains(spt, st)); GM_TRY(gm_batch_gains(qry, st));      // (computed once per batch, at its first two-piece step)
         // bound slots of this step: zero (the producers use atomicMax), then the maxima of theta's weight matrices (slot k = 0)
         GM_HIP(hipMemsetAsync(p.bound_ws, 0, sizeof(unsigned) * p.bound_words, st));
         p.pd.theta = theta;
@@ -1345,7 +1347,8 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         for (int l = 0; l < L.n_gcn; ++l) { off[l] = L.w_off[l]; n[l] = (int64_t)L.dims[l] * L.dims[l + 1]; }
         GM_TRY(gm_amax_segs(theta, off, n, L.n_gcn, p.pd.wam, GM_BOUND_PAD, st));
     }
-    gm_prof_reset();
+    gm_prof_reset(GM_PROF_STEP_CATS);
+    gm_prof_reset_cat(GM_PROF_GEMM_SPLIT_BYTES);
     tm.lap("plan");
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the

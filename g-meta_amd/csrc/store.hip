@@ -50,6 +50,7 @@ extern "C" int gm_store_create(int32_t n_graphs, const int64_t* n_nodes, const i
                 for (int64_t e = in_ptr[no + v]; e < in_ptr[no + v + 1]; ++e) out_idx[cur[no + in_idx[e]]++] = (int32_t)v;
         }
     }
+    s->symmetric = s->total_edges > 0 && in_ptr == out_ptr && in_idx == out_idx && getenv("GM_EXTRACT_NO_SYM") == nullptr;
     hipStream_t st = nullptr;
     int rc = GM_OK;
 #define UP(dptr, vec, T)                                                                              \

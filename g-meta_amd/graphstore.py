@@ -57,6 +57,17 @@ class GraphStore:
         self.n_edges = [int(p[-1]) for p in ptrs]
         self.host_csr = list(zip(ptrs, idxs))      # host copy of the in-edge CSR (Subgraphs(sample_mode='reference') walks it like sdp.py:301)
 
+    def symmetric(self):
+        """True when every out-edge list equals the in-edge list element for element (undirected graphs stored in both directions with
+        ascending rows): extraction then walks the adjacency lists once for both CSR orientations (csrc/extract.hip)."""
+        for ptr, ix in self.host_csr:
+            n = len(ptr) - 1
+            dst = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+            order = np.argsort(ix, kind='stable')                      # out-CSR: by source, destinations in in-CSR (= ascending destination) order
+            if not (np.array_equal(np.bincount(ix, minlength=n), np.diff(ptr)) and np.array_equal(dst[order], ix.astype(np.int64))):
+                return False
+        return True
+
     def close(self):
         if getattr(self, 'handle', None):
             _lib.lib().gm_store_destroy(self.handle)

@@ -241,7 +241,10 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
  * whole table, not rows*width; total_ms is 0 for this category -- use category 0's), 4 / 5 = the grouped GEMMs / weight
  * gradients that ran on the split-bf16 kernels (work = flops of the fp32 product; the kernels issue 6 bf16 MFMA flops per
  * fp32 flop) -- categories 1 / 2 then hold only the launches on the exact-fp32 MFMA kernels; 6 / 7 = the grouped GEMMs / weight
- * gradients on the two-piece fp16 split kernels (3 fp16 MFMA flops per fp32 flop). */
+ * gradients on the two-piece fp16 split kernels (3 fp16 MFMA flops per fp32 flop).  Categories 8 / 9 / 10 belong to gm_extract on this thread
+ * (not reset by gm_meta_step; gm_profile_enable resets them): 8 = k_nodes (h-hop expansion, sampling, node lists, induced degrees),
+ * 9 = k_fill (the batched CSR in both orientations), work = subgraphs; 10 = batch finalisation (GPU span including its host round trips).
+ * 11 = work-only shadow of categories 4 + 6: compulsory HBM bytes of the split GEMM launches, 4 rows (K + N) (A read once, C written once). */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 
 #ifdef __cplusplus

@@ -196,3 +196,45 @@ def test_two_piece_mode_reruns_a_step_whose_weights_outgrew_their_bound():
     # and with an ordinary learning rate nothing is re-run
     _, _, moved, m, n = _run(args, data, batch, config, 2)
     assert 'rerun_three_piece' not in m.last_stats and moved > 0 and n[1] > 0
+
+
+def test_symmetric_parent_walks_adjacency_once_and_matches_the_two_walk_path(monkeypatch):
+    """A parent graph whose out-CSR is element for element its in-CSR (undirected, both directions stored) fills both orientations of the
+    induced CSR from one walk of the adjacency lists (extract.hip, ExStore::sym).  Same arrays as the two-walk path (GM_EXTRACT_NO_SYM=1
+    at store creation) and as the oracle, on a fixture and at the arxiv shape with sampling."""
+    import gmeta_amd
+    import gmeta_oracle as orc
+    from gmeta_amd import synth
+    from gmeta_amd.subgraphs import SubgraphBatch
+    fx = Fixture('g1_sampled_h2')
+
+    def arrays(store, seeds, off, h, sn, link):
+        B = SubgraphBatch.extract(store, seeds, off, h, sn, 222, link)
+        ip, ix = B.csr(); ipt, ixt = B.csr(transposed=True)
+        return [np.asarray(a).copy() for a in (B.parent(), ip, ix, ipt, ixt, B.centres_local(), B.sub_off)]
+    seeds = fx.z['qry_seeds'].reshape(-1, 3); off = np.arange(fx.T + 1) * fx.z['qry_seeds'].shape[1]
+    a_sym = arrays(gmeta_amd.GraphStore(fx.edges, fx.feats), seeds, off, fx.args['h'], fx.args['sample_nodes'], fx.link)
+    monkeypatch.setenv('GM_EXTRACT_NO_SYM', '1')
+    a_two = arrays(gmeta_amd.GraphStore(fx.edges, fx.feats), seeds, off, fx.args['h'], fx.args['sample_nodes'], fx.link)
+    monkeypatch.delenv('GM_EXTRACT_NO_SYM')
+    for x, y in zip(a_sym, a_two):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a_sym[1], a_sym[3]) and np.array_equal(a_sym[2], a_sym[4])      # symmetric: by-source CSR == by-destination CSR
+    # arxiv shape: hubs (> EX_BIG_DEG neighbours) and sampling
+    np.random.seed(222); random.seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=2)
+    data = synth.make_dataset(cfg)
+    n, src, dst = data['graphs'][0]
+    deg = np.bincount(np.asarray(dst), minlength=n)
+    hubs = np.argsort(-deg)[:3]
+    rng = np.random.default_rng(7)
+    cs = np.concatenate([hubs, rng.integers(0, n, 29)]).astype(np.int32)
+    seeds = np.stack([np.zeros_like(cs), cs, -np.ones_like(cs)], 1)
+    off = np.array([0, len(cs)])
+    a_sym = arrays(gmeta_amd.GraphStore(data['graphs'], data['feats']), seeds, off, 2, 1000, False)
+    monkeypatch.setenv('GM_EXTRACT_NO_SYM', '1')
+    a_two = arrays(gmeta_amd.GraphStore(data['graphs'], data['feats']), seeds, off, 2, 1000, False)
+    for x, y in zip(a_sym, a_two):
+        assert np.array_equal(x, y)
+    ob = orc.extract_batch([orc.Graph(n, src, dst)], seeds, 2, 1000, 222, False)
+    assert np.array_equal(a_sym[0], ob.parent) and np.array_equal(a_sym[1], ob.indptr) and np.array_equal(a_sym[2], ob.indices)
