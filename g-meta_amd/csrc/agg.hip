@@ -372,7 +372,7 @@ int gm_agg_window(int64_t rows, int64_t edges) {
     return win;
 }
 
-int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s) {
+int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s, gm_stager* sg) {
     *out = gm_agg_sched{};
     const int on = gm_knob().agg_sched, part_env = gm_knob().agg_hub_part;      // part_env 0: one block per hub row
     if (!on || n_heavy <= 0 || rows <= 0) return GM_OK;                  // no hub rows: the plain window launch
@@ -414,15 +414,14 @@ int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int3
     for (auto& l : lists) len = std::max(len, l.size());
     std::vector<int32_t> flat(GM_NXCD * len, -1);
     for (int x = 0; x < GM_NXCD; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * len);
-    GM_TRY(gm_alloc(&out->d_sched, flat.size(), s));
-    GM_HIP(hipMemcpyAsync(out->d_sched, flat.data(), 4 * flat.size(), hipMemcpyHostToDevice, s));
+    GM_TRY(gm_balloc(b, &out->d_sched, flat.size(), s));
+    GM_TRY(sg->upload(out->d_sched, flat));     // (through pinned staging: no host round trip)
     if (hub_part) {
-        GM_TRY(gm_alloc(&out->d_hub, tab.size(), s));
-        GM_HIP(hipMemcpyAsync(out->d_hub, tab.data(), 4 * tab.size(), hipMemcpyHostToDevice, s));
-        GM_TRY(gm_alloc(&out->d_hub_scratch, (size_t)tab[n_heavy] * GM_AGG_HUB_LD, s));
+        GM_TRY(gm_balloc(b, &out->d_hub, tab.size(), s));
+        GM_TRY(sg->upload(out->d_hub, tab));
+        GM_TRY(gm_balloc(b, &out->d_hub_scratch, (size_t)tab[n_heavy] * GM_AGG_HUB_LD, s));
         out->hub_part = hub_part;
     }
-    GM_HIP(hipStreamSynchronize(s));            // the host vectors are pageable and go out of scope
     out->len = (int32_t)len;
     return GM_OK;
 }

@@ -55,6 +55,65 @@ void gm_dev_free(void* p, hipStream_t s) {
     }
 }
 
+// ---------------------------------------------------------------- pinned staging pool (gm_stager)
+struct StageChunk { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, held = false; };
+struct StagePool {
+    std::vector<StageChunk> chunks;
+    ~StagePool() { for (auto& c : chunks) { if (c.ev) (void)hipEventDestroy(c.ev); if (c.p) (void)hipHostFree(c.p); } }
+    int acquire(size_t bytes) {
+        int best = -1;
+        for (size_t k = 0; k < chunks.size(); ++k) {
+            StageChunk& c = chunks[k];
+            if (c.held) continue;
+            if (c.pending) { if (hipEventQuery(c.ev) != hipSuccess) { (void)hipGetLastError(); continue; } c.pending = false; }
+            if (c.cap >= bytes && (best < 0 || c.cap < chunks[best].cap)) best = (int)k;
+        }
+        if (best < 0) {
+            StageChunk c;
+            c.cap = std::max<size_t>(bytes, (size_t)1 << 20);
+            if (hipHostMalloc((void**)&c.p, c.cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
+            if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(c.p); return -1; }
+            chunks.push_back(c); best = (int)chunks.size() - 1;
+        }
+        chunks[best].held = true;
+        return best;
+    }
+};
+static StagePool& stage_pool() {
+    static thread_local std::map<int, StagePool> m;      // per (thread, device)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+    return m[dev];
+}
+void* gm_stager::take(size_t bytes) {
+    bytes = (bytes + 63) / 64 * 64;
+    if (bytes > left) {
+        const int k = stage_pool().acquire(bytes);
+        if (k < 0) return nullptr;
+        used.push_back(k);
+        cur = stage_pool().chunks[k].p; left = stage_pool().chunks[k].cap;
+    }
+    void* r = cur; cur += bytes; left -= bytes;
+    return r;
+}
+int gm_stager::upload(void* dptr, const void* src, size_t bytes) {
+    if (!bytes) return GM_OK;
+    void* h = take(bytes);
+    GM_REQUIRE(h, GM_ENOMEM, "pinned staging allocation of %zu bytes failed", bytes);
+    memcpy(h, src, bytes);
+    GM_HIP(hipMemcpyAsync(dptr, h, bytes, hipMemcpyHostToDevice, s));
+    return GM_OK;
+}
+gm_stager::~gm_stager() {
+    StagePool& pool = stage_pool();
+    for (int k : used) {
+        StageChunk& c = pool.chunks[k];
+        c.held = false;
+        if (hipEventRecord(c.ev, s) == hipSuccess) c.pending = true;      // reusable once the stream has passed this point
+        else { (void)hipGetLastError(); (void)hipStreamSynchronize(s); c.pending = false; }
+    }
+}
+
 int gm_make_layout(const gm_model_t* m, gm_layout* L) {
     GM_REQUIRE(m && m->n_gcn >= 1 && m->n_gcn <= GM_MAX_GCN, GM_EINVAL, "model: n_gcn must be in [1,%d]", GM_MAX_GCN);
     GM_REQUIRE(m->n_out >= 1 && m->n_out <= 64, GM_ERANGE, "model: n_out=%d outside [1,64]", m->n_out);

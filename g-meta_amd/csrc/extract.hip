@@ -576,6 +576,20 @@ int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s) {
     return GM_OK;
 }
 
+int gm_balloc_bytes(gm_batch* b, void** p, size_t bytes, hipStream_t s) {
+    bytes = (bytes + 255) / 256 * 256;
+    if (b->slabs.empty() || b->slabs.back().cap - b->slabs.back().used < bytes) {
+        // slab size: what the big arrays of this batch will need in total when the sizes are known (rows / edges), else 8 MiB steps
+        const size_t guess = (size_t)b->rows * 64 + (size_t)b->edges * 24 + ((size_t)1 << 20);
+        gm_batch::slab sl{nullptr, std::max(bytes, b->slabs.empty() ? guess : std::max<size_t>(guess / 4, (size_t)8 << 20)), 0};
+        GM_TRY(gm_dev_alloc((void**)&sl.base, sl.cap, s));
+        b->slabs.push_back(sl);
+    }
+    gm_batch::slab& sl = b->slabs.back();
+    *p = sl.base + sl.used; sl.used += bytes;
+    return GM_OK;
+}
+
 static void batch_free(gm_batch* b) {
     hipStream_t s = b->stream;
     for (int o = 0; o < 2; ++o) if (b->hub_ev[o]) { (void)hipEventDestroy(b->hub_ev[o]); b->hub_ev[o] = nullptr; }
@@ -583,17 +597,8 @@ static void batch_free(gm_batch* b) {
         if (hipStreamWaitEvent(s, b->used_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b->used_ev); }
         (void)hipEventDestroy(b->used_ev); b->used_ev = nullptr;
     }
-    gm_dev_free(b->d_sub_off, s); gm_dev_free(b->d_set_sub_off, s); gm_dev_free(b->d_set_row_off, s); gm_dev_free(b->d_graph, s);
-    gm_dev_free(b->d_parent, s); gm_dev_free(b->d_feat_row, s); gm_dev_free(b->d_indptr, s); gm_dev_free(b->d_indices, s);
-    gm_dev_free(b->d_indptr_t, s); gm_dev_free(b->d_indices_t, s); gm_dev_free(b->d_centre, s); gm_dev_free(b->d_norm, s);
-    gm_dev_free(b->d_sub_set, s); gm_dev_free(b->d_tiles, s); gm_dev_free(b->d_chunks, s); gm_dev_free(b->d_set_chunk_off, s);
-    gm_dev_free(b->d_heavy[0], s); gm_dev_free(b->d_heavy[1], s); gm_dev_free(b->d_sched[0], s); gm_dev_free(b->d_sched[1], s);
-    gm_dev_free((int4*)b->d_fuse2, s); gm_dev_free((int4*)b->d_fuse2_feat, s); gm_dev_free(b->d_gain, s);
-    gm_dev_free(b->d_enorm[0], s); gm_dev_free(b->d_enorm[1], s); gm_dev_free(b->d_efeat, s);
-    gm_dev_free(b->d_hub[0], s); gm_dev_free(b->d_hub[1], s); gm_dev_free(b->d_hub_scratch[0], s); gm_dev_free(b->d_hub_scratch[1], s);
-    gm_dev_free(b->d_crow, s); gm_dev_free(b->d_cnorm, s); gm_dev_free(b->d_e1_row, s); gm_dev_free(b->d_e1_par, s); gm_dev_free(b->d_e1_norm, s);
-    gm_dev_free(b->d_c_tiles, s); gm_dev_free(b->d_c_chunks, s); gm_dev_free(b->d_c_set_chunk_off, s);
-    gm_dev_free(b->d_e1_chunks, s); gm_dev_free(b->d_e1_set_chunk_off, s);
+    for (auto& sl : b->slabs) gm_dev_free(sl.base, s);       // every array of the batch lives in these (gm_balloc)
+    b->slabs.clear();
     for (int l = 0; l <= GM_MAX_GCN; ++l) { gm_cone_free(b->cone[l], s); b->cone[l] = nullptr; }
 }
 
@@ -608,7 +613,7 @@ int gm_batch_gains(const gm_batch* cb, hipStream_t s) {
     gm_batch* b = const_cast<gm_batch*>(cb);
     if (b->d_gain) return GM_OK;
     float* g = nullptr;
-    GM_TRY(gm_alloc(&g, (size_t)2, b->stream));                                            // freed with the batch, on its own stream
+    GM_TRY(gm_balloc(b, &g, (size_t)2, b->stream));                                        // (the batch's slabs: freed with it, on its own stream)
     if (s != b->stream) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); GM_HIP(hipEventRecord(e, b->stream)); GM_HIP(hipStreamWaitEvent(s, e, 0)); GM_HIP(hipEventDestroy(e)); }
     GM_HIP(hipMemsetD32Async((hipDeviceptr_t)g, 0x3f800000, 2, s));                        // 1.0f, 1.0f
     if (b->rows > 0) {
@@ -621,7 +626,11 @@ int gm_batch_gains(const gm_batch* cb, hipStream_t s) {
     return GM_OK;
 }
 
-int gm_batch_finalize(gm_batch* b, hipStream_t s) {
+// Launch tables and derived per-batch tables.  ONE host round trip: the kernels whose results the host needs (hub-row lists, the fused launch's
+// row / edge counts, the centres' in-degrees) are launched back to back, their results come back in one batch of copies into pinned memory,
+// and everything the host derives from them goes up through pinned staging without waiting (gm_stager).
+#define GM_HEAVY_FIRST 8192     // hub rows per orientation fetched with the first round trip (more: one more round trip)
+int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     gm_phase_timer tm("finalize");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
     for (int t = 0; t < b->sets; ++t)
@@ -634,91 +643,91 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
         set_chunk_off[t + 1] = (int32_t)(chunks.size() / 3);
     }
     b->n_tiles = (int32_t)(tiles.size() / 3); b->n_chunks = (int32_t)(chunks.size() / 3);
-    GM_TRY(gm_alloc(&b->d_sub_set, sub_set.size(), s)); GM_TRY(gm_alloc(&b->d_tiles, tiles.size(), s));
-    GM_TRY(gm_alloc(&b->d_chunks, chunks.size(), s)); GM_TRY(gm_alloc(&b->d_set_chunk_off, set_chunk_off.size(), s));
-    GM_HIP(hipMemcpyAsync(b->d_sub_set, sub_set.data(), 4 * sub_set.size(), hipMemcpyHostToDevice, s));
-    if (!tiles.empty()) GM_HIP(hipMemcpyAsync(b->d_tiles, tiles.data(), 4 * tiles.size(), hipMemcpyHostToDevice, s));
-    if (!chunks.empty()) GM_HIP(hipMemcpyAsync(b->d_chunks, chunks.data(), 4 * chunks.size(), hipMemcpyHostToDevice, s));
-    GM_HIP(hipMemcpyAsync(b->d_set_chunk_off, set_chunk_off.data(), 4 * set_chunk_off.size(), hipMemcpyHostToDevice, s));
-    GM_HIP(hipStreamSynchronize(s));     // host vectors go out of scope
+    GM_TRY(gm_balloc(b, &b->d_sub_set, sub_set.size(), s)); GM_TRY(gm_balloc(b, &b->d_tiles, tiles.size(), s));
+    GM_TRY(gm_balloc(b, &b->d_chunks, chunks.size(), s)); GM_TRY(gm_balloc(b, &b->d_set_chunk_off, set_chunk_off.size(), s));
+    GM_TRY(sg.upload(b->d_sub_set, sub_set)); GM_TRY(sg.upload(b->d_tiles, tiles)); GM_TRY(sg.upload(b->d_chunks, chunks));
+    GM_TRY(sg.upload(b->d_set_chunk_off, set_chunk_off));
     tm.lap("tables");
-    // heavy-row lists for both CSR orientations (a row can have at most rows-1... edges: cap = edges / heavy_deg + 1)
+    // ---- device side, nothing here waits for the host: hub-row lists of both orientations, per-edge tables, the fused launch's row table +
+    // counts, centre rows with their in-degrees
     b->heavy_deg = gm_heavy_deg_for(b->rows, b->edges);
     const int cap = (int)(b->edges / b->heavy_deg + 1);
     int32_t* d_cnt = nullptr;
     GM_TRY(gm_alloc(&d_cnt, 2, s));
     GM_HIP(hipMemsetAsync(d_cnt, 0, 8, s));
     for (int o = 0; o < 2; ++o) {
-        GM_TRY(gm_alloc(&b->d_heavy[o], 2 * (size_t)cap, s));
+        GM_TRY(gm_balloc(b, &b->d_heavy[o], 2 * (size_t)cap, s));
         const int blocks = (int)std::min<int64_t>(2048, (b->rows + 255) / 256);
         hipLaunchKernelGGL(k_find_heavy, dim3(blocks), dim3(256), 0, s, o ? b->d_indptr_t : b->d_indptr, b->rows, b->d_heavy[o], d_cnt + o, cap, b->heavy_deg);
     }
-    int32_t cnt[2];
-    GM_HIP(hipMemcpyAsync(cnt, d_cnt, 8, hipMemcpyDeviceToHost, s));
-    GM_HIP(hipStreamSynchronize(s));
-    gm_dev_free(d_cnt, s);
-    b->sched_win = gm_agg_window(b->rows, b->edges);
-    for (int o = 0; o < 2; ++o) {
-        b->n_heavy[o] = std::min(cnt[o], cap);
-        if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
-            const size_t nh = b->n_heavy[o];
-            std::vector<int32_t> h(nh), hd(nh);
-            // stream-ordered copies + a wait on THIS stream only: a plain hipMemcpy is a null-stream operation and would
-            // serialise the prefetch thread's batch build with whatever the training thread has queued on the default stream
-            GM_HIP(hipMemcpyAsync(h.data(), b->d_heavy[o], 4 * nh, hipMemcpyDeviceToHost, s));
-            GM_HIP(hipMemcpyAsync(hd.data(), b->d_heavy[o] + cap, 4 * nh, hipMemcpyDeviceToHost, s));
-            GM_HIP(hipStreamSynchronize(s));
-            std::vector<std::pair<int32_t, int32_t>> pr(nh);
-            for (size_t k = 0; k < nh; ++k) pr[k] = {h[k], hd[k]};
-            std::sort(pr.begin(), pr.end());
-            for (size_t k = 0; k < nh; ++k) { h[k] = pr[k].first; hd[k] = pr[k].second; }
-            if (nh > 1) { GM_HIP(hipMemcpyAsync(b->d_heavy[o], h.data(), 4 * nh, hipMemcpyHostToDevice, s)); GM_HIP(hipStreamSynchronize(s)); }
-            gm_agg_sched sc;
-            GM_TRY(gm_agg_schedule(b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s));
-            b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
-        }
-    }
     const int edge_tables = gm_knob().agg_edge_tables;
     if (b->edges > 0 && edge_tables) {
-        GM_TRY(gm_alloc(&b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_alloc(&b->d_efeat, (size_t)b->edges, s));
+        GM_TRY(gm_balloc(b, &b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_balloc(b, &b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_balloc(b, &b->d_efeat, (size_t)b->edges, s));
         hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
                            b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);
-        GM_HIP(hipGetLastError());
     }
+    unsigned long long* d_counts = nullptr;
     if (b->rows > 0) {
         int4 *f0 = nullptr, *ff = nullptr;
-        GM_TRY(gm_alloc(&f0, (size_t)b->rows, s)); GM_TRY(gm_alloc(&ff, (size_t)b->rows, s));
+        GM_TRY(gm_balloc(b, &f0, (size_t)b->rows, s)); GM_TRY(gm_balloc(b, &ff, (size_t)b->rows, s));
         b->d_fuse2 = f0; b->d_fuse2_feat = ff;
-        unsigned long long* d_counts = nullptr; unsigned long long h_counts[2] = {0, 0};
         GM_TRY(gm_alloc(&d_counts, 2, s));
         GM_HIP(hipMemsetAsync(d_counts, 0, 16, s));
         hipLaunchKernelGGL(k_fuse2, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, b->d_norm,
                            b->d_feat_row, f0, ff, d_counts);
-        GM_HIP(hipGetLastError());
-        GM_HIP(hipMemcpyAsync(h_counts, d_counts, 16, hipMemcpyDeviceToHost, s));
-        GM_HIP(hipStreamSynchronize(s));
-        gm_dev_free(d_counts, s);
-        b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1];
+    }
+    const int nc = b->centres; b->n_c = b->subs * nc;
+    int32_t* d_cdeg = nullptr;
+    GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
+    hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
+                       b->d_crow, b->d_cnorm, d_cdeg);
+    GM_HIP(hipGetLastError());
+    // ---- the one round trip
+    const int first = std::min(cap, GM_HEAVY_FIRST);
+    const int32_t* h_cnt = sg.download(d_cnt, 2);
+    const int32_t* h_heavy[2] = {nullptr, nullptr}; const int32_t* h_hdeg[2] = {nullptr, nullptr};
+    for (int o = 0; o < 2; ++o) { h_heavy[o] = sg.download(b->d_heavy[o], (size_t)first); h_hdeg[o] = sg.download(b->d_heavy[o] + cap, (size_t)first); }
+    const unsigned long long* h_counts = d_counts ? sg.download(d_counts, 2) : nullptr;
+    const int32_t* h_cdeg = sg.download(d_cdeg, (size_t)b->n_c);
+    GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
+    GM_HIP(hipStreamSynchronize(s));
+    gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
+    if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
+    b->sched_win = gm_agg_window(b->rows, b->edges);
+    for (int o = 0; o < 2; ++o) {
+        b->n_heavy[o] = std::min(h_cnt[o], cap);
+        if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
+            const size_t nh = b->n_heavy[o];
+            std::vector<int32_t> h(nh), hd(nh);
+            if ((int)nh <= first) { std::copy(h_heavy[o], h_heavy[o] + nh, h.begin()); std::copy(h_hdeg[o], h_hdeg[o] + nh, hd.begin()); }
+            else {                       // more hub rows than the first fetch carried: one more round trip for this orientation
+                const int32_t* a = sg.download(b->d_heavy[o], nh); const int32_t* d = sg.download(b->d_heavy[o] + cap, nh);
+                GM_REQUIRE(a && d, GM_ENOMEM, "finalize: pinned staging failed");
+                GM_HIP(hipStreamSynchronize(s));
+                std::copy(a, a + nh, h.begin()); std::copy(d, d + nh, hd.begin());
+            }
+            std::vector<std::pair<int32_t, int32_t>> pr(nh);
+            for (size_t k = 0; k < nh; ++k) pr[k] = {h[k], hd[k]};
+            std::sort(pr.begin(), pr.end());
+            for (size_t k = 0; k < nh; ++k) { h[k] = pr[k].first; hd[k] = pr[k].second; }
+            if (nh > 1) GM_TRY(sg.upload(b->d_heavy[o], h));
+            gm_agg_sched sc;
+            GM_TRY(gm_agg_schedule(b, b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s, &sg));
+            b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
+        }
     }
     tm.lap("heavy");
     // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres
-    const int nc = b->centres; b->n_c = b->subs * nc;
-    int32_t* d_cdeg = nullptr;
-    GM_TRY(gm_alloc(&b->d_crow, b->n_c, s)); GM_TRY(gm_alloc(&b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
-    hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
-                       b->d_crow, b->d_cnorm, d_cdeg);
-    std::vector<int32_t> cdeg(b->n_c), eoff(b->n_c + 1, 0);
-    GM_HIP(hipMemcpyAsync(cdeg.data(), d_cdeg, 4 * (size_t)b->n_c, hipMemcpyDeviceToHost, s));
-    GM_HIP(hipStreamSynchronize(s));
-    gm_dev_free(d_cdeg, s);
-    for (int k = 0; k < b->n_c; ++k) eoff[k + 1] = eoff[k] + cdeg[k];
+    std::vector<int32_t> eoff(b->n_c + 1, 0);
+    for (int k = 0; k < b->n_c; ++k) eoff[k + 1] = eoff[k] + h_cdeg[k];
     b->n_e1 = eoff[b->n_c];
     int32_t* d_eoff = nullptr;
     GM_TRY(gm_alloc(&d_eoff, eoff.size(), s));
-    GM_HIP(hipMemcpyAsync(d_eoff, eoff.data(), 4 * eoff.size(), hipMemcpyHostToDevice, s));
-    GM_TRY(gm_alloc(&b->d_e1_row, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_par, b->n_e1, s)); GM_TRY(gm_alloc(&b->d_e1_norm, b->n_e1, s));
+    GM_TRY(sg.upload(d_eoff, eoff));
+    GM_TRY(gm_balloc(b, &b->d_e1_row, b->n_e1, s)); GM_TRY(gm_balloc(b, &b->d_e1_par, b->n_e1, s)); GM_TRY(gm_balloc(b, &b->d_e1_norm, b->n_e1, s));
     hipLaunchKernelGGL(k_centre_edges, dim3(b->n_c), dim3(64), 0, s, b->d_crow, d_eoff, b->n_c, b->d_indptr, b->d_indices, b->d_norm,
                        b->d_e1_row, b->d_e1_par, b->d_e1_norm);
+    GM_HIP(hipGetLastError());
     std::vector<int32_t> ct, cc, ccoff(b->sets + 1, 0), ec, ecoff(b->sets + 1, 0), c_set_off(b->sets + 1), e_set_off(b->sets + 1);
     for (int t = 0; t <= b->sets; ++t) { c_set_off[t] = b->h_set_sub_off[t] * nc; e_set_off[t] = eoff[b->h_set_sub_off[t] * nc]; }
     const int ccr = gm_wgrad_chunk_rows(c_set_off), ecr = gm_wgrad_chunk_rows(e_set_off);
@@ -733,12 +742,10 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s) {
     b->n_c_tiles = (int32_t)(ct.size() / 3); b->n_c_chunks = (int32_t)(cc.size() / 3); b->n_e1_chunks = (int32_t)(ec.size() / 3);
     auto up = [&](int32_t** d, const std::vector<int32_t>& v) -> int {
         GM_TRY(gm_alloc(d, v.size(), s));
-        if (!v.empty()) GM_HIP(hipMemcpyAsync(*d, v.data(), 4 * v.size(), hipMemcpyHostToDevice, s));
-        return GM_OK;
+        return sg.upload(*d, v);
     };
     GM_TRY(up(&b->d_c_tiles, ct)); GM_TRY(up(&b->d_c_chunks, cc)); GM_TRY(up(&b->d_c_set_chunk_off, ccoff));
     GM_TRY(up(&b->d_e1_chunks, ec)); GM_TRY(up(&b->d_e1_set_chunk_off, ecoff));
-    GM_HIP(hipStreamSynchronize(s));
     gm_dev_free(d_eoff, s);
     return GM_OK;
 }
@@ -750,20 +757,18 @@ extern "C" void gm_batch_destroy(gm_batch_t* b) {
 }
 
 static int batch_alloc(gm_batch* b, hipStream_t s) {
-    GM_TRY(gm_alloc(&b->d_sub_off, b->subs + 1, s)); GM_TRY(gm_alloc(&b->d_set_sub_off, b->sets + 1, s));
-    GM_TRY(gm_alloc(&b->d_set_row_off, b->sets + 1, s)); GM_TRY(gm_alloc(&b->d_graph, b->subs, s));
-    GM_TRY(gm_alloc(&b->d_parent, b->rows, s)); GM_TRY(gm_alloc(&b->d_feat_row, b->rows, s));
-    GM_TRY(gm_alloc(&b->d_indptr, b->rows + 1, s)); GM_TRY(gm_alloc(&b->d_indices, b->edges, s));
-    GM_TRY(gm_alloc(&b->d_indptr_t, b->rows + 1, s)); GM_TRY(gm_alloc(&b->d_indices_t, b->edges, s));
-    GM_TRY(gm_alloc(&b->d_centre, (size_t)b->subs * b->centres, s)); GM_TRY(gm_alloc(&b->d_norm, b->rows, s));
+    GM_TRY(gm_balloc(b, &b->d_sub_off, b->subs + 1, s)); GM_TRY(gm_balloc(b, &b->d_set_sub_off, b->sets + 1, s));
+    GM_TRY(gm_balloc(b, &b->d_set_row_off, b->sets + 1, s)); GM_TRY(gm_balloc(b, &b->d_graph, b->subs, s));
+    GM_TRY(gm_balloc(b, &b->d_parent, b->rows, s)); GM_TRY(gm_balloc(b, &b->d_feat_row, b->rows, s));
+    GM_TRY(gm_balloc(b, &b->d_indptr, b->rows + 1, s)); GM_TRY(gm_balloc(b, &b->d_indices, b->edges, s));
+    GM_TRY(gm_balloc(b, &b->d_indptr_t, b->rows + 1, s)); GM_TRY(gm_balloc(b, &b->d_indices_t, b->edges, s));
+    GM_TRY(gm_balloc(b, &b->d_centre, (size_t)b->subs * b->centres, s)); GM_TRY(gm_balloc(b, &b->d_norm, b->rows, s));
     return GM_OK;
 }
 
-static int upload_small(gm_batch* b, hipStream_t s) {
-    GM_HIP(hipMemcpyAsync(b->d_sub_off, b->h_sub_off.data(), sizeof(int32_t) * (b->subs + 1), hipMemcpyHostToDevice, s));
-    GM_HIP(hipMemcpyAsync(b->d_set_sub_off, b->h_set_sub_off.data(), sizeof(int32_t) * (b->sets + 1), hipMemcpyHostToDevice, s));
-    GM_HIP(hipMemcpyAsync(b->d_set_row_off, b->h_set_row_off.data(), sizeof(int32_t) * (b->sets + 1), hipMemcpyHostToDevice, s));
-    GM_HIP(hipMemcpyAsync(b->d_graph, b->h_graph.data(), sizeof(int32_t) * b->subs, hipMemcpyHostToDevice, s));
+static int upload_small(gm_batch* b, gm_stager& sg) {
+    GM_TRY(sg.upload(b->d_sub_off, b->h_sub_off)); GM_TRY(sg.upload(b->d_set_sub_off, b->h_set_sub_off));
+    GM_TRY(sg.upload(b->d_set_row_off, b->h_set_row_off)); GM_TRY(sg.upload(b->d_graph, b->h_graph));
     return GM_OK;
 }
 
@@ -826,16 +831,17 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
 #define EX_TRY(x) do { rc = (x); if (rc != GM_OK) { cleanup(); batch_free(b); delete b; return rc; } } while (0)
 #define EX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm_set_error("%s: %s", #x, hipGetErrorString(e_)); cleanup(); batch_free(b); delete b; return GM_EHIP; } } while (0)
     tm.lap("validate");
+    gm_stager sg(st);                          // pinned staging: the build makes TWO host round trips (subgraph sizes, finalisation)
     EX_TRY(gm_alloc(&d_seeds, n_seeds, st));
     EX_TRY(gm_alloc(&d_nodes, (size_t)n_seeds * cap, st)); EX_TRY(gm_alloc(&d_degi, (size_t)n_seeds * cap, st));
     EX_TRY(gm_alloc(&d_dego, (size_t)n_seeds * cap, st));
     EX_TRY(gm_alloc(&d_nsub, n_seeds, st)); EX_TRY(gm_alloc(&d_esub, n_seeds, st));
-    EX_HIP(hipMemcpyAsync(d_seeds, seeds, sizeof(gm_seed_t) * n_seeds, hipMemcpyHostToDevice, st));
+    EX_TRY(sg.upload(d_seeds, seeds, sizeof(gm_seed_t) * n_seeds));
     if (given) {
         const int64_t tot = nodes_off[n_seeds];
         EX_TRY(gm_alloc(&d_given, tot, st)); EX_TRY(gm_alloc(&d_given_off, n_seeds + 1, st));
-        EX_HIP(hipMemcpyAsync(d_given, nodes_flat, sizeof(int32_t) * tot, hipMemcpyHostToDevice, st));
-        EX_HIP(hipMemcpyAsync(d_given_off, nodes_off, sizeof(int64_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
+        EX_TRY(sg.upload(d_given, nodes_flat, sizeof(int32_t) * tot));
+        EX_TRY(sg.upload(d_given_off, nodes_off, sizeof(int64_t) * (n_seeds + 1)));
     }
     gm_prof_begin(GM_PROF_EX_NODES, st, n_seeds);
     if (gpath) {
@@ -848,9 +854,8 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     }
     gm_prof_end(GM_PROF_EX_NODES, st);
     EX_HIP(hipGetLastError());
-    std::vector<int32_t> nsub(n_seeds), esub(n_seeds);
-    EX_HIP(hipMemcpyAsync(nsub.data(), d_nsub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
-    EX_HIP(hipMemcpyAsync(esub.data(), d_esub, sizeof(int32_t) * n_seeds, hipMemcpyDeviceToHost, st));
+    const int32_t* nsub = sg.download(d_nsub, (size_t)n_seeds); const int32_t* esub = sg.download(d_esub, (size_t)n_seeds);
+    if (!nsub || !esub) { gm_set_error("extract: pinned staging failed"); cleanup(); batch_free(b); delete b; return GM_ENOMEM; }
     EX_HIP(hipStreamSynchronize(st));
 
     tm.lap("k_nodes+sizes");
@@ -874,9 +879,9 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     b->h_set_row_off.resize(n_sets + 1);
     for (int s = 0; s <= n_sets; ++s) b->h_set_row_off[s] = b->h_sub_off[set_offsets[s]];
     EX_TRY(batch_alloc(b, st));
-    EX_TRY(upload_small(b, st));
+    EX_TRY(upload_small(b, sg));
     EX_TRY(gm_alloc(&d_eoff, n_seeds + 1, st));
-    EX_HIP(hipMemcpyAsync(d_eoff, eoff.data(), sizeof(int32_t) * (n_seeds + 1), hipMemcpyHostToDevice, st));
+    EX_TRY(sg.upload(d_eoff, eoff));
     gm_prof_begin(GM_PROF_EX_FILL, st, n_seeds);
     if (gpath) {
         hipLaunchKernelGGL(k_fill<true>, dim3(n_seeds), dim3(EX_BLOCK), sizeof(uint32_t) * (EX_BLOCK + 16), st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap,
@@ -890,10 +895,9 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     }
     gm_prof_end(GM_PROF_EX_FILL, st);
     EX_HIP(hipGetLastError());
-    EX_HIP(hipStreamSynchronize(st));   // eoff (host vector) must outlive the async copy; also surfaces kernel faults here
     tm.lap("alloc+k_fill");
     gm_prof_begin(GM_PROF_EX_FINAL, st, 1);
-    rc = gm_batch_finalize(b, st);
+    rc = gm_batch_finalize(b, st, sg);
     gm_prof_end(GM_PROF_EX_FINAL, st);
     EX_TRY(rc);
     tm.lap("finalize");
@@ -955,9 +959,9 @@ extern "C" int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, 
         r0 += q->rows; e0 += q->edges; s0 += q->subs;
     }
     if (hipGetLastError() != hipSuccess) { batch_free(b); delete b; gm_set_error("concat: copy kernel launch failed"); return GM_EHIP; }
-    rc = upload_small(b, st);
-    if (rc == GM_OK && hipStreamSynchronize(st) != hipSuccess) { gm_set_error("concat: stream sync failed"); rc = GM_EHIP; }
-    if (rc == GM_OK) rc = gm_batch_finalize(b, st);
+    gm_stager sg(st);
+    rc = upload_small(b, sg);
+    if (rc == GM_OK) rc = gm_batch_finalize(b, st, sg);
     if (rc != GM_OK) { batch_free(b); delete b; return rc; }
     *out = b;
     return GM_OK;

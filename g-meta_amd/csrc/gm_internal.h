@@ -146,10 +146,18 @@ struct gm_batch {
     int32_t* d_e1_chunks = nullptr; int32_t* d_e1_set_chunk_off = nullptr; int32_t n_e1_chunks = 0;
     mutable gm_cone* cone[GM_MAX_GCN + 1] = {};     // receptive-field tables per number of GCN layers (gm_hparams_t.cone)
     hipStream_t stream = nullptr;      // stream the arrays were produced on (and are freed on, stream-ordered)
+    // The ~45 device arrays above are carved out of a few slabs (gm_balloc): a stream-ordered allocation or free costs the host 20-35 us, and a
+    // meta-batch builds and drops two batches per step (3 ms of frees in Subgraphs.get_batch before this)
+    struct slab { char* base; size_t cap, used; };
+    std::vector<slab> slabs;
     mutable hipEvent_t used_ev = nullptr;   // last consumer on ANOTHER stream: the frees wait for it (gm_batch_mark_use)
 };
-int gm_batch_finalize(gm_batch* b, hipStream_t s);
-int gm_batch_gains(const gm_batch* b, hipStream_t s);     // d_gain at first use (two-piece kernels only)
+struct gm_stager;
+int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg);
+int gm_batch_gains(const gm_batch* b, hipStream_t s);
+// n elements of T from the batch's slabs (256-byte aligned; lives until the batch is destroyed)
+int gm_balloc_bytes(gm_batch* b, void** p, size_t bytes, hipStream_t s);
+template <class T> static inline int gm_balloc(gm_batch* b, T** p, size_t n, hipStream_t s) { return gm_balloc_bytes(b, (void**)p, (n ? n : 1) * sizeof(T), s); }     // d_gain at first use (two-piece kernels only)
 // A consumer that ran kernels over the batch on `st` calls this afterwards: gm_batch_destroy then orders its frees behind
 // that work instead of relying on the host having synchronised (deferred read-back, prefetch threads).
 void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
@@ -195,6 +203,29 @@ int gm_dev_alloc(void** p, size_t bytes, hipStream_t s);
 void gm_dev_free(void* p, hipStream_t s);
 template <class T>
 static inline int gm_alloc(T** p, size_t n, hipStream_t s) { return gm_dev_alloc((void**)p, (n ? n : 1) * sizeof(T), s); }
+
+// ---- pinned staging for batch builds.  A hipMemcpyAsync from / to PAGEABLE host memory waits for the stream on the host (and the callers used
+// to add a hipStreamSynchronize so that their std::vectors could go out of scope): every small table of a batch build was a host round trip,
+// and under a saturated GPU (extraction prefetched while a meta-step runs) each round trip waits for the build's kernel to get a CU -- ~20 of them
+// made one extraction as long as the meta-step it was meant to hide behind.  A gm_stager hands out pinned host memory from a per-thread pool;
+// copies through it are truly asynchronous and the memory returns to the pool once the stream has passed the stager's end.
+struct gm_stager {
+    hipStream_t s;
+    std::vector<int> used;           // pool chunks this build holds
+    char* cur = nullptr; size_t left = 0;
+    explicit gm_stager(hipStream_t st) : s(st) {}
+    ~gm_stager();
+    gm_stager(const gm_stager&) = delete;
+    gm_stager& operator=(const gm_stager&) = delete;
+    void* take(size_t bytes);                                        // pinned, 64-byte aligned; NULL when the host allocation fails
+    int upload(void* dptr, const void* src, size_t bytes);           // src (any host memory) -> staging -> device, asynchronous
+    template <class T> int upload(T* dptr, const std::vector<T>& v) { return v.empty() ? GM_OK : upload((void*)dptr, (const void*)v.data(), v.size() * sizeof(T)); }
+    template <class T> T* download(const T* dsrc, size_t n) {        // device -> pinned (valid after the caller synchronises `s`); NULL on failure
+        T* h = (T*)take((n ? n : 1) * sizeof(T));
+        if (h && n && hipMemcpyAsync(h, dsrc, n * sizeof(T), hipMemcpyDeviceToHost, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return h;
+    }
+};
 
 // ---- layout helpers
 struct gm_layout {
@@ -254,7 +285,8 @@ int gm_agg_window(int64_t rows, int64_t edges);
 // equal length out->len; entry >= 0: window block id, <= -2: hub part -(entry) - 2 (hub row heavy[..] itself when the rows are not
 // split: out->d_hub == NULL), -1: nothing.  A hub row's blocks follow the window block that contains the row, on the XCD whose L2 is
 // streaming that subgraph.  heavy_deg_host: the rows' edge counts (NULL: never split).
-int gm_agg_schedule(int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s);
+struct gm_stager;
+int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s, gm_stager* sg);
 int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG; default by density, see gm_heavy_deg_for)
 int gm_heavy_deg_for(int64_t rows, int64_t edges);
 int gm_launch_aggregate(const gm_agg_args& a, hipStream_t s);

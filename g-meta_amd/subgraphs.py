@@ -255,6 +255,11 @@ class Subgraphs(Dataset):
         else:
             raise ValueError("task_setup must be 'Disjoint' or 'Shared'")
         self._task_memo = {}          # per-task seed / raw-label arrays (the names never change after create_batch_*)
+        # The name -> (graph, i, j) parsing of sdp.py:355-362 is pure Python (~3 ms per 32-task meta-batch): done here, once, with the task
+        # lists -- in the prefetch thread it would hold the GIL against the training thread between two meta-steps
+        if len(self.support_x_batch) <= 65536:
+            for i in range(len(self.support_x_batch)):
+                self._task_arrays(i)
 
     # ---- CSV index (sdp.py:119-148): columns (pandas index, name, label); label kept as string
     @staticmethod
@@ -480,7 +485,9 @@ class Subgraphs(Dataset):
         ys_yq = [self._labels(a[2], a[3]) for a in arrs]
         return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])
 
-    def batches(self, index_lists, prefetch=1, cone_layers=0):
+    _PREFETCH_PRIORITY = 0      # stream priority of the prefetch thread (a high-priority stream measured no better: extraction is host-bound)
+
+    def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None):
         """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being extracted by a
         background thread on its own HIP stream while the caller runs the meta-step on the current one -- what
         DataLoader(num_workers>0) does for the reference (train.py:96,173), minus the per-worker copy of the memo cache
@@ -499,7 +506,7 @@ class Subgraphs(Dataset):
         def work():
             try:
                 torch.cuda.set_device(dev)
-                side = torch.cuda.Stream()
+                side = torch.cuda.Stream(priority=self._PREFETCH_PRIORITY if priority is None else int(priority))
                 with torch.cuda.stream(side):
                     for idx in index_lists:
                         if stop.is_set():
