@@ -203,6 +203,23 @@ __global__ __launch_bounds__(256) void k_amax_segs(const float* x, AmaxSegs sg, 
     if ((threadIdx.x & 63) == 0) gs_note_max(out + (int64_t)blockIdx.y * out_stride, __float_as_uint(m));
 }
 
+// 4 x 4 transpose inside every quad of lanes, registers <-> lanes (DPP quad permutes, no LDS): in: register k of lane t = M[k][t];
+// out: register k of lane t = M[t][k].  The 32 x 32 MFMA accumulator holds, in registers 4g .. 4g+3 of lane li, rows 8g + 4kh + (0..3) of
+// COLUMN li; after the transpose lane 4q + t holds row 8g + 4kh + t, columns 4q .. 4q+3 -- a 16-byte store per lane, 128 contiguous bytes
+// per row and store instruction.
+template <int CTRL> __device__ __forceinline__ float gs_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ void gs_quad_transpose(float& a0, float& a1, float& a2, float& a3, const bool odd1, const bool odd2) {
+    // stage 1: bit 0 of the register index <-> bit 0 of the lane (quad_perm [1,0,3,2] = 0xB1)
+    const float p1 = gs_dpp<0xB1>(a1), q0 = gs_dpp<0xB1>(a0), p3 = gs_dpp<0xB1>(a3), q2 = gs_dpp<0xB1>(a2);
+    const float b0 = odd1 ? p1 : a0, b1 = odd1 ? a1 : q0, b2 = odd1 ? p3 : a2, b3 = odd1 ? a3 : q2;
+    // stage 2: bit 1 (quad_perm [2,3,0,1] = 0x4E)
+    const float r2 = gs_dpp<0x4E>(b2), s0 = gs_dpp<0x4E>(b0), r3 = gs_dpp<0x4E>(b3), s1 = gs_dpp<0x4E>(b1);
+    a0 = odd2 ? r2 : b0; a2 = odd2 ? b2 : s0;
+    a1 = odd2 ? r3 : b1; a3 = odd2 ? b3 : s1;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // PERSISTENT, wave-specialised split-bf16 GEMM for N == 256 or 128 (one 128 x N tile per step, 16-k chunks):
 //   waves 0..7    COMPUTE  64x64 sub-tiles: LDS fragments -> 24 bf16 MFMAs per chunk; at the end of a tile the accumulators go
@@ -234,7 +251,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
     constexpr int A_ST = NP * A_PLANE, B_ST = NP * B_PLANE, NB = 3;
     static_assert(NP == 2 || NP == 3, "pieces per operand");
     constexpr int OFF_B = 2 * A_ST;
-    constexpr int EP_LD = 68, E_WAVE = 16 * EP_LD * 4;                                // 4352 B per compute wave
+    constexpr int E_WAVE = 0;                                                         // (no epilogue staging: the accumulators are transposed in registers)
     constexpr int OFF_E = OFF_B + NB * B_ST, OFF_SC = OFF_E + 8 * E_WAVE, OFF_BIAS = OFF_SC + 2 * GS_BM * 4;
     constexpr int A_PER = (BM * BK / 4) / 256;                                        // float4 per A-feeder lane and chunk: MI (four feeder waves)
     constexpr int B_PPW = (NP * 2 * (BN / 64)) / 4;                                   // DMA pieces per B-feeder wave and chunk: 6 (N = 256) / 3
@@ -493,8 +510,6 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
         const int wr = wave / WC, wc = wave % WC, li = lane & 31, kh = lane >> 5;
         const int a_lane = kh * A_OCT + (wr * 32 * MI + li) * 16, b_lane = OFF_B + kh * B_OCT + (wc * 64 + li) * 16;
         int b_st = 0;                                                                 // B stage of the current chunk (gc % NB)
-        float* E = reinterpret_cast<float*>(smem + OFF_E + wave * E_WAVE);
-        const int er = lane >> 4, ec = (lane & 15) * 4;
         GS_BARRIER();
         int gc = 0;
         float vmax = 0.f; int vmax_set = -1;                      // amax_out: running bound of this wave's blocks, flushed when the set changes
@@ -573,47 +588,51 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                 }
                 GS_BARRIER();
             }
-            // ---- epilogue of tile ti: wave-private staging, stores only (no global load, no barrier)
+            // ---- epilogue of tile ti: stores only (no global load, no barrier, no LDS staging).  The accumulators are transposed inside the
+            // quads of lanes (gs_quad_transpose) so that a lane stores 16 bytes of ONE row and eight lanes cover 128 contiguous bytes of it; the
+            // LDS round trips of the staged epilogue (8.6 k of a tile's 47 k cycles with the matrix pipe idle) are gone.
             const GsTile tl = tile_of(b + ti * G);                // scalar (SMEM) loads: lgkmcnt, not vmcnt
             const int row0 = tl.row0, nrows = tl.nrows;
             const float* sc_t = scales + (ti & 1) * GS_BM;
-            const int col = wc * 64 + ec;
-            const float4 b4 = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + col);
+            const int t4 = li & 3, q4 = li >> 2;
+            const bool odd1 = (li & 1) != 0, odd2 = (li & 2) != 0;
+            float4 b4[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + wc * 64 + j * 32 + q4 * 4);
             if constexpr (NP == 2) { if (g.amax_out && tl.set != vmax_set) { if (vmax_set >= 0) vmax_flush(); vmax_set = tl.set; } }
 #pragma unroll
-            for (int ih = 0; ih < 2 * MI; ++ih) {                  // 16 rows of the wave's block at a time: accumulator registers e with (e >> 3) == ih & 1
-                const int i = ih >> 1, h = ih & 1;
+            for (int i = 0; i < MI; ++i) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int e8 = 0; e8 < 8; ++e8) E[((e8 & 3) + 8 * (e8 >> 2) + 4 * kh) * EP_LD + j * 32 + li] = acc[i][j][h * 8 + e8];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int rl = wr * 32 * MI + i * 32 + h * 16 + it * 4 + er;
-                    if (rl >= nrows) continue;
-                    const int64_t row = row0 + rl;
+                for (int gq = 0; gq < 4; ++gq) {                  // registers 4 gq .. 4 gq + 3: rows 8 gq + 4 kh + (0..3) of the wave's 32-row block i
+                    const int rl = wr * 32 * MI + i * 32 + gq * 8 + kh * 4 + t4;
                     const float sc = sc_t[rl];
-                    float4 v = *reinterpret_cast<const float4*>(&E[(it * 4 + er) * EP_LD + ec]);
-                    v.x = v.x * sc + b4.x; v.y = v.y * sc + b4.y; v.z = v.z * sc + b4.z; v.w = v.w * sc + b4.w;
-                    if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
-                    if constexpr (NP == 2) { if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
-                    if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
-                    if (g.nt_store) {
-                        typedef float f4v __attribute__((ext_vector_type(4)));
-                        f4v vv = {v.x, v.y, v.z, v.w};
-                        __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
-                    } else {
-                        *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
-                    }
-                    if (g.zero_out) {                       // zeros made here: a loop-invariant zero quad gets hoisted and, at 128 VGPRs, spilled
-                        typedef float f4z __attribute__((ext_vector_type(4)));
-                        f4z z;
-                        asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z.x), "=v"(z.y), "=v"(z.z), "=v"(z.w));
-                        *reinterpret_cast<f4z*>(g.zero_out + row * g.ldc + col) = z;
+                    const int64_t row = row0 + rl;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float a0 = acc[i][j][gq * 4 + 0], a1 = acc[i][j][gq * 4 + 1], a2 = acc[i][j][gq * 4 + 2], a3 = acc[i][j][gq * 4 + 3];
+                        gs_quad_transpose(a0, a1, a2, a3, odd1, odd2);
+                        float4 v;
+                        v.x = a0 * sc + b4[j].x; v.y = a1 * sc + b4[j].y; v.z = a2 * sc + b4[j].z; v.w = a3 * sc + b4[j].w;
+                        if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
+                        if (rl >= nrows) continue;
+                        const int col = wc * 64 + j * 32 + q4 * 4;
+                        if constexpr (NP == 2) { if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
+                        if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
+                        if (g.nt_store) {
+                            typedef float f4v __attribute__((ext_vector_type(4)));
+                            f4v vv = {v.x, v.y, v.z, v.w};
+                            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));
+                        } else {
+                            *reinterpret_cast<float4*>(g.C + row * g.ldc + col) = v;
+                        }
+                        if (g.zero_out) {                       // zeros made here: a loop-invariant zero quad gets hoisted and, at 128 VGPRs, spilled
+                            typedef float f4z __attribute__((ext_vector_type(4)));
+                            f4z z;
+                            asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 0\n\tv_mov_b32 %2, 0\n\tv_mov_b32 %3, 0" : "=v"(z.x), "=v"(z.y), "=v"(z.z), "=v"(z.w));
+                            *reinterpret_cast<f4z*>(g.zero_out + row * g.ldc + col) = z;
+                        }
                     }
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
         if constexpr (NP == 2) { if (g.amax_out && vmax_set >= 0) vmax_flush_last(); }     // (bit patterns of non-negative floats order as integers)
