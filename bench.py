@@ -560,6 +560,22 @@ def main():
                       'note': 'latency-bound integer work: one workgroup per subgraph, adjacency lists walked through dependent loads; the induced '
                               'subgraphs are built in two phases (count, then fill) so the lists are walked twice against the one pass priced here'}
         del bx
+    # ---- the one collective of a sharded meta-step, timed on its own (same buffer size, same stream): what the step's value already contains
+    allreduce = None
+    if use_dist:
+        P_ = sum(p.numel() for p in maml.net.parameters())
+        buf = torch.zeros(P_ + 2 * (cfg['update_step'] + 1) + 1, dtype=torch.float32, device='cuda')
+        for _ in range(5):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 50
+        ev0.record()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        ev1.record(); torch.cuda.synchronize()
+        allreduce = {'us_per_call': round(ev0.elapsed_time(ev1) / reps * 1e3, 2), 'bytes': int(buf.numel() * 4), 'ranks': world,
+                     'what': 'torch.distributed.all_reduce(SUM) of [grad | losses_q | corrects | count] over RCCL, %d back-to-back calls between two events' % reps}
     if use_dist:                           # tear the communicator down before printing: nothing follows the JSON line
         dist.barrier()
         dist.destroy_process_group()
@@ -682,6 +698,8 @@ def main():
                                      'labelled_extra_ms_if_all_flops_ran_at_fp32_mfma_peak': round(t_f32, 2),
                                      'note': 'split launches priced at 6 (bf16, three pieces) or 3 (fp16, two pieces) MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
                                              'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
+        if allreduce:
+            out['allreduce'] = allreduce
         if extraction:
             out['extraction'] = extraction
         if e2e:

@@ -172,6 +172,7 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int head_threads;              // GM_HEAD_THREADS: workgroup size of k_head_loss (256 / 512 / 1024; 0 = by the task's row count)
     int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
     int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks

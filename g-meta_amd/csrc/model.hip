@@ -230,8 +230,9 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
 
 // Head forward + prototypical loss (+ head backward and the SGD of the head's own parameters) of one set per block: the
 // five launches between the last GCN layer of a forward and the first weight gradient of its backward, in one.
-#define HL_THREADS 1024
-__global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
+#define HL_THREADS 1024     // largest workgroup of k_head_loss (LDS sizing)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
                                                           float* Gc, SgdK u, int stage, int proto_floats) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int set = blockIdx.x, tid = threadIdx.x;
@@ -254,62 +255,62 @@ __global__ __launch_bounds__(HL_THREADS) void k_head_loss(HeadK hk, float* logit
         rows_l = crow + S * hk.nc;                                      // [Ct * n] the set's class rows (subgraph ids)
         const int nq = S * hk.nc;
         // first round trip, everything that needs no other load: centre rows (two loads each), class rows, head weights
-        for (int q = tid; q < nq; q += HL_THREADS) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
+        for (int q = tid; q < nq; q += NT) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
         {
             const int off = pk.tab[set * 3], Qs = pk.tab[set * 3 + 1] * pk.tab[set * 3 + 2];
-            for (int q = tid; q < Qs; q += HL_THREADS) rows_l[q] = pk.rows[off + q];
+            for (int q = tid; q < Qs; q += NT) rows_l[q] = pk.rows[off + q];
         }
-        for (int id = tid; id < hk.C * hk.hc; id += HL_THREADS) wl_s[id] = P[hk.wl_off + id];
-        for (int id = tid; id < hk.C; id += HL_THREADS) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
+        for (int id = tid; id < hk.C * hk.hc; id += NT) wl_s[id] = P[hk.wl_off + id];
+        for (int id = tid; id < hk.C; id += NT) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
         __syncthreads();
         // second round trip: the centre rows of H_L, all loads of a thread in flight together (16-byte loads when the rows allow it)
         if ((hk.Hd & 3) == 0 && (hk.ldh & 3) == 0 && ((uintptr_t)hk.H & 15) == 0) {
             const int hd4 = hk.Hd >> 2, total4 = nq * hd4;
-            for (int id0 = tid; id0 < total4; id0 += 8 * HL_THREADS) {
+            for (int id0 = tid; id0 < total4; id0 += 8 * NT) {
                 float4 v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int id = min(id0 + u * HL_THREADS, total4 - 1), q = id / hd4, c4 = id - q * hd4;
+                    const int id = min(id0 + u * NT, total4 - 1), q = id / hd4, c4 = id - q * hd4;
                     v[u] = *reinterpret_cast<const float4*>(hk.H + (int64_t)crow[q] * hk.ldh + c4 * 4);
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total4) *reinterpret_cast<float4*>(hs + (int64_t)id * 4) = v[u]; }
+                for (int u = 0; u < 8; ++u) { const int id = id0 + u * NT; if (id < total4) *reinterpret_cast<float4*>(hs + (int64_t)id * 4) = v[u]; }
             }
         } else {
             const int total = nq * hk.Hd;
-            for (int id0 = tid; id0 < total; id0 += 8 * HL_THREADS) {
+            for (int id0 = tid; id0 < total; id0 += 8 * NT) {
                 float v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    const int id = min(id0 + u * HL_THREADS, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
+                    const int id = min(id0 + u * NT, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
                     v[u] = hk.H[(int64_t)crow[q] * hk.ldh + col];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int id = id0 + u * HL_THREADS; if (id < total) hs[id] = v[u]; }
+                for (int u = 0; u < 8; ++u) { const int id = id0 + u * NT; if (id < total) hs[id] = v[u]; }
             }
         }
         lg = lg_s;                              // LDS copies hold the set's subgraphs only: indexed relative to s0 (base below)
-        if (pk.dlogits) { dl = dl_s; for (int id = tid; id < S * D; id += HL_THREADS) dl_s[id] = 0.f; }
+        if (pk.dlogits) { dl = dl_s; for (int id = tid; id < S * D; id += NT) dl_s[id] = 0.f; }
         __syncthreads();
     } else if (pk.dlogits) {
-        for (int id = tid; id < S * D; id += HL_THREADS) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
+        for (int id = tid; id < S * D; id += NT) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
     }
     const int base = stage ? s0 : 0;
-    for (int s = s0 + (tid >> 6); s < s1; s += HL_THREADS / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s, base);
+    for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s, base);
     __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
     ProtoK pl = pk;
     pl.logits = lg; pl.dlogits = dl; pl.row_base = base;
-    proto_set<HL_THREADS>(pl, set, tid, sm, rows_l);
+    proto_set<NT>(pl, set, tid, sm, rows_l);
     if (stage) {              // the global copies (API / debugging): logits always, dlogits when requested
         __syncthreads();
-        for (int id = tid; id < S * D; id += HL_THREADS) {
+        for (int id = tid; id < S * D; id += NT) {
             logits[(int64_t)s0 * D + id] = lg[id];
             if (pk.dlogits) pk.dlogits[(int64_t)s0 * D + id] = dl[id];
         }
     }
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<HL_THREADS>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base, crow);
+    head_bwd_set<NT>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base, crow);
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -1071,9 +1072,15 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     const int stage_on = gm_knob().head_stage;
     const int stage_h = stage_on && proto_bytes + hs_bytes <= 150 * 1024;
     const size_t lds = proto_bytes + (stage_h ? hs_bytes : 0);
-    GM_TRY(gm_func_full_lds((const void*)k_head_loss));
-    hipLaunchKernelGGL(k_head_loss, dim3(b->sets), dim3(HL_THREADS), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc,
-                       bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f}, stage_h, (int)(proto_bytes / sizeof(float)));
+    // Workgroup size (GM_HEAD_THREADS, default 1024): one workgroup per task.  Measured: 256 threads -- which could start on a CU that a persistent
+    // GEMM workgroup of the other stream fills -- lose more inside the kernel than they gain at its start (FirstMM shape 1.62 -> 1.89 ms per
+    // meta-step, 4-task arxiv shard 4.59 -> 4.86; 512: 1.71 / 4.67).
+    int nt = gm_knob().head_threads;
+    if (nt != 256 && nt != 512) nt = 1024;
+    const SgdK sg = bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f};
+    if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
+    else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
+    else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
     GM_HIP(hipGetLastError());
     if (bwd && dQ && hk.dq_amax) c.dqv = true;
     return GM_OK;
