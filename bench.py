@@ -94,6 +94,18 @@ def extraction_bytes(store, db, idx, batch, h, link):
     return {'expand': int(expand), 'induce': int(induce), 'write': int(write)}
 
 
+def launch_classes(launches):
+    """The aggregate launches of one serialised step grouped by their algorithmic bytes: count, bytes, time and rate per class."""
+    out = []
+    for name, lo_b, hi_b in (('< 64 MB', 0, 64e6), ('64-512 MB', 64e6, 512e6), ('0.5-1.5 GB', 512e6, 1.5e9), ('>= 1.5 GB', 1.5e9, 1e18)):
+        sel = [(m, w) for m, w in launches if lo_b <= w < hi_b and m > 0]
+        if sel:
+            ms, by = sum(m for m, _ in sel), sum(w for _, w in sel)
+            out.append({'algorithmic_bytes': name, 'launches': len(sel), 'gb': round(by / 1e9, 2), 'ms': round(ms, 3), 'gb_per_s': round(by / (ms * 1e-3) / 1e9, 1),
+                        'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)})
+    return out
+
+
 def shard_bounds(T, world):
     """Contiguous task ranges of a meta-batch per rank (sizes differ by at most one)."""
     return np.linspace(0, T, world + 1).round().astype(int)
@@ -400,6 +412,7 @@ def main():
     # serialize=1 (same inputs, same launches, one stream) -- the rocprofv3 summary under profiles/ uses the same mode.
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
     gemm_bytes = ov_gemm_bytes
+    agg_launches = []
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
@@ -418,6 +431,11 @@ def main():
                 ms, n, fl = prof_read(cat)
                 mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
             gemm_bytes += prof_read(11)[2]
+            if k == a.roofline_steps - 1:           # per-launch view of the last serialised step: which launches carry the mix
+                cap = 512
+                ms_a, wk_a = (C.c_double * cap)(), (C.c_int64 * cap)()
+                n_l = lib.gm_profile_read_launches(0, ms_a, wk_a, cap)
+                agg_launches = [(ms_a[i], wk_a[i]) for i in range(max(n_l, 0))]
         maml.serialize = 0
         ser_steps = a.roofline_steps
     lib.gm_profile_enable(0)
@@ -642,6 +660,7 @@ def main():
                          'measured': 'HIP events on the launch stream over %s' % ('the timed region (serialize=1)' if a.serialize else
                                      '%d serialised steps run right after the timed region' % a.roofline_steps),
                          'achieved_while_overlapped': round(ov_bytes / (ov_ms * 1e-3) / 1e9, 1) if ov_ms > 0 else None,
+                         'by_launch_size': launch_classes(agg_launches),
                          'launch_mix': ('full launches (support chain, the differentiated query pass) AND the partial launches of the forward-only query passes, '
                                         'whose 0..2-source rows are aggregated inside the fused aggregate+GEMM kernel: those launches are priced with B_agg '
                                         'restricted to what they touch (every indptr entry; indices, norms and output rows of the >=3-source rows; their '

@@ -63,6 +63,7 @@ PROTOTYPES = {
     'gm_profile_enable': (None, [i32]),
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
     'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),
+    'gm_profile_read_launches': (C.c_int, [i32, vp, vp, i32]),
 }
 
 _lib = None

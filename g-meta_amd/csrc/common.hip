@@ -146,6 +146,7 @@ extern "C" int64_t gm_model_param_count(const gm_model_t* m) {
 // HIP events around every launch of a category, recorded on the stream the kernel is launched on.
 struct ProfCat {
     std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int64_t> works;   // work of every timed launch, in launch order
     size_t used = 0;
     int64_t work = 0, launches = 0;
     bool open = false;
@@ -169,6 +170,8 @@ void gm_prof_begin(int cat, hipStream_t s, int64_t work) {
     }
     (void)hipEventRecord(c.ev[c.used], s);
     c.work += work; c.launches += 1; c.open = true;
+    if (c.works.size() < c.used / 2 + 1) c.works.resize(c.used / 2 + 1);
+    c.works[c.used / 2] = work;
 }
 bool gm_prof_enabled() { return g_prof_on != 0; }
 void gm_prof_reset_cat(int cat) { ProfCat& c = g_prof[cat]; c.used = 0; c.work = 0; c.launches = 0; c.open = false; }
@@ -194,6 +197,19 @@ extern "C" int gm_profile_read(int32_t category, double* total_ms, int64_t* laun
     if (launches) *launches = c.launches;
     if (work) *work = c.work;
     return GM_OK;
+}
+// Per-launch view of one category: ms[k], work[k] of the k-th timed launch since the last reset (up to cap); returns the number of launches.
+extern "C" int gm_profile_read_launches(int32_t category, double* ms, int64_t* work, int32_t cap) {
+    GM_REQUIRE(category >= 0 && category < GM_PROF_CATS && ms && work && cap >= 0, GM_EINVAL, "profile_read_launches: bad arguments");
+    ProfCat& c = g_prof[category];
+    int n = 0;
+    for (size_t k = 0; k + 1 < c.used + 1 && k < c.used && n < cap; k += 2, ++n) {
+        GM_HIP(hipEventSynchronize(c.ev[k + 1]));
+        float t = 0;
+        GM_HIP(hipEventElapsedTime(&t, c.ev[k], c.ev[k + 1]));
+        ms[n] = t; work[n] = k / 2 < c.works.size() ? c.works[k / 2] : 0;
+    }
+    return n;
 }
 extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithmic_bytes) {
     return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);

@@ -49,7 +49,7 @@ class Meta(nn.Module):
         self._flat_theta_buf = None
         self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -127,6 +127,22 @@ class Meta(nn.Module):
                 torch.cuda.empty_cache()  # leaving it parked in torch's caching allocator next to the new, larger one
             self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         return self._ws
+
+    def _readback(self, t):
+        """Asynchronous device -> pinned-host copy of `t` on the current stream; returns a slot [pinned buffer, event, busy] whose first
+        t.numel() floats hold the data once the event has completed.  Slots are reused after their handle has been read (a handle of
+        Meta.forward_deferred may be read any number of steps late: an unread slot is never overwritten, a new one is pinned instead)."""
+        ring = getattr(self, '_rb_ring', None)
+        if ring is None:
+            ring = self._rb_ring = []
+        slot = next((r for r in ring if not r[2] and r[0].numel() >= t.numel()), None)
+        if slot is None:
+            slot = [torch.empty(max(t.numel(), 1024), dtype=torch.float32, pin_memory=True), torch.cuda.Event(), False]
+            ring.append(slot)
+        slot[2] = True
+        slot[0][:t.numel()].copy_(t, non_blocking=True)
+        slot[1].record()
+        return slot, t.numel()
 
     def _run(self, x_spt, y_spt, x_qry, y_qry, K, need_grad):
         """One gm_meta_step over the local tasks.  Returns (out tensor [P + 2(K+1) + 1 + T(K+1) + 1], P, T); the last float is the
@@ -214,6 +230,9 @@ class Meta(nn.Module):
             else:
                 torch.distributed.all_reduce(head, op=torch.distributed.ReduceOp.SUM)
         if head.is_cuda and self._adam_fused:
+            # The read-back of [losses_q | corrects | count | per-task | violation] is queued BEFORE the guard and the optimiser kernels (it does not
+            # depend on them): the host gets the accuracies ~50 us earlier and prepares the next meta-step while Adam still runs
+            rb = self._readback(out[P:])
             # mean + NaN guard on the device (gm_meta_finish), then the fused Adam with `found_inf`: the kernel skips the
             # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)
             fg = self._bind_grads(head.device)               # (stands for meta_optim.zero_grad(); loss_q.backward())
@@ -223,7 +242,7 @@ class Meta(nn.Module):
             self.meta_optim.found_inf = self._found_inf
             self.meta_optim.grad_scale = None
             self.meta_optim.step()
-            return _Deferred(self, out[P:], K1, applied=True, rerun=rerun)
+            return _Deferred(self, rb, K1, applied=True, rerun=rerun)
         # Non-fused Adam (optim.Adam(fused=True) unavailable) or CPU tensors: the NaN guard needs the loss on the host, so the update is
         # applied HERE -- every meta-batch steps the optimiser like meta.py:163-169, whether or not the caller ever reads the
         # accuracies (train.py only reads them on report steps); only the handle's bookkeeping is left for .accs()
@@ -289,8 +308,8 @@ class Meta(nn.Module):
 def _labels(ys):
     """The per-task label arrays of a meta-batch as one contiguous int32 vector (torch CPU tensors or numpy arrays)."""
     if len(ys) and all(isinstance(y, torch.Tensor) and not y.is_cuda for y in ys):
-        return torch.cat([y.reshape(-1) for y in ys]).to(torch.int32).numpy()      # one op instead of a numpy view per tensor
-    return np.ascontiguousarray(np.concatenate([np.asarray(y).reshape(-1) for y in ys]), np.int32)
+        ys = [y.numpy() for y in ys]                                               # (views: no copy)
+    return np.concatenate([np.asarray(y).reshape(-1) for y in ys]).astype(np.int32, copy=False)
 
 
 def gather_rows(mine, bounds, width):
@@ -321,8 +340,11 @@ class _Deferred:
         if self._accs is not None:
             return self._accs
         m, K1 = self._meta, self._K1
-        if self._applied:                                     # device path: Adam already queued, buf = [losses_q | corrects | count | per-task | violation]
-            tail = self._buf.cpu().numpy().astype(np.float64)
+        if self._applied:                                     # device path: Adam already queued, buf = (pinned [losses_q | corrects | count | per-task | violation], event)
+            slot, n = self._buf
+            slot[1].synchronize()
+            tail = slot[0][:n].numpy().astype(np.float64)
+            slot[2] = False                                   # (astype copied: the pinned slot may be reused)
         else:                                                 # host path (non-fused Adam / CPU tensors): guard + step here
             head, P = self._buf, self._P
             tail = head[P:].cpu().numpy().astype(np.float64)
@@ -331,7 +353,7 @@ class _Deferred:
         if self._rerun is not None and np.isnan(loss_q):
             viol = float(tail[-1])
             if m._dist_on() and torch.distributed.get_world_size() > 1:      # every rank sees the NaN of the reduced loss: agree on its cause
-                v = torch.tensor([viol], dtype=torch.float32, device=self._buf.device)
+                v = torch.tensor([viol], dtype=torch.float32, device='cuda')
                 torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX)
                 viol = float(v.item())
             if viol != 0.0:

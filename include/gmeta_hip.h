@@ -246,6 +246,8 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
  * 9 = k_fill (the batched CSR in both orientations), work = subgraphs; 10 = batch finalisation (GPU span including its host round trips).
  * 11 = work-only shadow of categories 4 + 6: compulsory HBM bytes of the split GEMM launches, 4 rows (K + N) (A read once, C written once). */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
+/* The same per launch: ms[k] / work[k] of the k-th timed launch of the category since the last reset (at most cap); returns their number (< 0: error). */
+int gm_profile_read_launches(int32_t category, double* ms, int64_t* work, int32_t cap);
 
 #ifdef __cplusplus
 }
