@@ -420,7 +420,7 @@ int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_hos
         GM_TRY(gm_balloc(b, &out->d_hub, tab.size(), s));
         GM_TRY(sg->upload(out->d_hub, tab));
         GM_TRY(gm_balloc(b, &out->d_hub_scratch, (size_t)tab[n_heavy] * GM_AGG_HUB_LD, s));
-        out->hub_part = hub_part;
+        out->hub_part = hub_part; out->hub_words = (int32_t)tab.size(); out->parts = tab[n_heavy];
     }
     out->len = (int32_t)len;
     return GM_OK;

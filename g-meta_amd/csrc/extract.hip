@@ -558,21 +558,46 @@ void gm_batch_mark_use(const gm_batch* b, hipStream_t st) {
 
 // Hub-part counters / partial rows of orientation o are about to be used by a launch on `s`: if the previous such launch went to ANOTHER
 // stream, order this one behind everything queued there so far (which includes that launch).  Costs nothing while a batch stays on one stream.
-int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s) {
+int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s, int set) {
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    if (b->hub_used[o] && b->hub_stream[o] != s) {
+    const int k = set * 2 + o;
+    if (b->hub_used[k] && b->hub_stream[k] != s) {
         // The remembered stream may have been destroyed by its owner since: a failed record / wait must neither drop the ordering nor leave a
         // sticky error for the next hipGetLastError() -- fall back to draining the device before the scratch is reused.
         bool ordered = false;
-        if (b->hub_ev[o] || hipEventCreateWithFlags(&b->hub_ev[o], hipEventDisableTiming) == hipSuccess)
-            ordered = hipEventRecord(b->hub_ev[o], b->hub_stream[o]) == hipSuccess && hipStreamWaitEvent(s, b->hub_ev[o], 0) == hipSuccess;
+        if (b->hub_ev[k] || hipEventCreateWithFlags(&b->hub_ev[k], hipEventDisableTiming) == hipSuccess)
+            ordered = hipEventRecord(b->hub_ev[k], b->hub_stream[k]) == hipSuccess && hipStreamWaitEvent(s, b->hub_ev[k], 0) == hipSuccess;
         if (!ordered) {
             (void)hipGetLastError();
             GM_HIP(hipDeviceSynchronize());
         }
     }
-    b->hub_used[o] = true; b->hub_stream[o] = s;
+    b->hub_used[k] = true; b->hub_stream[k] = s;
+    return GM_OK;
+}
+
+// Second set of hub-part arrival counters and partial rows: the part tables are copied (device to device, on `s`, behind the batch's build),
+// the counters start at zero like the first set's.
+int gm_batch_hub_alt(const gm_batch* cb, hipStream_t s) {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    gm_batch* b = const_cast<gm_batch*>(cb);
+    bool waited = false;
+    for (int o = 0; o < 2; ++o) {
+        if (!b->d_hub[o] || b->d_hub2[o]) continue;
+        int32_t* h2 = nullptr; float* sc2 = nullptr;
+        GM_TRY(gm_balloc(b, &h2, (size_t)b->hub_words[o], b->stream));
+        GM_TRY(gm_balloc(b, &sc2, (size_t)b->hub_parts[o] * GM_AGG_HUB_LD, b->stream));
+        if (!waited && s != b->stream) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); GM_HIP(hipEventRecord(e, b->stream)); GM_HIP(hipStreamWaitEvent(s, e, 0)); GM_HIP(hipEventDestroy(e)); waited = true; }
+        GM_HIP(hipMemcpyAsync(h2, b->d_hub[o], sizeof(int32_t) * (size_t)b->hub_words[o], hipMemcpyDeviceToDevice, s));
+        // (the first set's counters are zero between launches -- the last arriver resets them -- but a launch of the first set may be in flight on
+        // another stream right now: zero the copy's counters explicitly)
+        const size_t n_heavy = (size_t)b->n_heavy[o], parts = (size_t)b->hub_parts[o];
+        GM_HIP(hipMemsetAsync(h2 + n_heavy + 1 + parts, 0, sizeof(int32_t) * n_heavy, s));
+        b->d_hub2[o] = h2; b->d_hub_scratch2[o] = sc2;
+    }
+    if (waited) gm_batch_mark_use(b, s);
     return GM_OK;
 }
 
@@ -592,7 +617,7 @@ int gm_balloc_bytes(gm_batch* b, void** p, size_t bytes, hipStream_t s) {
 
 static void batch_free(gm_batch* b) {
     hipStream_t s = b->stream;
-    for (int o = 0; o < 2; ++o) if (b->hub_ev[o]) { (void)hipEventDestroy(b->hub_ev[o]); b->hub_ev[o] = nullptr; }
+    for (int o = 0; o < 4; ++o) if (b->hub_ev[o]) { (void)hipEventDestroy(b->hub_ev[o]); b->hub_ev[o] = nullptr; }
     if (b->used_ev) {
         if (hipStreamWaitEvent(s, b->used_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b->used_ev); }
         (void)hipEventDestroy(b->used_ev); b->used_ev = nullptr;
@@ -713,7 +738,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
             if (nh > 1) GM_TRY(sg.upload(b->d_heavy[o], h));
             gm_agg_sched sc;
             GM_TRY(gm_agg_schedule(b, b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s, &sg));
-            b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part;
+            b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part; b->hub_words[o] = sc.hub_words; b->hub_parts[o] = sc.parts;
         }
     }
     tm.lap("heavy");

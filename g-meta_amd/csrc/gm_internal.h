@@ -117,10 +117,14 @@ struct gm_batch {
     // hub rows split into parts of hub_part edges, one block each (gm_agg_schedule): part table + arrival counters, and the partial
     // rows.  One aggregate launch per orientation at a time (a batch's launches are stream-ordered: they share the layer buffers too).
     int32_t* d_hub[2] = {nullptr, nullptr}; float* d_hub_scratch[2] = {nullptr, nullptr}; int32_t hub_part[2] = {0, 0};
+    int32_t hub_words[2] = {0, 0}, hub_parts[2] = {0, 0};      // size of d_hub[o] (int32 words) and its part count (d_hub_scratch[o]: parts x GM_AGG_HUB_LD floats)
+    // a SECOND set of arrival counters / partial rows (gm_batch_hub_alt): lets two streams run aggregate launches over the batch at the same
+    // time (gm_meta_step's two query streams); the part tables are copies, only the counters and the partial rows are private
+    mutable int32_t* d_hub2[2] = {nullptr, nullptr}; mutable float* d_hub_scratch2[2] = {nullptr, nullptr};
     // The arrival counters / partial rows belong to ONE launch at a time.  Launches of a batch are stream-ordered in gm_meta_step; a caller
     // that moves an orientation's launches to another stream (public gm_aggregate / gm_gcn_* API) is ordered behind the previous stream's
     // launch by gm_batch_hub_order (an event wait, only when the stream changes).  Host-side bookkeeping, guarded by hub_mu.
-    mutable hipStream_t hub_stream[2] = {nullptr, nullptr}; mutable bool hub_used[2] = {false, false}; mutable hipEvent_t hub_ev[2] = {nullptr, nullptr};
+    mutable hipStream_t hub_stream[4] = {nullptr, nullptr, nullptr, nullptr}; mutable bool hub_used[4] = {false, false, false, false}; mutable hipEvent_t hub_ev[4] = {nullptr, nullptr, nullptr, nullptr};      // [set * 2 + orientation]
     // per-edge tables (gm_batch_finalize): the source's norm for both CSR orientations (enorm[o][e] = norm[indices_o[e]]) and the source's
     // feature row (efeat[e] = feat_row[indices[e]]): what the aggregate would otherwise fetch with a dependent 4-byte gather per edge
     float* d_enorm[2] = {nullptr, nullptr}; int32_t* d_efeat = nullptr;
@@ -172,6 +176,7 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int query_streams;             // GM_QUERY_STREAMS: 1 / 2 streams for the query evaluations of gm_meta_step (0 = by the query batch's size)
     int head_threads;              // GM_HEAD_THREADS: workgroup size of k_head_loss (256 / 512 / 1024; 0 = by the task's row count)
     int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
     int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
@@ -274,11 +279,13 @@ struct gm_agg_args {
 const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)
 #define GM_FUSE_MAXDEG 2
 #define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
-struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; };
-int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s);
-template <class A> inline int gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s) {
-    a.hub = b->d_hub[o]; a.hub_scratch = b->d_hub_scratch[o]; a.hub_part = b->hub_part[o];
-    return a.hub ? gm_batch_hub_order(b, o, s) : GM_OK;
+struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; int32_t hub_words = 0, parts = 0; };
+int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s, int set = 0);
+int gm_batch_hub_alt(const gm_batch* b, hipStream_t s);      // allocates the second counter / partial-row set (once)
+template <class A> inline int gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s, int set = 0) {
+    const bool alt = set == 1 && b->d_hub2[o];
+    a.hub = alt ? b->d_hub2[o] : b->d_hub[o]; a.hub_scratch = alt ? b->d_hub_scratch2[o] : b->d_hub_scratch[o]; a.hub_part = b->hub_part[o];
+    return a.hub ? gm_batch_hub_order(b, o, s, alt ? 1 : 0) : GM_OK;
 }
 // Rows per wave window for a launch over `rows` rows (64 at most, halved until the launch has enough waves).
 int gm_agg_window(int64_t rows, int64_t edges);

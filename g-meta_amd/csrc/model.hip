@@ -445,6 +445,7 @@ struct GcnCtx {
     // Two-piece fp16 split kernels (np == 2, gm_meta_step's dense schedule; gm_bound.h): per-pass slots am[pass][2 Lg + 1][sets] (zeroed once per
     // meta-step) receive the per-set maxima of H_l (forward GEMM epilogues), T_l (dZ GEMM epilogues) and dQ_L (head backward); hv / tv / dqv:
     // recorded in the current pass.  A launch whose bounds are not all there runs the three-piece bf16 kernels.
+    int hub_set = 0;           // which of the batch's two hub counter / partial-row sets this context's aggregate launches use (gm_batch_hub_alt)
     int np = 3; unsigned* am = nullptr; int am_passes = 0, am_pass = -1;
     const unsigned* feat_bound = nullptr;      // [sets] per-task bound of the layer-1 operand: the largest |feature| of the graphs the task draws from (NULL: loose table, three-piece)
     bool hv[GM_MAX_GCN] = {}, tv[GM_MAX_GCN] = {}; bool dqv = false;
@@ -595,7 +596,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = A; g.lda = lda; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.Z[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             GM_TRY(gm_launch_gemm_nn(g, st));
-            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st)); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
+            gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st, c.hub_set)); a.x = c.Z[l]; a.ldx = fo; a.s_out = b->d_norm;
             a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = b->d_set_row_off; a.n_sets = b->sets; a.relu = 1;
             a.out = c.H[l]; a.rows = b->rows; a.width = fo; a.relu_bits = c.M[l];
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
@@ -609,7 +610,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                               // row) nearly every row still goes through the ordinary aggregate and the gather feeders only cost (3.30 -> 3.21 ms)
                               2 * b->unfused_rows <= b->rows;
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
-                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
+                gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st, c.hub_set)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
                 if (fuse) {
@@ -704,7 +705,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
         if (l > 0) w.partial = c.partial_l[l];
         if (fi > fo) {
             // dY = A^T (norm * dQ) ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
-            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st)); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
+            gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st, c.hub_set)); a.x = dQ; a.ldx = fo; a.s_in = b->d_norm; a.e_w = b->d_enorm[1]; a.out = T; a.rows = b->rows; a.width = fo;
             gm_prof_agg_begin(st, gm_aggregate_bytes(b, fo)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fo));
             GM_TRY(gm_launch_aggregate(a, st));
             gm_prof_agg_end(st);
@@ -763,7 +764,7 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             if (kn) { c.pd->valid[kn][l][0] = w.pl_fwd != nullptr; c.pd->valid[kn][l][1] = w.pl_dz != nullptr; }
             if (w.wt_next) { c.wt_of[l] = c.sgd.next; c.wt_stride[l] = c.sgd.next_stride; }
             if (l > 0) {
-                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st)); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
+                gm_agg_args a{}; a.indptr = b->d_indptr_t; a.indices = b->d_indices_t; a.heavy = b->d_heavy[1]; a.n_heavy = b->n_heavy[1]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[1]; a.sched_len = b->sched_len[1]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 1, st, c.hub_set)); a.x = T; a.ldx = fi; a.s_out = b->d_norm; a.mask_h = maskprev; a.mask_b = maskbits;
                 a.out = dQ; a.rows = b->rows; a.width = fi;
                 gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi)); gm_prof_note(GM_PROF_AGG_STRICT, gm_aggregate_bytes(b, fi));
                 GM_TRY(gm_launch_aggregate(a, st));
@@ -1106,7 +1107,7 @@ static gm_model_t internal_model(const gm_model_t* m, const gm_store* store, int
 }
 
 struct MetaStreams {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side2 = nullptr;      // query streams (side2: GM_QUERY_STREAMS = 2)
     hipStream_t main = nullptr;      // CU-partitioned mode only (GM_CU_MASK_SUPPORT): the support chain's own stream, masked to its CUs
     std::vector<hipEvent_t> ev;
     int ensure(int n) {
@@ -1137,6 +1138,11 @@ struct MetaStreams {
                 (void)hipGetLastError();
                 GM_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
             }
+        }
+        if (!side2 && !main) {
+            int lo = 0, hi = 0;
+            if (gm_knob().side_stream_priority && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) GM_HIP(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, lo));
+            else { (void)hipGetLastError(); GM_HIP(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking)); }
         }
         while ((int)ev.size() < n) { hipEvent_t e; GM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev.push_back(e); }
         return GM_OK;
@@ -1180,7 +1186,9 @@ static StageRing& stage_ring() {
 
 struct MetaPlan {
     gm_layout L; int T, K; int64_t Pp;       // Pp = P padded to 64 floats: per-task weight vectors stay 16-B aligned
-    GcnCtx S, Q;
+    GcnCtx S, Q, Q2;                         // Q2: second query context (own activations) when two query streams are used
+    int nq_ctx;
+    float *logit_q2;
     float *fw, *g, *gq, *gp, *logit_s, *logit_q, *dlog_s, *dlog_q, *protos, *dprotos, *ls, *as_, *lq, *aq, *theta_p;
     PlaneDir pd;
     int64_t TP, proto_sz;               // fw holds K vectors-of-tasks fw_1..fw_K (distinct buffers: the support chain may run ahead)
@@ -1195,12 +1203,12 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
                      int Ct, int ns, int nq, int64_t* need) {
     GM_TRY(gm_make_layout(m, &p.L));
     p.T = spt->sets; p.K = hp->update_step; p.Pp = (p.L.P + 63) / 64 * 64;
-    p.S = GcnCtx{}; p.Q = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.S.L = p.L; p.Q.L = p.L;
+    p.S = GcnCtx{}; p.Q = GcnCtx{}; p.Q2 = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.Q2.b = qry; p.S.L = p.L; p.Q.L = p.L; p.Q2.L = p.L;
     if (hp->cone) {                      // receptive-field tables: built on first use, cached in the batch
         const gm_cone *cs = nullptr, *cq = nullptr;
         GM_TRY(gm_batch_cone(spt, p.L.n_gcn, spt->stream, &cs));
         GM_TRY(gm_batch_cone(qry, p.L.n_gcn, qry->stream, &cq));
-        if (cs->ok && cq->ok) { p.S.cone = cs; p.Q.cone = cq; }      // else: a self pair among the centres -> dense schedule
+        if (cs->ok && cq->ok) { p.S.cone = cs; p.Q.cone = cq; p.Q2.cone = cq; }      // else: a self pair among the centres -> dense schedule
     }
     Carver cv(ws, ws_bytes);
     const int64_t TP = (int64_t)p.T * p.Pp; const int C = p.L.n_out; const int K1 = p.K + 1;
@@ -1218,7 +1226,17 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
         p.tab_s = blk ? p.rows_q + qry->subs : nullptr; p.tab_q = blk ? p.tab_s + 3 * p.T : nullptr;
         p.featb_s = blk ? reinterpret_cast<unsigned*>(p.tab_q + 3 * p.T) : nullptr; p.featb_q = blk ? p.featb_s + p.T : nullptr;
     }
+    // Two query streams (GM_QUERY_STREAMS=2, off by default): evaluations k and k + 1 are independent of each other (each needs only fw_k and the
+    // prototypes of step k - 1), so they can run in two contexts on two streams.  Measured: no gain anywhere -- 4-task arxiv shard 4.68 vs 4.67 ms,
+    // 8 tasks 8.22 vs 8.07, Tissue shape 3.46 vs 3.55, FirstMM shape 1.61 vs 1.66, task_num 32 28.09 vs 28.17 (same box): kernels of
+    // different queues time-slice the chip, they do not fill each other's stalls.  Kept as a knob (bitwise the one-stream result; tested).
+    {
+        const int qs = gm_knob().query_streams;
+        p.nq_ctx = (hp->serialize || hp->cone || hp->sparse_bwd) ? 1 : (qs == 2 ? 2 : 1);
+    }
+    p.logit_q2 = p.nq_ctx == 2 ? cv.take<float>((int64_t)qry->subs * C) : nullptr;
     gcn_carve(p.S, cv); gcn_carve(p.Q, cv);
+    if (p.nq_ctx == 2) { gcn_carve(p.Q2, cv); p.Q2.hub_set = 1; }
     // split-bf16 planes of every fast-weight vector (dense schedule, layers the split GEMM can take): forward planes for every such
     // layer, dZ planes for layers >= 1; ~1 MB per task and inner step at 128/256/256
     p.pd = PlaneDir{};
@@ -1248,8 +1266,9 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
         p.bound_words = ws_s + ws_q + ws_w + GM_BOUND_PAD;                   // (+ the violation word, on a line of its own)
         p.bound_ws = cv.take<unsigned>(p.bound_words);
         if (!p.bound_ws) p.bound_ws = reinterpret_cast<unsigned*>(16);       // sizing pass
-        p.S.np = p.Q.np = 2;
+        p.S.np = p.Q.np = p.Q2.np = 2;
         p.S.am = p.bound_ws; p.S.am_passes = p.K; p.Q.am = p.bound_ws + ws_s; p.Q.am_passes = K1;
+        p.Q2.am = p.Q.am; p.Q2.am_passes = K1;       // (the two query contexts share the slot array: evaluation j uses pass j, set by the step)
         p.pd.wam = p.bound_ws + ws_s + ws_q;
         p.viol = p.pd.wam + ws_w; p.pd.viol = p.viol;
     }
@@ -1300,7 +1319,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_TRY(gm_make_layout(m, &Lu));
     GM_TRY(meta_plan(p, spt, qry, &mp, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
     const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
-    p.S.pd = p.Q.pd = p.pd.base ? &p.pd : nullptr;
+    p.S.pd = p.Q.pd = p.Q2.pd = p.pd.base ? &p.pd : nullptr;
     if (shift) {
         hipLaunchKernelGGL(k_pad_params, dim3((int)std::min<int64_t>(512, (L.P + 255) / 256)), dim3(256), 0, st, theta, Lu.P, cut, shift, p.theta_p);
         GM_HIP(hipGetLastError());
@@ -1338,9 +1357,9 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
                 }
             }
             if (loose) {
-                p.S.np = p.Q.np = 3; p.S.am = p.Q.am = nullptr; p.S.am_passes = p.Q.am_passes = 0;
+                p.S.np = p.Q.np = p.Q2.np = 3; p.S.am = p.Q.am = p.Q2.am = nullptr; p.S.am_passes = p.Q.am_passes = p.Q2.am_passes = 0;
                 p.pd.wam = nullptr; p.pd.viol = nullptr; p.viol = nullptr; p.bound_ws = nullptr;
-            } else { p.S.feat_bound = p.featb_s; p.Q.feat_bound = p.featb_q; }
+            } else { p.S.feat_bound = p.featb_s; p.Q.feat_bound = p.Q2.feat_bound = p.featb_q; }
         }
         GM_HIP(hipMemcpyAsync(p.rows_s, h, 4 * n_tab, hipMemcpyHostToDevice, st));
         GM_TRY(ring.release_after(slot, st));
@@ -1363,6 +1382,9 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     MetaStreams& ms = meta_streams();
     GM_TRY(ms.ensure(2 * K + 10));
     hipStream_t sq = hp->serialize ? st : ms.side;
+    const bool two_q = p.nq_ctx == 2 && !hp->serialize && ms.side2;
+    hipStream_t sq2 = two_q ? ms.side2 : sq;
+    if (two_q) GM_TRY(gm_batch_hub_alt(qry, st));          // private hub counters / partial rows for the second query stream
     hipStream_t const st0 = st;                            // the caller's stream: inputs arrive on it, the output leaves on it
     if (!hp->serialize && ms.main) st = ms.main;           // CU-partitioned mode: the support chain runs on its own masked stream
     int ev = 0;
@@ -1371,6 +1393,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     {
         hipEvent_t e_in = signal(st0);                     // inputs (theta, class tables, batches) are ready
         wait(sq, e_in);
+        if (two_q) wait(sq2, e_in);
         if (st != st0) wait(st, e_in);
     }
 
@@ -1394,41 +1417,50 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     };
     // One query evaluation (meta.py:129-141,152-154): forward on sq, then head + proto_loss_qry (+ head backward when the
     // meta-gradient is wanted) once the prototypes / weights it needs are ready.
-    auto qry_fwd = [&](const float* w, int64_t wstride, int fwd_only) -> int { return gcn_forward(p.Q, w, wstride, p.logit_q, sq, hoist, 1, fwd_only); };
-    auto qry_loss = [&](const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
-        ProtoK pk{p.logit_q, C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
-        return head_loss(p.Q, w, wstride, p.logit_q, pk, grad ? 1 : 0, p.gq, Pp, sparse, sq);
+    // Evaluation j (j = 0: theta, j >= 1: fw_j) runs in query context j % 2 on that context's stream when two query streams are used.
+    auto q_ctx = [&](int j) -> GcnCtx& { return (two_q && (j & 1)) ? p.Q2 : p.Q; };
+    auto q_str = [&](int j) -> hipStream_t { return (two_q && (j & 1)) ? sq2 : sq; };
+    auto q_log = [&](int j) -> float* { return (two_q && (j & 1)) ? p.logit_q2 : p.logit_q; };
+    auto qry_fwd = [&](int j, const float* w, int64_t wstride, int fwd_only) -> int {
+        GcnCtx& c = q_ctx(j);
+        if (c.np == 2) c.am_pass = j - 1;                  // (gcn_forward advances it: evaluation j records its bounds in pass j, whichever context runs it)
+        return gcn_forward(c, w, wstride, q_log(j), q_str(j), hoist, 1, fwd_only);
+    };
+    auto qry_loss = [&](int j, const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
+        ProtoK pk{q_log(j), C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
+        return head_loss(q_ctx(j), w, wstride, q_log(j), pk, grad ? 1 : 0, p.gq, Pp, sparse, q_str(j));
     };
     // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq.  Host enqueue order matters at the
     // start of a step (the GPU is idle and a launch costs the host ~5 us): the first query forward needs nothing but theta and is the head
     // of the longer chain on small shards, so it goes out first -- behind the support step's ~17 launches it started ~110 us late.
     // (Where the support chain is the longer one -- small query batches: the FirstMM shape lost 2.5 % -- its launches keep the lead.)
     const bool query_first = qry->rows >= 100000;
-    if (query_first) GM_TRY(qry_fwd(theta, 0, 1));
+    if (query_first) GM_TRY(qry_fwd(0, theta, 0, 1));
     GM_TRY(spt_step(0, theta, 0, fw(1)));
     hipEvent_t e_proto0 = signal(st);
-    if (!query_first) GM_TRY(qry_fwd(theta, 0, 1));
-    wait(sq, e_proto0);
-    GM_TRY(qry_loss(theta, 0, 0, 0, false));
+    if (!query_first) GM_TRY(qry_fwd(0, theta, 0, 1));
+    wait(q_str(0), e_proto0);
+    GM_TRY(qry_loss(0, theta, 0, 0, 0, false));
     GM_TRY(spt_step_bwd(theta, 0));
-    hipEvent_t e_fw = signal(st);                          // fw_1 ready
-    wait(sq, e_fw);
-    GM_TRY(qry_fwd(fw(1), Pp, 1));
-    GM_TRY(qry_loss(fw(1), Pp, 1, 0, false));
+    hipEvent_t e_fw = signal(st);                          // fw_1 ready (and, being later on st, the prototypes of step 0)
+    wait(q_str(1), e_fw);
+    GM_TRY(qry_fwd(1, fw(1), Pp, 1));
+    GM_TRY(qry_loss(1, fw(1), Pp, 1, 0, false));
     bool have_grad = false;
     for (int k = 1; k < K; ++k) {            // meta.py:143-157
         GM_TRY(spt_step(k, fw(k), Pp, fw(k + 1)));
         GM_TRY(spt_step_bwd(fw(k), Pp));
         e_fw = signal(st);                                 // fw_{k+1} and the prototypes of step k are ready
-        wait(sq, e_fw);
+        const int j = k + 1;
+        wait(q_str(j), e_fw);
         const bool last = hp->need_meta_grad && k == K - 1;
-        GM_TRY(qry_fwd(fw(k + 1), Pp, last ? ((sparse && sparse_bwd_ok(p.L)) ? 0 : 2) : 1));       // only the last evaluation is differentiated
-        GM_TRY(qry_loss(fw(k + 1), Pp, k + 1, k, last));
+        GM_TRY(qry_fwd(j, fw(k + 1), Pp, last ? ((sparse && sparse_bwd_ok(p.L)) ? 0 : 2) : 1));       // only the last evaluation is differentiated
+        GM_TRY(qry_loss(j, fw(k + 1), Pp, k + 1, k, last));
         if (last) {
             // first-order meta-gradient (no create_graph anywhere, meta.py:125,149): d L_q / d fw_K through the
-            // query forward (on sq) plus d L_q / d fw_{K-1} through the prototypes of the last support forward (on st).
-            hipEvent_t e_dp = signal(sq);                  // dprotos ready
-            GM_TRY(gcn_backward(p.Q, fw(k + 1), Pp, p.dlog_q, p.gq, Pp, sq, sparse, 1));
+            // query forward (on its query stream) plus d L_q / d fw_{K-1} through the prototypes of the last support forward (on st).
+            hipEvent_t e_dp = signal(q_str(j));            // dprotos ready
+            GM_TRY(gcn_backward(q_ctx(j), fw(k + 1), Pp, p.dlog_q, p.gq, Pp, q_str(j), sparse, 1));
             wait(st, e_dp);
             GM_HIP(hipMemsetAsync(p.dlog_s, 0, sizeof(float) * spt->subs * C, st));
             hipLaunchKernelGGL(k_protos_to_dlogits, dim3(T), dim3(256), 0, st, p.dprotos, p.rows_s, p.tab_s, Ct, C, p.dlog_s);
@@ -1437,6 +1469,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         }
     }
     wait(st0, signal(sq));                                 // join
+    if (two_q) wait(st0, signal(sq2));
     if (st != st0) wait(st0, signal(st));
     st = st0;
     const int64_t tot = Lu.P + 2 * K1 + 1 + (int64_t)T * K1;

@@ -238,3 +238,24 @@ def test_symmetric_parent_walks_adjacency_once_and_matches_the_two_walk_path(mon
         assert np.array_equal(x, y)
     ob = orc.extract_batch([orc.Graph(n, src, dst)], seeds, 2, 1000, 222, False)
     assert np.array_equal(a_sym[0], ob.parent) and np.array_equal(a_sym[1], ob.indptr) and np.array_equal(a_sym[2], ob.indices)
+
+
+def test_two_query_streams_are_bitwise_the_one_stream_step():
+    """GM_QUERY_STREAMS=2: the K + 1 query evaluations alternate between two contexts / streams (own activations, own hub counters and
+    partial rows).  Same arithmetic per evaluation -> accuracies, losses, meta-gradient and post-Adam weights bitwise those of the default."""
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    args, data, batch, config, store = _arxiv4()
+
+    def run(streams):
+        _lib.check(lib.gm_set_tuning(b'GM_QUERY_STREAMS', streams), 'set_tuning')
+        try:
+            return _run(args, data, batch, config, 3)
+        finally:
+            lib.gm_set_tuning(b'GM_QUERY_STREAMS', 0)
+    acc1, g1, moved1, m1, _ = run(1)
+    acc2, g2, moved2, m2, _ = run(2)
+    assert np.array_equal(acc1, acc2) and moved1 == moved2 and moved1 > 0
+    assert np.array_equal(m1.last_stats['losses_q'], m2.last_stats['losses_q'])
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)
