@@ -342,7 +342,7 @@ class _Deferred:
         m, K1 = self._meta, self._K1
         if self._applied:                                     # device path: Adam already queued, buf = (pinned [losses_q | corrects | count | per-task | violation], event)
             slot, n = self._buf
-            slot[1].synchronize()
+            slot[1].synchronize()           # (polling the event instead measured no different: the wait's wake-up is not what the step start waits for)
             tail = slot[0][:n].numpy().astype(np.float64)
             slot[2] = False                                   # (astype copied: the pinned slot may be reused)
         else:                                                 # host path (non-fused Adam / CPU tensors): guard + step here
