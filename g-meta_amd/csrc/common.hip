@@ -1,6 +1,7 @@
 // Error handling, allocation helpers, model layout, aggregate-launch profiling.
 #include <stdarg.h>
 #include <stdlib.h>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <set>
@@ -264,6 +265,9 @@ const gm_knobs& gm_knob() {
 
 // Tuning knobs by the name of their environment variable, after start-up (tests force the large-launch kernels onto small fixtures with this;
 // bench.py times variants in one process).  Not synchronised with concurrent library calls: set knobs while no other thread is inside the library.
+static std::atomic<int> g_tuning_epoch{0};
+// counts the changes made through gm_set_tuning: callers that cache sizes derived from the knobs (the host mirror's workspace sizes) key on it
+extern "C" int32_t gm_tuning_epoch(void) { return g_tuning_epoch.load(std::memory_order_relaxed); }
 extern "C" int gm_set_tuning(const char* name, int32_t value) {
     GM_REQUIRE(name, GM_EINVAL, "set_tuning: NULL name");
     (void)gm_knob();
@@ -276,7 +280,7 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)
-        if (!strcmp(name, e.name)) { g_knobs.*(e.field) = value; return GM_OK; }
+        if (!strcmp(name, e.name)) { g_knobs.*(e.field) = value; g_tuning_epoch.fetch_add(1, std::memory_order_relaxed); return GM_OK; }
     gm_set_error("set_tuning: unknown or start-up-only knob %s", name);
     return GM_EINVAL;
 }

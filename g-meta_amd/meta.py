@@ -179,7 +179,7 @@ class Meta(nn.Module):
         # objects are recycled; a dead or different partner recomputes) -- two FFI calls (one of them a full planning pass) less on the host
         # path between the read-back of one step and the first launch of the next
         key = (S.rows, Q.rows, S.subs, Q.subs, S.sets, Q.sets, P, int(K), int(need_grad), int(self.hoist_z1), int(self.serialize), int(self.sparse_bwd),
-               int(self.cone), int(lib.gm_get_gemm_mode()), int(lib.gm_get_split_pieces()))
+               int(self.cone), int(lib.gm_get_gemm_mode()), int(lib.gm_get_split_pieces()), int(lib.gm_tuning_epoch()))
         sizes = getattr(S, '_meta_sizes', None)
         if sizes is None or sizes[0] != key or sizes[1]() is not Q:
             n_out = int(lib.gm_meta_out_floats(S.handle, C.byref(model), C.byref(hp)))

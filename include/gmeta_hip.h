@@ -222,6 +222,7 @@ int32_t gm_get_split_pieces(void);
 /* Tuning knob by the name of its environment variable, after start-up; GM_EINVAL for unknown names.  Tests use it to
  * force the large-launch kernels onto small fixtures (GM_GEMM_SPLIT_MIN_TILES, GM_SPLIT16_MIN_ROWS); not synchronised with concurrent calls. */
 int gm_set_tuning(const char* name, int32_t value);
+int32_t gm_tuning_epoch(void);   /* number of gm_set_tuning changes so far (cache key for sizes that depend on the knobs) */
 
 /* Fused aggregate + update for forward passes nobody differentiates (the query evaluations of the inner steps in gm_meta_step,
  * i.e. meta.py:129-141,152-154 before the last step, and every query pass of finetunning): rows with one or two sources are
