@@ -60,7 +60,8 @@ void gm_dev_free(void* p, hipStream_t s) {
 struct StageChunk { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, held = false; };
 struct StagePool {
     std::vector<StageChunk> chunks;
-    ~StagePool() { for (auto& c : chunks) { if (c.ev) (void)hipEventDestroy(c.ev); if (c.p) (void)hipHostFree(c.p); } }
+    // (no destructor: thread-local pools of the main thread would be torn down after the HIP runtime at process exit; a few MiB of pinned memory
+    // per thread that ever built a batch are left to the process)
     int acquire(size_t bytes) {
         int best = -1;
         for (size_t k = 0; k < chunks.size(); ++k) {
