@@ -259,3 +259,23 @@ def test_two_query_streams_are_bitwise_the_one_stream_step():
     assert np.array_equal(m1.last_stats['losses_q'], m2.last_stats['losses_q'])
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('case', [c for c in WIDE_CASES if c not in NAN_CASES])
+@pytest.mark.parametrize('pieces', [3, 2])
+def test_finetunning_through_forced_split_kernels_matches_reference(case, pieces):
+    """Meta.finetunning (meta.py:175-234) on task 0 of the hidden-128 fixtures with the split kernels forced on: the reference's accuracies."""
+    import gmeta_amd
+    from hip_util import fixture_meta, make_store
+    fx = Fixture(case)
+    store = make_store(fx)
+    m = fixture_meta(fx)
+
+    def one(tag):
+        return gmeta_amd.SubgraphBatch.from_nodes(store, fx.z[tag + '_seeds'][0], [0, fx.z[tag + '_seeds'].shape[1]], fx.replay_lists(tag, 0), fx.link)
+    ys = [torch.from_numpy(fx.z['y_spt'][0].astype(np.int64))]; yq = [torch.from_numpy(fx.z['y_qry'][0].astype(np.int64))]
+    with forced_split(pieces) as fs:
+        accs = m.finetunning([one('spt')], ys, [one('qry')], yq, None, None, None, None, None, None, fx.feats)
+        g3, w3, g2, w2, g1 = fs.launches()
+    assert (g2 if pieces == 2 else g3) > 0
+    np.testing.assert_allclose(accs, fx.z['ft_accs'], atol=1e-6)
