@@ -413,6 +413,7 @@ def main():
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
     gemm_bytes = ov_gemm_bytes
     agg_launches = []
+    bound_extra = 0
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
@@ -421,7 +422,7 @@ def main():
         ov_ms, ov_n, ov_bytes = prof_read()
         maml.serialize = 1
         step(0); drain()
-        agg_ms, agg_n, agg_bytes, strict_bytes, gemm_bytes = 0.0, 0, 0, 0, 0
+        agg_ms, agg_n, agg_bytes, strict_bytes, gemm_bytes, bound_extra = 0.0, 0, 0, 0, 0, 0
         for k in range(a.roofline_steps):
             step(k); drain()
             ms, n, by = prof_read()
@@ -431,6 +432,7 @@ def main():
                 ms, n, fl = prof_read(cat)
                 mm[cat][0] += ms; mm[cat][1] += n; mm[cat][2] += fl
             gemm_bytes += prof_read(11)[2]
+            bound_extra += prof_read(12)[2]
             if k == a.roofline_steps - 1:           # per-launch view of the last serialised step: which launches carry the mix
                 cap = 512
                 ms_a, wk_a = (C.c_double * cap)(), (C.c_int64 * cap)()
@@ -661,6 +663,8 @@ def main():
                                      '%d serialised steps run right after the timed region' % a.roofline_steps),
                          'achieved_while_overlapped': round(ov_bytes / (ov_ms * 1e-3) / 1e9, 1) if ov_ms > 0 else None,
                          'by_launch_size': launch_classes(agg_launches),
+                         'frac_with_round3_pricing': round((agg_bytes + bound_extra) / (agg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if agg_ms > 0 else None,
+                         'round3_pricing_note': 'rounds 2-3 priced the sources of a partial launch as min(edges, rows) rows (an upper bound); `frac` counts the DISTINCT source rows',
                          'launch_mix': ('full launches (support chain, the differentiated query pass) AND the partial launches of the forward-only query passes, '
                                         'whose 0..2-source rows are aggregated inside the fused aggregate+GEMM kernel: those launches are priced with B_agg '
                                         'restricted to what they touch (every indptr entry; indices, norms and output rows of the >=3-source rows; their '

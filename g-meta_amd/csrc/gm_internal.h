@@ -419,7 +419,8 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_EX_FILL 9       // extraction, phase B: k_fill (batched CSR in both orientations, parents, norms, centres); work = subgraphs
 #define GM_PROF_EX_FINAL 10     // batch finalisation (launch tables, hub schedule, gains, per-edge / per-row tables): GPU span incl. the host round trips inside it
 #define GM_PROF_GEMM_SPLIT_BYTES 11   // work-only shadow of the split GEMM launches (categories 4 and 6): compulsory HBM bytes 4 rows (K + N) -- the A operand read once, C written once
-#define GM_PROF_CATS 12
+#define GM_PROF_AGG_BOUND 12          // work-only shadow of category 0 with the partial launches priced as in rounds 2-3 (sources = min(edges, rows), an upper bound)
+#define GM_PROF_CATS 13
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
 void gm_prof_reset(int n_cats = GM_PROF_CATS);

@@ -625,6 +625,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                     // strict HBM pricing as for the full launches: a gather launch reads at most the whole (cache-resident) feature table
                     const int64_t pbs = pb0 + 4 * (gather ? std::min<int64_t>(src, b->store->total_nodes) : src) * (int64_t)fi;
                     gm_prof_agg_begin(st, pb); gm_prof_note(GM_PROF_AGG_STRICT, pbs);
+                    gm_prof_note(GM_PROF_AGG_BOUND, pb0 + 4 * std::min<int64_t>(b->unfused_edges, b->rows) * (int64_t)fi - pb);      // (difference to the exact count)
                     GM_TRY(gm_launch_aggregate(a, st));
                     gm_prof_agg_end(st);
                 } else {
@@ -1374,7 +1375,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         GM_TRY(gm_amax_segs(theta, off, n, L.n_gcn, p.pd.wam, GM_BOUND_PAD, st));
     }
     gm_prof_reset(GM_PROF_STEP_CATS);
-    gm_prof_reset_cat(GM_PROF_GEMM_SPLIT_BYTES);
+    gm_prof_reset_cat(GM_PROF_GEMM_SPLIT_BYTES); gm_prof_reset_cat(GM_PROF_AGG_BOUND);
     tm.lap("plan");
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the

@@ -245,6 +245,7 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
  * gradients on the two-piece fp16 split kernels (3 fp16 MFMA flops per fp32 flop).  Categories 8 / 9 / 10 belong to gm_extract on this thread
  * (not reset by gm_meta_step; gm_profile_enable resets them): 8 = k_nodes (h-hop expansion, sampling, node lists, induced degrees),
  * 9 = k_fill (the batched CSR in both orientations), work = subgraphs; 10 = batch finalisation (GPU span including its host round trips).
+ * 12 = work-only: bytes by which the rounds-2/3 pricing of the partial aggregate launches (sources = min(edges, rows)) exceeds the exact count.
  * 11 = work-only shadow of categories 4 + 6: compulsory HBM bytes of the split GEMM launches, 4 rows (K + N) (A read once, C written once). */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 /* The same per launch: ms[k] / work[k] of the k-th timed launch of the category since the last reset (at most cap); returns their number (< 0: error). */
