@@ -385,6 +385,7 @@ def main():
     ov_mm = {c: [0.0, 0, 0] for c in MM_CATS}
     strict_bytes = 0
     ov_gemm_bytes = 0
+    ov_bound = 0
     for k in range(a.steps):
         accs = step(k)                 # returns after the one device->host read of losses/accs
         if a.defer or not a.serialize:
@@ -393,6 +394,7 @@ def main():
         ov_ms += ms; ov_n += n; ov_bytes += by
         strict_bytes += prof_read(3)[2]
         ov_gemm_bytes += prof_read(11)[2]
+        ov_bound += prof_read(12)[2]
         for cat in MM_CATS:
             ms, n, fl = prof_read(cat)
             ov_mm[cat][0] += ms; ov_mm[cat][1] += n; ov_mm[cat][2] += fl
@@ -413,7 +415,7 @@ def main():
     agg_ms, agg_n, agg_bytes = ov_ms, ov_n, ov_bytes
     gemm_bytes = ov_gemm_bytes
     agg_launches = []
-    bound_extra = 0
+    bound_extra = ov_bound
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
