@@ -26,6 +26,7 @@ struct AggK {
     const int32_t* hub; float* hub_scratch; int hub_part, hub_ld;
     const float* e_w; const int32_t* x_idx;     // per-edge source scale / source row of x (see gm_agg_args)
     int skip_lo, skip_hi;                       // rows with skip_lo <= degree <= skip_hi are left to the fused aggregate+GEMM kernel (empty range: none)
+    const int32_t* rowlist; int64_t n_list;     // optional: the windows walk this (ascending) row list instead of rows 0 .. rows
 };
 
 // edge e -> (row of x to read, its scale): from the per-edge tables when the launch has them, else through indices / s_in / x_row
@@ -261,18 +262,21 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane / LPR, l = lane % LPR;
     const int64_t R0 = ((int64_t)lb * (AGG_BLOCK / GM_WAVE) + wave) * a.win;
-    if (R0 >= a.rows) return;
+    const int64_t nrows_w = a.rowlist ? a.n_list : a.rows;          // rows the windows walk: the list's, or all
+    if (R0 >= nrows_w) return;
     // ---- per-lane row descriptor (coalesced)
-    const int64_t myrow = R0 + lane;
+    const bool mine = lane < a.win && R0 + lane < nrows_w;
+    const int64_t myrow = a.rowlist ? (mine ? (int64_t)a.rowlist[R0 + lane] : 0) : R0 + lane;
+    const int myrow32 = (int)myrow;
     int p0 = 0, dg = 0, u0 = 0, u1 = 0; float w0 = 0.f, w1 = 0.f, so = 1.f;
-    if (lane < a.win && myrow < a.rows) {
+    if (mine) {
         p0 = a.indptr[myrow]; dg = a.indptr[myrow + 1] - p0;
         if (a.s_out) so = a.s_out[myrow];
         if (dg >= a.skip_lo && dg <= a.skip_hi) dg = -2;                   // not this launch's row
         if (dg >= 1) agg_edge(a, p0, u0, w0);
         if (dg >= 2) agg_edge(a, p0 + 1, u1, w1);
     }
-    const int nwin = (int)min((int64_t)a.win, a.rows - R0);
+    const int nwin = (int)min((int64_t)a.win, nrows_w - R0);
     const float* xl = a.x + l * 4;
     for (int t0 = 0; t0 < nwin; t0 += G * UNR) {
         float4 acc[UNR][NCH];
@@ -300,7 +304,8 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             if (rdg[k] < 0) continue;
-            const int64_t row = R0 + t0 + k * G + g;
+            const int rr_ = t0 + k * G + g;
+            const int64_t row = a.rowlist ? (int64_t)__shfl(myrow32, rr_ < GM_WAVE ? rr_ : 0, 64) : R0 + rr_;
             // rows with more than two in-edges (p99 ~ 19, hubs up to ~1000): the group's LPR lanes fetch the next LPR
             // sources + scales with one coalesced load each, then 8 row loads at a time are issued from registers.
             const int eend = rp0[k] + rdg[k];
@@ -372,6 +377,37 @@ int gm_agg_window(int64_t rows, int64_t edges) {
     return win;
 }
 
+int gm_agg_schedule_flat(gm_batch* b, int64_t rows, int win, const int32_t* pos, int n_heavy, const std::vector<int32_t>& tab, int32_t** d_sched, int32_t* len_out,
+                         hipStream_t s, gm_stager* sg) {
+    const bool split = !tab.empty();
+    const int RPB = win * (AGG_BLOCK / GM_WAVE);
+    const int nwb = std::max(1, (int)((rows + RPB - 1) / RPB));
+    const int q = nwb / GM_NXCD, r = nwb % GM_NXCD;
+    std::vector<std::vector<int32_t>> lists(GM_NXCD);
+    int hk = 0;
+    for (int x = 0; x < GM_NXCD; ++x) {
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = x < r ? q + 1 : q;
+        lists[x].reserve(cnt + 8);
+        for (int wb = start; wb < start + cnt; ++wb) {
+            lists[x].push_back(wb);
+            while (hk < n_heavy && pos[hk] / RPB == wb) {               // pos is ascending
+                if (split) for (int g = tab[hk]; g < tab[hk + 1]; ++g) lists[x].push_back(-g - 2);
+                else lists[x].push_back(-hk - 2);
+                ++hk;
+            }
+        }
+    }
+    GM_REQUIRE(hk == n_heavy, GM_EINVAL, "aggregate schedule: hub-row list is not ascending / out of range");
+    size_t len = 0;
+    for (auto& l : lists) len = std::max(len, l.size());
+    std::vector<int32_t> flat(GM_NXCD * len, -1);
+    for (int x = 0; x < GM_NXCD; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * len);
+    GM_TRY(gm_balloc(b, d_sched, flat.size(), s));
+    GM_TRY(sg->upload(*d_sched, flat));          // (through pinned staging: no host round trip)
+    *len_out = (int32_t)len;
+    return GM_OK;
+}
+
 int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s, gm_stager* sg) {
     *out = gm_agg_sched{};
     const int on = gm_knob().agg_sched, part_env = gm_knob().agg_hub_part;      // part_env 0: one block per hub row
@@ -392,37 +428,14 @@ int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_hos
             for (int k = 0; k < n_heavy; ++k) for (int g = tab[k]; g < tab[k + 1]; ++g) tab[n_heavy + 1 + g] = k;
         }
     }
-    const int RPB = win * (AGG_BLOCK / GM_WAVE);
-    const int nwb = (int)((rows + RPB - 1) / RPB);
-    const int q = nwb / GM_NXCD, r = nwb % GM_NXCD;
-    std::vector<std::vector<int32_t>> lists(GM_NXCD);
-    int hk = 0;
-    for (int x = 0; x < GM_NXCD; ++x) {
-        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = x < r ? q + 1 : q;
-        lists[x].reserve(cnt + 8);
-        for (int wb = start; wb < start + cnt; ++wb) {
-            lists[x].push_back(wb);
-            while (hk < n_heavy && heavy_host[hk] / RPB == wb) {        // heavy_host is ascending
-                if (hub_part) for (int g = tab[hk]; g < tab[hk + 1]; ++g) lists[x].push_back(-g - 2);
-                else lists[x].push_back(-hk - 2);
-                ++hk;
-            }
-        }
-    }
-    GM_REQUIRE(hk == n_heavy, GM_EINVAL, "aggregate schedule: hub-row list is not ascending / out of range");
-    size_t len = 0;
-    for (auto& l : lists) len = std::max(len, l.size());
-    std::vector<int32_t> flat(GM_NXCD * len, -1);
-    for (int x = 0; x < GM_NXCD; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + x * len);
-    GM_TRY(gm_balloc(b, &out->d_sched, flat.size(), s));
-    GM_TRY(sg->upload(out->d_sched, flat));     // (through pinned staging: no host round trip)
+    GM_TRY(gm_agg_schedule_flat(b, rows, win, heavy_host, n_heavy, tab, &out->d_sched, &out->len, s, sg));
     if (hub_part) {
         GM_TRY(gm_balloc(b, &out->d_hub, tab.size(), s));
         GM_TRY(sg->upload(out->d_hub, tab));
         GM_TRY(gm_balloc(b, &out->d_hub_scratch, (size_t)tab[n_heavy] * GM_AGG_HUB_LD, s));
         out->hub_part = hub_part; out->hub_words = (int32_t)tab.size(); out->parts = tab[n_heavy];
     }
-    out->len = (int32_t)len;
+    out->tab = tab;
     return GM_OK;
 }
 
@@ -433,9 +446,9 @@ static void launch_win(const AggK& a0, hipStream_t s) {
     // keep the rows in flight on an XCD within reach of its 4-MiB L2 -- a source row is gathered by ~2 destination rows
     // of the same subgraph, and the second gather only hits if it follows the first closely (measured on the 1.1 M-row
     // query batch: 4.2 -> 4.6 TB/s) -- and spread small batches (support sets, a 4-task shard) over the whole chip.
-    a.win = a.sched ? a0.win : gm_agg_window(a.rows, 0);
+    a.win = (a.sched || a.rowlist) ? a0.win : gm_agg_window(a.rows, 0);
     const int RPB = a.win * (AGG_BLOCK / GM_WAVE);
-    a.nblocks = (int)((a.rows + RPB - 1) / RPB);
+    a.nblocks = (int)(((a.rowlist ? a.n_list : a.rows) + RPB - 1) / RPB);
     int grid = a.nblocks;
     if (a.sched) grid = GM_NXCD * a.sched_len;
     else if (a.n_heavy > 0) hipLaunchKernelGGL((k_agg_heavy<LPR, NCH>), dim3(a.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, a);
@@ -468,12 +481,15 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     AggK a{g.indptr, g.indices, g.x, g.x_row, g.ldx, g.s_in, g.s_out, g.mask_h, g.bias, g.bias_stride,
            g.set_row_off, g.n_sets, g.relu, g.out, g.rows, g.width, 0, g.mask_b, g.relu_bits, g.heavy, g.n_heavy, g.heavy_deg,
            g.sched, g.sched_len, agg_nt(g.rows, g.width), g.sched ? g.sched_win : 64,
-           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx, g.skip_on ? g.skip_lo : 1, g.skip_on ? g.skip_hi : 0};
+           g.sched ? g.hub : nullptr, g.sched ? g.hub_scratch : nullptr, g.hub_part, GM_AGG_HUB_LD, g.e_w, g.x_idx, g.skip_on ? g.skip_lo : 1, g.skip_on ? g.skip_hi : 0,
+           g.rowlist, g.n_list};
+    if (g.rowlist) a.win = g.list_win;
     const bool vec4 = (g.width % 4 == 0) && (g.ldx % 4 == 0) && (((uintptr_t)g.x & 15) == 0) && (((uintptr_t)g.out & 15) == 0);
     const bool bias_ok = !g.bias || ((((uintptr_t)g.bias & 15) == 0) && (g.bias_stride % 4 == 0));
     const bool mask_ok = !g.mask_h || (((uintptr_t)g.mask_h & 15) == 0);
     GM_REQUIRE(!(g.mask_b || g.relu_bits) || vec4, GM_EINVAL, "aggregate: packed relu masks need width %% 4 == 0 and 16-byte aligned operands");
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
+    GM_REQUIRE(!g.rowlist || win, GM_EINVAL, "aggregate: a row list needs the window kernel");
     if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; a.hub = nullptr; }      // the generic kernel walks every row itself
     if (win) {
         if (g.width == 64) launch_win<16, 1>(a, s);

@@ -254,6 +254,8 @@ const gm_knobs& gm_knob() {
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.head_threads = env("GM_HEAD_THREADS", 0);
         k.query_streams = env("GM_QUERY_STREAMS", 0);
+        k.agg_mid_list = env("GM_AGG_MID_LIST", 1);
+        k.agg_mid_win = env("GM_AGG_MID_WIN", 0);
         k.side_stream_priority = env("GM_SIDE_STREAM_PRIORITY", 1);
         k.wgrad_round_bias = env("GM_WGRAD_ROUND_BIAS", 25);
         k.split_pieces = env("GM_SPLIT_PIECES", 3);                   // 3: every operand carries its full 24 significand bits (the reference multiplies in fp32, learner.py:36,47); 2 = opt-in fast mode
@@ -277,7 +279,7 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
         {"GM_AGG_VARIANT", &gm_knobs::agg_variant}, {"GM_GEMM_SPLIT_MIN_TILES", &gm_knobs::gemm_split_min_tiles}, {"GM_GEMM_SPLIT_GRID", &gm_knobs::gemm_split_grid},
         {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
-        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams},
+        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)

@@ -523,6 +523,47 @@ int64_t gm_batch_unfused_sources(const gm_batch* b, hipStream_t s) {
     gm_dev_free(bits, s); gm_dev_free(cnt, s);
     return ok ? (b->unfused_src = (int64_t)h) : fallback;
 }
+// Ordered compaction of the rows with lo <= in-degree <= hi (the window rows of a partial aggregate launch): per-block counts, a one-block scan
+// of the counts, then every block writes its rows at its offset (ballot ranks: ascending row ids).
+#define MID_BLOCK 1024
+__device__ __forceinline__ bool mid_row(const int32_t* indptr, int64_t r, int64_t rows, int lo, int hi) {
+    if (r >= rows) return false;
+    const int d = indptr[r + 1] - indptr[r];
+    return d >= lo && d <= hi;
+}
+__global__ __launch_bounds__(MID_BLOCK) void k_mid_count(const int32_t* indptr, int64_t rows, int lo, int hi, int32_t* bcnt) {
+    __shared__ int wsum[MID_BLOCK / 64];
+    const int64_t r = (int64_t)blockIdx.x * MID_BLOCK + threadIdx.x;
+    const unsigned long long m = __ballot(mid_row(indptr, r, rows, lo, hi));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < MID_BLOCK / 64; ++k) t += wsum[k]; bcnt[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_mid_scan(int32_t* bcnt, int nb) {      // exclusive scan in place, one block
+    __shared__ int part[1024];
+    const int per = (nb + 1023) / 1024, a = threadIdx.x * per, b = min(nb, a + per);
+    int t = 0;
+    for (int k = a; k < b; ++k) t += bcnt[k];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 1024; ++k) { const int v = part[k]; part[k] = run; run += v; } }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int k = a; k < b; ++k) { const int v = bcnt[k]; bcnt[k] = run; run += v; }
+}
+__global__ __launch_bounds__(MID_BLOCK) void k_mid_scatter(const int32_t* indptr, int64_t rows, int lo, int hi, const int32_t* boff, int32_t* list, int cap) {
+    __shared__ int wsum[MID_BLOCK / 64];
+    const int64_t r = (int64_t)blockIdx.x * MID_BLOCK + threadIdx.x;
+    const bool f = mid_row(indptr, r, rows, lo, hi);
+    const unsigned long long m = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    int base = boff[blockIdx.x];
+    for (int k = 0; k < wv; ++k) base += wsum[k];
+    const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+    if (f && at < cap) list[at] = (int32_t)r;
+}
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
                               int32_t* crow, float* cnorm, int32_t* cdeg) {
@@ -719,6 +760,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
     if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
     b->sched_win = gm_agg_window(b->rows, b->edges);
+    std::vector<int32_t> heavy0, tab0;                       // forward orientation: sorted hub rows and their part table (for the list schedule below)
     for (int o = 0; o < 2; ++o) {
         b->n_heavy[o] = std::min(h_cnt[o], cap);
         if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
@@ -738,7 +780,36 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
             if (nh > 1) GM_TRY(sg.upload(b->d_heavy[o], h));
             gm_agg_sched sc;
             GM_TRY(gm_agg_schedule(b, b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s, &sg));
+            if (o == 0) { heavy0 = h; tab0 = sc.tab; }
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part; b->hub_words[o] = sc.hub_words; b->hub_parts[o] = sc.parts;
+        }
+    }
+    // ---- the window rows of the fused passes' partial aggregate launch as a compact ascending list + its block schedule (no host wait: the
+    // list's length follows from counts the round trip above already brought: rows with more than GM_FUSE_MAXDEG in-edges minus the hub rows)
+    if (b->d_fuse2 && gm_knob().agg_mid_list) {
+        const int64_t n_mid = b->unfused_rows - (int64_t)b->n_heavy[0];
+        if (n_mid > 0 && n_mid < b->rows && h_cnt[0] <= cap) {
+            const int nb = (int)((b->rows + MID_BLOCK - 1) / MID_BLOCK);
+            int32_t* d_bcnt = nullptr;
+            GM_TRY(gm_alloc(&d_bcnt, (size_t)nb, s));
+            GM_TRY(gm_balloc(b, &b->d_mid, (size_t)n_mid, s));
+            hipLaunchKernelGGL(k_mid_count, dim3(nb), dim3(MID_BLOCK), 0, s, b->d_indptr, (int64_t)b->rows, GM_FUSE_MAXDEG + 1, b->heavy_deg, d_bcnt);
+            hipLaunchKernelGGL(k_mid_scan, dim3(1), dim3(1024), 0, s, d_bcnt, nb);
+            hipLaunchKernelGGL(k_mid_scatter, dim3(nb), dim3(MID_BLOCK), 0, s, b->d_indptr, (int64_t)b->rows, GM_FUSE_MAXDEG + 1, b->heavy_deg, d_bcnt, b->d_mid, (int)n_mid);
+            GM_HIP(hipGetLastError());
+            gm_dev_free(d_bcnt, s);
+            b->n_mid = (int32_t)n_mid;
+            // window size over the list: enough waves to fill the chip, at least two rows per wave (two rows in flight per lane group)
+            int win = 64;
+            while (win > 2 && n_mid / win < 16384) win >>= 1;
+            if (gm_knob().agg_mid_win > 0) win = gm_knob().agg_mid_win;
+            b->mid_win = win;
+            if (b->n_heavy[0] > 0 && b->d_sched[0]) {
+                // hub parts ride in the same launch: placed after the list block nearest to the hub row's position (row id scaled to the list)
+                std::vector<int32_t> pos(heavy0.size());
+                for (size_t k = 0; k < heavy0.size(); ++k) pos[k] = (int32_t)std::min<int64_t>(n_mid - 1, (int64_t)heavy0[k] * n_mid / b->rows);
+                GM_TRY(gm_agg_schedule_flat(b, n_mid, win, pos.data(), (int)heavy0.size(), tab0, &b->d_sched_mid, &b->sched_len_mid, s, &sg));
+            }
         }
     }
     tm.lap("heavy");

@@ -136,6 +136,11 @@ struct gm_batch {
     // their aggregate is written by the ordinary kernel (gm_agg_args::skip_lo/hi) and picked up as is
     void* d_fuse2 = nullptr; void* d_fuse2_feat = nullptr;
     int64_t unfused_rows = 0, unfused_edges = 0;     // rows (and their in-edges) the ordinary aggregate still writes in a fused pass
+    // The partial aggregate launch of a fused pass walks a COMPACT list of its window rows (in-degree GM_FUSE_MAXDEG+1 .. heavy_deg, ascending)
+    // instead of every row of the batch: 8 % of the rows of the arxiv query batch carry work in that launch, and a wave whose 16-row window holds
+    // one of them runs its gathers one dependent batch at a time; with the list every wave window is full of rows that have work.
+    int32_t* d_mid = nullptr; int32_t n_mid = 0, mid_win = 0;
+    int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
     int32_t n_c = 0;                   // centre rows: subs * centres
@@ -176,6 +181,8 @@ struct gm_knobs {
     int gemm_split_grid;           // 0: the current device's CU count
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int agg_mid_win;               // GM_AGG_MID_WIN: rows per wave window over that list (0 = by its length)
+    int agg_mid_list;              // GM_AGG_MID_LIST: the partial aggregate launch of a fused pass walks a compact list of its window rows (1, default) or every row (0)
     int query_streams;             // GM_QUERY_STREAMS: 1 / 2 streams for the query evaluations of gm_meta_step (0 = by the query batch's size)
     int head_threads;              // GM_HEAD_THREADS: workgroup size of k_head_loss (256 / 512 / 1024; 0 = by the task's row count)
     int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
@@ -273,13 +280,15 @@ struct gm_agg_args {
     const int32_t* sched;      // optional block schedule (gm_agg_schedule): hub rows ride in the window launch
     int sched_len, sched_win;
     const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
+    const int32_t* rowlist; int64_t n_list; int list_win;      // window kernel only: the wave windows walk rowlist[0 .. n_list) instead of every row (sched / sched_len then index list blocks)
 };
 #define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
 #define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row
 const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)
 #define GM_FUSE_MAXDEG 2
 #define GM_AGG_HUB_LD 512      // floats per partial hub row (the widest window-kernel width)
-struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; int32_t hub_words = 0, parts = 0; };
+struct gm_agg_sched { int32_t* d_sched = nullptr; int32_t len = 0; int32_t* d_hub = nullptr; float* d_hub_scratch = nullptr; int32_t hub_part = 0; int32_t hub_words = 0, parts = 0;
+                      std::vector<int32_t> tab; };      // tab: the host copy of the part table (gm_agg_schedule_flat builds further schedules over the same parts)
 int gm_batch_hub_order(const gm_batch* b, int o, hipStream_t s, int set = 0);
 int gm_batch_hub_alt(const gm_batch* b, hipStream_t s);      // allocates the second counter / partial-row set (once)
 template <class A> inline int gm_agg_hub(A& a, const gm_batch* b, int o, hipStream_t s, int set = 0) {
@@ -294,6 +303,9 @@ int gm_agg_window(int64_t rows, int64_t edges);
 // split: out->d_hub == NULL), -1: nothing.  A hub row's blocks follow the window block that contains the row, on the XCD whose L2 is
 // streaming that subgraph.  heavy_deg_host: the rows' edge counts (NULL: never split).
 struct gm_stager;
+// Only the flat block schedule, for hub rows at (virtual, ascending) positions pos[] among `rows` window rows, over the part table `tab` of an earlier
+// gm_agg_schedule call (empty: one block per hub row)
+int gm_agg_schedule_flat(gm_batch* b, int64_t rows, int win, const int32_t* pos, int n_heavy, const std::vector<int32_t>& tab, int32_t** d_sched, int32_t* len, hipStream_t s, gm_stager* sg);
 int gm_agg_schedule(gm_batch* b, int64_t rows, int win, const int32_t* heavy_host, const int32_t* heavy_deg_host, int n_heavy, gm_agg_sched* out, hipStream_t s, gm_stager* sg);
 int gm_heavy_deg();   // rows with more edges than this are aggregated by a whole workgroup (env GM_HEAVY_DEG; default by density, see gm_heavy_deg_for)
 int gm_heavy_deg_for(int64_t rows, int64_t edges);

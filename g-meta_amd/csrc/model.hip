@@ -616,6 +616,12 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 if (fuse) {
                     // only the rows the fused kernel does not form itself (more than GM_FUSE_MAXDEG sources): a partial launch
                     a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
+                    if (b->d_mid && c.hub_set == 0 && gm_knob().agg_mid_list && (b->n_heavy[0] == 0 || b->d_sched_mid)) {
+                        // ... walking the compact list of those rows (hub rows keep their blocks; the schedule is the list's)
+                        a.rowlist = b->d_mid; a.n_list = b->n_mid; a.list_win = b->mid_win;
+                        if (b->n_heavy[0] > 0) { a.sched = b->d_sched_mid; a.sched_len = b->sched_len_mid; a.sched_win = b->mid_win; }
+                        else { a.sched = nullptr; a.sched_len = 0; }
+                    }
                     // SURVEY 8(d)'s B_agg restricted to what this launch touches: every indptr entry, the indices / norms of the rows it writes,
                     // those rows (written once) and their sources (read once: the high-degree rows of a subgraph reach ~all of its rows)
                     const int64_t pb0 = 4 * (b->rows + 1) + 4 * b->unfused_edges + 4 * b->unfused_rows + 4 * b->unfused_rows * (int64_t)fi;
