@@ -242,6 +242,7 @@ const gm_knobs& gm_knob() {
         k.gemm_split_grid = env("GM_GEMM_SPLIT_GRID", 0);
         k.gemm_fused_rounds = std::max(0, env("GM_GEMM_FUSED_ROUNDS", 0));          // 0: by launch size (gemm.hip)
         k.gemm_plain_rounds = std::max(1, env("GM_GEMM_PLAIN_ROUNDS", 1));
+        k.centre_store = env("GM_CENTRE_STORE", 1);
         k.gemm_half_tiles = env("GM_GEMM_HALF_TILES", 1);
         k.gemm_bn = env("GM_GEMM_BN", 256);
         k.gemm_mid_tiles = env("GM_GEMM_MID_TILES", 1536);
@@ -277,7 +278,7 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
     static const struct { const char* name; int gm_knobs::*field; } tab[] = {
         {"GM_AGG_MIN_WAVES", &gm_knobs::agg_min_waves}, {"GM_AGG_MIN_WIN", &gm_knobs::agg_min_win}, {"GM_AGG_UNR", &gm_knobs::agg_unr}, {"GM_AGG_NT", &gm_knobs::agg_nt},
         {"GM_AGG_VARIANT", &gm_knobs::agg_variant}, {"GM_GEMM_SPLIT_MIN_TILES", &gm_knobs::gemm_split_min_tiles}, {"GM_GEMM_SPLIT_GRID", &gm_knobs::gemm_split_grid},
-        {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
+        {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_CENTRE_STORE", &gm_knobs::centre_store}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
         {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},

@@ -564,6 +564,15 @@ __global__ __launch_bounds__(MID_BLOCK) void k_mid_scatter(const int32_t* indptr
     const int at = base + __popcll(m & ((1ull << lane) - 1ull));
     if (f && at < cap) list[at] = (int32_t)r;
 }
+// norm with the sign bit set (every row), then cleared again on the centre rows: gm_batch::d_norm_c
+__global__ void k_norm_neg(const float* norm, int64_t n, float* out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __uint_as_float(__float_as_uint(norm[i]) | 0x80000000u);
+}
+__global__ void k_norm_centres(const float* norm, const int32_t* crow, int n_c, float* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_c) { const int r = crow[k]; out[r] = __uint_as_float(__float_as_uint(norm[r]) & 0x7fffffffu); }
+}
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
                               int32_t* crow, float* cnorm, int32_t* cdeg) {
@@ -747,6 +756,10 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
     hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
                        b->d_crow, b->d_cnorm, d_cdeg);
+    GM_HIP(hipGetLastError());
+    GM_TRY(gm_balloc(b, &b->d_norm_c, b->rows, s));
+    hipLaunchKernelGGL(k_norm_neg, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, b->d_norm, (int64_t)b->rows, b->d_norm_c);
+    hipLaunchKernelGGL(k_norm_centres, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_norm, b->d_crow, b->n_c, b->d_norm_c);
     GM_HIP(hipGetLastError());
     // ---- the one round trip
     const int first = std::min(cap, GM_HEAVY_FIRST);

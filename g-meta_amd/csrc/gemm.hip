@@ -532,7 +532,7 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     if (a.n_tiles <= 0) return GM_OK;
     const int cat = a.Bsplit ? (a.np == 2 ? GM_PROF_GEMM_SPLIT16 : GM_PROF_GEMM_SPLIT) : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
-    if (a.Bsplit) gm_prof_note(GM_PROF_GEMM_SPLIT_BYTES, 4 * a.rows * (int64_t)(a.K + a.N));
+    if (a.Bsplit) gm_prof_note(GM_PROF_GEMM_SPLIT_BYTES, 4 * a.rows * (int64_t)a.K + 4 * (a.row_scale_keep ? a.n_keep : a.rows) * (int64_t)a.N);      // compulsory A + C bytes
     const int rc = launch_gemm_nn(a, s);
     gm_prof_end(cat, s);
     return rc;
@@ -545,7 +545,7 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         GM_REQUIRE(ok, GM_EINVAL, "gemm: launch not eligible for the split-bf16 kernel (N=%d K=%d)", a.N, a.K);
         SplitGemmK k{};
         k.A = a.A; k.lda = a.lda; k.Bt = a.Bsplit; k.bt_stride = a.bsplit_stride; k.C = a.C; k.ldc = a.ldc; k.K = a.K; k.N = a.N;
-        k.row_scale = a.row_scale; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
+        k.row_scale = a.row_scale_keep ? a.row_scale_keep : a.row_scale; k.keep_signed = a.row_scale_keep ? 1 : 0; k.bias = a.bias; k.bias_stride = a.bias_stride; k.relu = a.relu; k.relu_bits = a.relu_bits;
         k.tiles = a.tiles; k.n_tiles = a.n_tiles; k.n_col_tiles = 1; k.nt_store = 1; k.zero_out = a.zero_out;      // (ordinary C stores lose at every size: 4-task shard +3 %, task_num 32 +1.3 %)
         const bool f16 = a.np == 2;
         GM_REQUIRE(!f16 || (a.a_bound.amax && a.b_bound.amax), GM_EINVAL, "gemm: the two-piece split kernel needs bounds for both operands");

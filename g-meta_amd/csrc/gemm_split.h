@@ -72,6 +72,7 @@ struct SplitGemmK {
     // derive the same power-of-two scales (gs_scale_of);  amax_out[set * GM_BOUND_PAD] (NP == 2 kernels only): the epilogue records the largest |C| it stores
     // (atomicMax on the bit pattern) -- the bound of whoever consumes C
     gm_bound a_bound, b_bound; unsigned* amax_out;
+    int keep_signed;                           // row_scale carries "nobody reads this row" in its sign bit: such rows are computed and not stored
 };
 #define GM_SPLIT_FUSE_SELF 0x40000000
 #define GM_SPLIT_FUSE_ZERO 0x20000000
@@ -600,12 +601,18 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) b4[j] = *reinterpret_cast<const float4*>(biasl + (ti & 1) * BN + wc * 64 + j * 32 + q4 * 4);
             if constexpr (NP == 2) { if (g.amax_out && tl.set != vmax_set) { if (vmax_set >= 0) vmax_flush(); vmax_set = tl.set; } }
+            // keep_signed: the sign bit of a row's scale says that nobody reads the row (forward-only pass, last layer: the head gathers the
+            // centre rows only).  A wave whose 32 MI rows are all of that kind has no epilogue at all.
+            if (g.keep_signed && __ballot(!(__float_as_uint(sc_t[wr * 32 * MI + (lane & (32 * MI - 1))]) >> 31)) == 0ull) continue;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {                  // registers 4 gq .. 4 gq + 3: rows 8 gq + 4 kh + (0..3) of the wave's 32-row block i
                     const int rl = wr * 32 * MI + i * 32 + gq * 8 + kh * 4 + t4;
-                    const float sc = sc_t[rl];
+                    const float sc_raw = sc_t[rl];
+                    const bool keep = !g.keep_signed || !(__float_as_uint(sc_raw) >> 31);
+                    if (g.keep_signed && __ballot(keep) == 0ull) continue;
+                    const float sc = fabsf(sc_raw);
                     const int64_t row = row0 + rl;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                         float4 v;
                         v.x = a0 * sc + b4[j].x; v.y = a1 * sc + b4[j].y; v.z = a2 * sc + b4[j].z; v.w = a3 * sc + b4[j].w;
                         if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
-                        if (rl >= nrows) continue;
+                        if (rl >= nrows || !keep) continue;
                         const int col = wc * 64 + j * 32 + q4 * 4;
                         if constexpr (NP == 2) { if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
                         if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));

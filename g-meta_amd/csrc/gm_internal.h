@@ -146,6 +146,8 @@ struct gm_batch {
     int32_t n_c = 0;                   // centre rows: subs * centres
     int32_t* d_crow = nullptr;         // [n_c]  batch row of every centre
     float* d_cnorm = nullptr;          // [n_c]  norm[centre row]
+    float* d_norm_c = nullptr;         // [rows] norm with the SIGN BIT SET on every row that is not a centre: row scale + "somebody reads this row" flag of the last layer's
+                                       //        forward-only update (gm_gemm_args::row_scale_keep)
     int32_t n_e1 = 0;                  // in-edges of centres, concatenated in centre order
     int32_t* d_e1_row = nullptr;       // [n_e1] source row of the edge
     int32_t* d_e1_par = nullptr;       // [n_e1] compact index of the centre it enters
@@ -179,6 +181,7 @@ struct gm_knobs {
     int gemm_mode;                 // 0 exact fp32, 1 split-bf16, -1 not set (library default)
     int gemm_split_min_tiles;      // -1: a quarter of the current device's CUs
     int gemm_split_grid;           // 0: the current device's CU count
+    int centre_store;              // GM_CENTRE_STORE: forward-only passes store only the centre rows of the last layer's activation (1, default) or every row (0)
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
     int agg_mid_win;               // GM_AGG_MID_WIN: rows per wave window over that list (0 = by its length)
@@ -319,6 +322,9 @@ struct gm_gemm_args {
     float* C; int64_t ldc;
     int K, N;
     const float* row_scale;             // optional: C *= row_scale[row] (before bias)
+    const float* row_scale_keep;        // optional, split kernels only (others ignore it): |value| = row_scale, sign bit set = nobody reads this row of C: it is computed and
+                                        //   not stored (the h[to_fetch] select of Classifier.forward, learner.py, fused into the last layer's epilogue); n_keep = rows stored (accounting)
+    int64_t n_keep;
     const float* bias; int64_t bias_stride;   // optional per-set bias [N]
     int relu;
     const float* mask_h;                // optional [rows, ldc]: zero C where mask_h <= 0 (relu')
