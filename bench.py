@@ -486,6 +486,20 @@ def main():
                                                   'what': 'default schedule with GM_SPLIT_PIECES=2 (opt-in): the split launches inside gm_meta_step take two fp16 pieces per operand, '
                                                           'three products -- operands NARROWER than the reference\'s fp32 (learner.py:36,47), reported for context only'}
                 lib.gm_set_split_pieces(-1)
+        if lib.gm_get_gemm_mode() == 1:
+            # the same schedule with the forward-only evaluations storing EVERY row of the last layer's activation (only the centre rows are ever read)
+            _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', 0), 'set_tuning')
+            step(0); drain()
+            torch.cuda.synchronize(); te = time.perf_counter()
+            for k in range(a.extra_steps):
+                step(k)
+            drain()
+            torch.cuda.synchronize()
+            ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
+            extra['store_every_row'] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1),
+                                        'what': 'default schedule with GM_CENTRE_STORE=0: the last GraphConv also stores the rows of its activation that nobody reads '
+                                                '(bitwise the same step; the default computes every row and stores the centre rows the head gathers, learner.py h[to_fetch])'}
+            _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', 2), 'set_tuning')
         if lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1:
             # the same schedule with every pass writing Z (fused aggregate + GEMM off): step time, and the aggregate's roofline over an
             # all-full-launch sample -- the figure of the earlier rounds (the large query launches are aggregate launches again)
@@ -647,6 +661,8 @@ def main():
                                     'sparse_bwd (dense forward, exact row-sparse backward)' if a.sparse_bwd else
                                     'full (reference-equivalent: every forward/backward dense over all subgraph rows)'),
                        'fused_aggregate_gemm': bool(fused),
+                       'last_layer_stores': 'every row of the last GraphConv is computed (and its relu bits written where a backward pass follows); the activation is stored at the centre rows the head gathers '
+                                            '(extra.store_every_row: the same step with GM_CENTRE_STORE=0)',
                        'streams': 1 if a.serialize else 2,
                        'readback': 'deferred by one step (Meta.forward_deferred)' if a.defer else 'every step (Meta.forward returns the accuracies)',
                        'parallelism': 'tasks sharded over %d rank(s) (rank 0: %d of %d), one all-reduce of the meta-gradient per step' % (world, hi - lo, T),

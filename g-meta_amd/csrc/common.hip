@@ -242,7 +242,7 @@ const gm_knobs& gm_knob() {
         k.gemm_split_grid = env("GM_GEMM_SPLIT_GRID", 0);
         k.gemm_fused_rounds = std::max(0, env("GM_GEMM_FUSED_ROUNDS", 0));          // 0: by launch size (gemm.hip)
         k.gemm_plain_rounds = std::max(1, env("GM_GEMM_PLAIN_ROUNDS", 1));
-        k.centre_store = env("GM_CENTRE_STORE", 1);
+        k.centre_store = env("GM_CENTRE_STORE", 2);
         k.gemm_half_tiles = env("GM_GEMM_HALF_TILES", 1);
         k.gemm_bn = env("GM_GEMM_BN", 256);
         k.gemm_mid_tiles = env("GM_GEMM_MID_TILES", 1536);

@@ -603,7 +603,9 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
             if constexpr (NP == 2) { if (g.amax_out && tl.set != vmax_set) { if (vmax_set >= 0) vmax_flush(); vmax_set = tl.set; } }
             // keep_signed: the sign bit of a row's scale says that nobody reads the row (forward-only pass, last layer: the head gathers the
             // centre rows only).  A wave whose 32 MI rows are all of that kind has no epilogue at all.
-            if (g.keep_signed && __ballot(!(__float_as_uint(sc_t[wr * 32 * MI + (lane & (32 * MI - 1))]) >> 31)) == 0ull) continue;
+            // (differentiated passes still leave the relu' bits / the zero fill of every row: no shortcut there, only the C stores go)
+            const bool keep_only = g.keep_signed && !g.relu_bits && !g.zero_out;
+            if (keep_only && __ballot(!(__float_as_uint(sc_t[wr * 32 * MI + (lane & (32 * MI - 1))]) >> 31)) == 0ull) continue;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                     const int rl = wr * 32 * MI + i * 32 + gq * 8 + kh * 4 + t4;
                     const float sc_raw = sc_t[rl];
                     const bool keep = !g.keep_signed || !(__float_as_uint(sc_raw) >> 31);
-                    if (g.keep_signed && __ballot(keep) == 0ull) continue;
+                    if (keep_only && __ballot(keep) == 0ull) continue;
                     const float sc = fabsf(sc_raw);
                     const int64_t row = row0 + rl;
 #pragma unroll
@@ -621,11 +623,12 @@ __global__ __launch_bounds__(1024) void k_gemm_split_p(SplitGemmK g) {
                         float4 v;
                         v.x = a0 * sc + b4[j].x; v.y = a1 * sc + b4[j].y; v.z = a2 * sc + b4[j].z; v.w = a3 * sc + b4[j].w;
                         if (g.relu) { v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w; }
-                        if (rl >= nrows || !keep) continue;
+                        if (rl >= nrows || (keep_only && !keep)) continue;
                         const int col = wc * 64 + j * 32 + q4 * 4;
                         if constexpr (NP == 2) { if (g.amax_out) vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w))); }
                         if (g.relu_bits) g.relu_bits[(row * g.ldc + col) >> 2] = (uint8_t)((v.x > 0.f) | ((v.y > 0.f) << 1) | ((v.z > 0.f) << 2) | ((v.w > 0.f) << 3));
-                        if (g.nt_store) {
+                        if (!keep) {
+                        } else if (g.nt_store) {
                             typedef float f4v __attribute__((ext_vector_type(4)));
                             f4v vv = {v.x, v.y, v.z, v.w};
                             __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(g.C + row * g.ldc + col));

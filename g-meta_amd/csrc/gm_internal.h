@@ -181,7 +181,7 @@ struct gm_knobs {
     int gemm_mode;                 // 0 exact fp32, 1 split-bf16, -1 not set (library default)
     int gemm_split_min_tiles;      // -1: a quarter of the current device's CUs
     int gemm_split_grid;           // 0: the current device's CU count
-    int centre_store;              // GM_CENTRE_STORE: forward-only passes store only the centre rows of the last layer's activation (1, default) or every row (0)
+    int centre_store;              // GM_CENTRE_STORE: the last layer's update stores only the centre rows of its activation -- in every pass (2, default), in the forward-only passes (1) -- or every row (0)
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
     int agg_mid_win;               // GM_AGG_MID_WIN: rows per wave window over that list (0 = by its length)

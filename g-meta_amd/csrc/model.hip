@@ -649,8 +649,9 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
             g.row_scale = b->d_norm; g.bias = params + L.b_off[l]; g.bias_stride = pstride; g.relu = 1; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
             g.relu_bits = fwd_only == 1 ? nullptr : c.M[l];
-            // forward-only pass, last layer: only the head reads H_L, and only its centre rows (h[to_fetch]): the other rows are computed, not stored
-            if (fwd_only == 1 && l == L.n_gcn - 1 && !c.centre && b->d_norm_c && gm_knob().centre_store) { g.row_scale_keep = b->d_norm_c; g.n_keep = b->n_c; }
+            // last layer: only the head reads H_L, and only its centre rows (h[to_fetch]; the backward pass takes relu' from the bits and the
+            // weight gradient from Z_L): the other rows are computed, their relu' bits written, their values not stored
+            if (l == L.n_gcn - 1 && !c.centre && b->d_norm_c && (gm_knob().centre_store >= 2 || (gm_knob().centre_store == 1 && fwd_only == 1))) { g.row_scale_keep = b->d_norm_c; g.n_keep = b->n_c; }
             if (split_ok) {
                 gm_bound ab = gm_no_bound(), bb;
                 const bool want16 = in_bound(c, l, ab);

@@ -283,10 +283,11 @@ def test_finetunning_through_forced_split_kernels_matches_reference(case, pieces
 
 @pytest.mark.parametrize('pieces', [3, 2])
 def test_centre_only_stores_of_the_last_layer_are_bitwise_the_full_stores(pieces):
-    """Forward-only query evaluations: the last GraphConv's update computes every row and stores only the centre rows (the `h[to_fetch]` of
-    Classifier.forward, learner.py, fused into the GEMM epilogue; GM_CENTRE_STORE=0 stores every row).  Nobody else reads that activation, so
-    accuracies, losses, the meta-gradient and the post-Adam weights are bitwise the same -- training step and finetunning, 4-task arxiv shard
-    (split kernels by launch size, fused aggregate + GEMM) and a hidden-128 fixture with the split kernels forced on."""
+    """The last GraphConv's update computes every row and stores only the centre rows (the `h[to_fetch]` of Classifier.forward, learner.py,
+    fused into the GEMM epilogue): the head is the only reader of that activation -- the backward pass takes relu' from the bit masks and the
+    weight gradient from Z_L.  GM_CENTRE_STORE = 2 (default: every pass), 1 (forward-only passes), 0 (every row stored): accuracies, losses,
+    the meta-gradient and the post-Adam weights are bitwise the same -- training step and finetunning, 4-task arxiv shard (split kernels by
+    launch size, fused aggregate + GEMM) and a hidden-128 fixture with the split kernels forced on."""
     from gmeta_amd import _lib
     from hip_util import hip_meta_step
     lib = _lib.lib()
@@ -300,23 +301,24 @@ def test_centre_only_stores_of_the_last_layer_are_bitwise_the_full_stores(pieces
                 ft = np.asarray(m.finetunning_batch(batch[0], batch[1], batch[2], batch[3]))
             return acc, g, moved, m, ft
         finally:
-            lib.gm_set_tuning(b'GM_CENTRE_STORE', 1)
-    acc1, g1, moved1, m1, ft1 = run(1)
+            lib.gm_set_tuning(b'GM_CENTRE_STORE', 2)
     acc0, g0, moved0, m0, ft0 = run(0)
-    assert np.array_equal(acc1, acc0) and moved1 == moved0 and moved1 > 0 and np.array_equal(ft1, ft0)
-    assert np.array_equal(m1.last_stats['losses_q'], m0.last_stats['losses_q'])
-    for a, b in zip(g1, g0):
-        assert torch.equal(a, b)
+    for mode in (2, 1):
+        acc1, g1, moved1, m1, ft1 = run(mode)
+        assert np.array_equal(acc1, acc0) and moved1 == moved0 and moved1 > 0 and np.array_equal(ft1, ft0)
+        assert np.array_equal(m1.last_stats['losses_q'], m0.last_stats['losses_q'])
+        for a, b in zip(g1, g0):
+            assert torch.equal(a, b)
     # a reference fixture (link prediction has two centres per subgraph: g7 is node classification; the forced split kernels take its 128-wide layers)
     fx = Fixture('g7_wide_h2')
     with forced_split(pieces):
         outs = []
-        for on in (1, 0):
+        for on in (2, 0):
             _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', on), 'set_tuning')
             try:
                 outs.append(hip_meta_step(fx, replay=True))
             finally:
-                lib.gm_set_tuning(b'GM_CENTRE_STORE', 1)
+                lib.gm_set_tuning(b'GM_CENTRE_STORE', 2)
     assert np.array_equal(outs[0]['accs'], outs[1]['accs']) and np.array_equal(outs[0]['grad'], outs[1]['grad'])
     for a, b in zip(outs[0]['vars1'], outs[1]['vars1']):
         assert np.array_equal(a, b)
