@@ -322,3 +322,35 @@ def test_centre_only_stores_of_the_last_layer_are_bitwise_the_full_stores(pieces
     assert np.array_equal(outs[0]['accs'], outs[1]['accs']) and np.array_equal(outs[0]['grad'], outs[1]['grad'])
     for a, b in zip(outs[0]['vars1'], outs[1]['vars1']):
         assert np.array_equal(a, b)
+
+
+def test_centre_only_stores_under_autograd_classifier():
+    """gmeta_amd.Classifier under torch.autograd (`to_fetch=None`: the batch's own centres) with the split kernels forced on: logits and
+    parameter gradients bitwise the same with the last layer's activation stored at the centre rows only (default) and at every row."""
+    import gmeta_amd
+    from gmeta_amd import _lib
+    import hip_util as hu
+    lib = _lib.lib()
+    fx = Fixture('g7_wide_h2')
+    store = hu.make_store(fx)
+    one = gmeta_amd.SubgraphBatch.from_nodes(store, fx.z['spt_seeds'][0], [0, fx.z['spt_seeds'].shape[1]], fx.replay_lists('spt', 0), fx.link)
+    net = gmeta_amd.Classifier(fx.config).cuda()
+    with torch.no_grad():
+        for p, v in zip(net.parameters(), fx.vars0):
+            p.copy_(torch.from_numpy(v))
+    outs = []
+    with forced_split(3) as fs:
+        for on in (2, 0):
+            _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', on), 'set_tuning')
+            try:
+                logits, _ = net(one, None, None)
+                w = torch.linspace(-1.0, 1.0, logits.numel(), device='cuda').view_as(logits)
+                grads = torch.autograd.grad((logits * w).sum(), list(net.parameters()))
+                torch.cuda.synchronize()
+                outs.append((logits.detach().clone(), [g.clone() for g in grads]))
+            finally:
+                lib.gm_set_tuning(b'GM_CENTRE_STORE', 2)
+        assert fs.launches()[0] > 0, 'no split GEMM launch'
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
