@@ -354,3 +354,18 @@ def test_centre_only_stores_under_autograd_classifier():
     assert torch.equal(outs[0][0], outs[1][0])
     for a, b in zip(outs[0][1], outs[1][1]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('hoist,sparse,cone', [(1, 0, 0), (0, 1, 0), (1, 1, 0), (0, 0, 1), (1, 0, 1)])
+@pytest.mark.parametrize('case', ['g7_wide_h2', 'g8_wide_scales'])
+def test_flagged_schedules_through_forced_split_kernels_match_reference(case, hoist, sparse, cone):
+    """The flagged exact schedules (hoisted layer-1 aggregate, row-sparse backward, receptive-field cone) with the three-piece split kernels forced
+    onto the hidden-128 fixtures -- and the last layer's centre-only stores active -- against the reference's own outputs."""
+    from hip_util import hip_meta_step
+    fx = Fixture(case)
+    with forced_split(3):
+        res = hip_meta_step(fx, replay=True, hoist=hoist, sparse_bwd=sparse, cone=cone)
+    np.testing.assert_allclose(res['accs'], fx.z['accs'], atol=1e-6)
+    np.testing.assert_allclose(res['stats']['losses_q'], fx.z['loss_q'].mean(0), atol=TOL)
+    ref_g = np.concatenate([g.reshape(-1) for g in fx.grad])
+    np.testing.assert_allclose(res['grad'], ref_g, atol=TOL, rtol=0)
