@@ -11,6 +11,7 @@ uneven shards when N does not divide task_num) and the meta-gradient is summed b
 step.  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          (starts its own 8 ranks: re-executes itself under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
         bench.py --gpus 8 --steps 5 --warmup 2
 """
@@ -278,6 +279,40 @@ def cpu_baseline_task_parallel(db, data, cfg, config, batch, theta, threads, hos
                     'meta.py:118-161; the reference itself loops them serially), wall time from a common start to the last worker' % (T, workers, threads)}
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def relaunch_command(n, argv):
+    """argv of the launcher a plain `python bench.py --gpus N ...` turns into (the driver's own command line for N > 1, with a free port)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+            '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_probe(a, rank, world, local):
+    """GMETA_BENCH_LAUNCH_PROBE=1 (tests/test_bench_launch.py): everything bench.py does BEFORE it touches a GPU -- the rendezvous, the task
+    sharding, the one-line report from rank 0 -- over gloo, so that the launch path of `python bench.py --gpus N` is covered on a CPU box."""
+    import torch
+    import torch.distributed as dist
+    from gmeta_amd import synth
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29511')
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    over = {'task_num': a.task_num} if a.task_num else {}
+    _, cfg = synth.make_args(a.config, **over)
+    bounds = shard_bounds(cfg['task_num'], world)
+    mine = torch.tensor([rank, local, int(bounds[rank + 1] - bounds[rank])], dtype=torch.int64)
+    got = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(got, mine)
+    dist.barrier()
+    dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'probe': 'launch', 'n_gpus': world, 'task_num': int(cfg['task_num']), 'ranks_reporting': [int(g[0]) for g in got],
+                          'local_ranks': [int(g[1]) for g in got], 'tasks_per_rank': [int(g[2]) for g in got]}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -298,14 +333,24 @@ def main():
     ap.add_argument('--roofline_steps', type=int, default=2, help='extra serialised steps after the timed region for the per-kernel roofline')
     a = ap.parse_args()
 
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run on this node, rendezvous on
+        # 127.0.0.1 at a free port; rank 0 of the relaunched job prints the one JSON line (exec: this process IS the launcher from here on)
+        os.execv(sys.executable, relaunch_command(a.gpus, sys.argv[1:]))
+
     import torch
     import torch.distributed as dist
-    import gmeta_amd
-    from gmeta_amd import _lib, synth
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     if a.gpus > 1 and world != a.gpus:
-        raise SystemExit('launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world))
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d: launch it with torch.distributed.run --nproc-per-node %d, or plainly '
+                         '(python bench.py --gpus %d starts its own ranks)' % (a.gpus, world, a.gpus, a.gpus))
+    if os.environ.get('GMETA_BENCH_LAUNCH_PROBE') == '1':
+        return launch_probe(a, rank, world, local)
+
+    import gmeta_amd
+    from gmeta_amd import _lib, synth
+
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get('GMETA_FORCE_DIST') == '1'      # the latter: exercise the RCCL path with one rank
     if use_dist:
@@ -598,7 +643,14 @@ def main():
         del bx
     # ---- the one collective of a sharded meta-step, timed on its own (same buffer size, same stream): what the step's value already contains
     allreduce = None
+    rank_report = None
     if use_dist:
+        # what every rank of the communicator reports about itself: [rank, device, tasks of its shard, rows of its shard] over RCCL
+        mine = torch.tensor([rank, torch.cuda.current_device(), hi - lo, int(rows)], dtype=torch.int64, device='cuda')
+        got = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        rank_report = {'ranks_reporting': [int(g[0]) for g in got], 'devices': [int(g[1]) for g in got], 'tasks_per_rank': [int(g[2]) for g in got],
+                       'rows_per_rank': [int(g[3]) for g in got], 'backend': dist.get_backend()}
         P_ = sum(p.numel() for p in maml.net.parameters())
         buf = torch.zeros(P_ + 2 * (cfg['update_step'] + 1) + 1, dtype=torch.float32, device='cuda')
         for _ in range(5):
@@ -741,6 +793,8 @@ def main():
                                              'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
         if allreduce:
             out['allreduce'] = allreduce
+        if rank_report:
+            out['ranks'] = rank_report
         if extraction:
             out['extraction'] = extraction
         if e2e:

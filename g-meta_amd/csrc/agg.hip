@@ -280,12 +280,15 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
     const float* xl = a.x + l * 4;
     for (int t0 = 0; t0 < nwin; t0 += G * UNR) {
         float4 acc[UNR][NCH];
-        int rdg[UNR], rp0[UNR]; float rso[UNR];
+        int rdg[UNR], rp0[UNR], rrow[UNR]; float rso[UNR];
 #pragma unroll
         for (int k = 0; k < UNR; ++k) {
             const int rr = t0 + k * G + g;                      // row of this lane group inside the window
             const int src = rr < GM_WAVE ? rr : 0;
             rdg[k] = rr < nwin ? __shfl(dg, src, 64) : -1;
+            // (row-list mode: the row id is broadcast HERE, where the wave is convergent -- behind the divergent `continue` below the source
+            // lane of a partial last window may be masked off and ds_bpermute would hand back 0)
+            rrow[k] = __shfl(myrow32, src, 64);
             if (a.n_heavy && rdg[k] > a.heavy_deg) rdg[k] = -1;            // written by its own workgroup (k_agg_heavy)
             rp0[k] = __shfl(p0, src, 64); rso[k] = __shfl(so, src, 64);
             const int a0 = __shfl(u0, src, 64), a1 = __shfl(u1, src, 64);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(AGG_BLOCK) void k_agg_win(AggK a) {
         for (int k = 0; k < UNR; ++k) {
             if (rdg[k] < 0) continue;
             const int rr_ = t0 + k * G + g;
-            const int64_t row = a.rowlist ? (int64_t)__shfl(myrow32, rr_ < GM_WAVE ? rr_ : 0, 64) : R0 + rr_;
+            const int64_t row = a.rowlist ? (int64_t)rrow[k] : R0 + rr_;
             // rows with more than two in-edges (p99 ~ 19, hubs up to ~1000): the group's LPR lanes fetch the next LPR
             // sources + scales with one coalesced load each, then 8 row loads at a time are issued from registers.
             const int eend = rp0[k] + rdg[k];

@@ -58,10 +58,11 @@ void gm_dev_free(void* p, hipStream_t s) {
 
 // ---------------------------------------------------------------- pinned staging pool (gm_stager)
 struct StageChunk { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, held = false; };
+// ONE pool per device for the whole process, behind a mutex: Subgraphs.batches() starts a fresh prefetch thread per epoch, and a per-thread pool
+// orphaned its pinned chunks (>= 1 MiB each) and events whenever such a thread ended.  The pools are deliberately leaked at process exit (a static
+// destructor would run after the HIP runtime's own teardown); what they hold is bounded by the largest number of builds in flight at once.
 struct StagePool {
     std::vector<StageChunk> chunks;
-    // (no destructor: thread-local pools of the main thread would be torn down after the HIP runtime at process exit; a few MiB of pinned memory
-    // per thread that ever built a batch are left to the process)
     int acquire(size_t bytes) {
         int best = -1;
         for (size_t k = 0; k < chunks.size(); ++k) {
@@ -81,19 +82,22 @@ struct StagePool {
         return best;
     }
 };
-static StagePool& stage_pool() {
-    static thread_local std::map<int, StagePool> m;      // per (thread, device)
+static std::mutex g_stage_mu;
+static StagePool& stage_pool_locked() {                      // caller holds g_stage_mu
+    static std::map<int, StagePool>* m = new std::map<int, StagePool>();      // per device, never destroyed
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
-    return m[dev];
+    return (*m)[dev];
 }
 void* gm_stager::take(size_t bytes) {
     bytes = (bytes + 63) / 64 * 64;
     if (bytes > left) {
-        const int k = stage_pool().acquire(bytes);
+        std::lock_guard<std::mutex> lk(g_stage_mu);
+        StagePool& pool = stage_pool_locked();
+        const int k = pool.acquire(bytes);
         if (k < 0) return nullptr;
         used.push_back(k);
-        cur = stage_pool().chunks[k].p; left = stage_pool().chunks[k].cap;
+        cur = pool.chunks[k].p; left = pool.chunks[k].cap;
     }
     void* r = cur; cur += bytes; left -= bytes;
     return r;
@@ -107,12 +111,13 @@ int gm_stager::upload(void* dptr, const void* src, size_t bytes) {
     return GM_OK;
 }
 gm_stager::~gm_stager() {
-    StagePool& pool = stage_pool();
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    StagePool& pool = stage_pool_locked();
     for (int k : used) {
         StageChunk& c = pool.chunks[k];
-        c.held = false;
         if (hipEventRecord(c.ev, s) == hipSuccess) c.pending = true;      // reusable once the stream has passed this point
         else { (void)hipGetLastError(); (void)hipStreamSynchronize(s); c.pending = false; }
+        c.held = false;
     }
 }
 
@@ -280,7 +285,7 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
         {"GM_AGG_VARIANT", &gm_knobs::agg_variant}, {"GM_GEMM_SPLIT_MIN_TILES", &gm_knobs::gemm_split_min_tiles}, {"GM_GEMM_SPLIT_GRID", &gm_knobs::gemm_split_grid},
         {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_CENTRE_STORE", &gm_knobs::centre_store}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
-        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list},
+        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list}, {"GM_AGG_MID_WIN", &gm_knobs::agg_mid_win},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)

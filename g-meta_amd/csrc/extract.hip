@@ -850,7 +850,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     }
     b->n_c_tiles = (int32_t)(ct.size() / 3); b->n_c_chunks = (int32_t)(cc.size() / 3); b->n_e1_chunks = (int32_t)(ec.size() / 3);
     auto up = [&](int32_t** d, const std::vector<int32_t>& v) -> int {
-        GM_TRY(gm_alloc(d, v.size(), s));
+        GM_TRY(gm_balloc(b, d, v.size(), s));          // (the batch's slabs: batch_free releases nothing else)
         return sg.upload(*d, v);
     };
     GM_TRY(up(&b->d_c_tiles, ct)); GM_TRY(up(&b->d_c_chunks, cc)); GM_TRY(up(&b->d_c_set_chunk_off, ccoff));

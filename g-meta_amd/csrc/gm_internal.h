@@ -186,10 +186,10 @@ struct gm_knobs {
     int fuse_agg, head_stage, side_stream_priority;
     int agg_mid_win;               // GM_AGG_MID_WIN: rows per wave window over that list (0 = by its length)
     int agg_mid_list;              // GM_AGG_MID_LIST: the partial aggregate launch of a fused pass walks a compact list of its window rows (1, default) or every row (0)
-    int query_streams;             // GM_QUERY_STREAMS: 1 / 2 streams for the query evaluations of gm_meta_step (0 = by the query batch's size)
-    int head_threads;              // GM_HEAD_THREADS: workgroup size of k_head_loss (256 / 512 / 1024; 0 = by the task's row count)
+    int query_streams;             // GM_QUERY_STREAMS: 2 = the query evaluations of gm_meta_step alternate between two streams; anything else (default 0) = one stream
+    int head_threads;              // GM_HEAD_THREADS: workgroup size of k_head_loss: 256 or 512; anything else (default 0) = 1024
     int split16_min_rows;          // GM_SPLIT16_MIN_ROWS: support + query rows from which gm_meta_step takes the two-piece kernels (smaller steps are launch-bound: no gain)
-    int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 2 = fp16 pair under recorded bounds (default), 3 = bf16 triple
+    int split_pieces;              // GM_SPLIT_PIECES: pieces per operand of the split kernels inside gm_meta_step: 3 = exact bf16 triple, all 24 operand bits (default); 2 = opt-in fp16 pair under recorded bounds
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
     int wgrad_split_min_chunks;    // GM_WGRAD_SPLIT_MIN_CHUNKS: smallest launch (row chunks) that takes the split weight-gradient kernel; -1: a quarter of the CUs
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
@@ -354,7 +354,7 @@ int gm_split_weights(const float* params, int64_t pstride, int64_t w_off, int K,
 // out[t * out_stride] = max(out[...], max_i |x[t * stride + off + i]|), i < n, as fp32 bit patterns (the slots must have been zeroed)
 int gm_amax(const float* x, int64_t stride, int64_t off, int64_t n, int sets, unsigned* out, int64_t out_stride, hipStream_t s);
 int gm_amax_segs(const float* x, const int64_t* off, const int64_t* n, int segs, unsigned* out, int64_t out_stride, hipStream_t s);   // up to 8 segments of x, one launch
-int gm_split_np();                      // pieces per operand of the split kernels where bounds are available: 2 (fp16, default) or 3 (bf16); env GM_SPLIT_PIECES
+int gm_split_np();                      // pieces per operand of the split kernels: 3 (bf16 triple, default) or 2 (opt-in fp16 pair, only where bounds are recorded); env GM_SPLIT_PIECES
 
 // Grouped transposed-A GEMM for weight gradients:
 //   dW_t[K,N] = sum_{rows of set t} a_scale[row] * A[row,:]^T  G[row,:]   and   db_t[N] = sum G[row,:]

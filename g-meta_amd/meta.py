@@ -49,7 +49,7 @@ class Meta(nn.Module):
         self._flat_theta_buf = None
         self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring', '_unchecked')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -128,17 +128,22 @@ class Meta(nn.Module):
             self._ws = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, device=dev)
         return self._ws
 
+    _RB_RING_MAX = 8      # pinned read-back slots kept for reuse (a caller holding more unread handles than this gets throw-away slots)
+
     def _readback(self, t):
         """Asynchronous device -> pinned-host copy of `t` on the current stream; returns a slot [pinned buffer, event, busy] whose first
-        t.numel() floats hold the data once the event has completed.  Slots are reused after their handle has been read (a handle of
-        Meta.forward_deferred may be read any number of steps late: an unread slot is never overwritten, a new one is pinned instead)."""
+        t.numel() floats hold the data once the event has completed.  A slot is busy from here until its handle has been read OR has died
+        (train.py reads one handle in `train_result_report_steps`: the others release their slot in _Deferred.__del__), so a training loop
+        cycles through one or two slots however rarely it reads.  The ring is bounded: a caller that keeps more than _RB_RING_MAX unread
+        handles alive gets extra slots that are dropped with their handle instead of being kept."""
         ring = getattr(self, '_rb_ring', None)
         if ring is None:
             ring = self._rb_ring = []
         slot = next((r for r in ring if not r[2] and r[0].numel() >= t.numel()), None)
         if slot is None:
             slot = [torch.empty(max(t.numel(), 1024), dtype=torch.float32, pin_memory=True), torch.cuda.Event(), False]
-            ring.append(slot)
+            if len(ring) < self._RB_RING_MAX:
+                ring.append(slot)
         slot[2] = True
         slot[0][:t.numel()].copy_(t, non_blocking=True)
         slot[1].record()
@@ -211,6 +216,12 @@ class Meta(nn.Module):
         if K < 2:
             raise ValueError('update_step must be >= 2: losses_q[0] and [1] are computed under no_grad (meta.py:129-141), '
                              'so the reference cannot back-propagate with fewer steps')
+        prev = getattr(self, '_unchecked', None)
+        if prev is not None:
+            # opt-in two-piece mode only: the previous step's violation word is looked at HERE, before the next step is queued -- whether or
+            # not the caller ever reads that step's accuracies (train.py reads one step in 30) -- and a violated step is re-run three-piece
+            self._unchecked = None
+            prev.accs()
         out, P, T = self._run(x_spt, y_spt, x_qry, y_qry, K, True)
         K1 = K + 1
         self._issued = getattr(self, '_issued', 0) + 1
@@ -242,7 +253,10 @@ class Meta(nn.Module):
             self.meta_optim.found_inf = self._found_inf
             self.meta_optim.grad_scale = None
             self.meta_optim.step()
-            return _Deferred(self, rb, K1, applied=True, rerun=rerun)
+            d = _Deferred(self, rb, K1, applied=True, rerun=rerun)
+            if rerun is not None:
+                self._unchecked = d          # (strong reference: checked at the start of the next step even if the caller drops the handle)
+            return d
         # Non-fused Adam (optim.Adam(fused=True) unavailable) or CPU tensors: the NaN guard needs the loss on the host, so the update is
         # applied HERE -- every meta-batch steps the optimiser like meta.py:163-169, whether or not the caller ever reads the
         # accuracies (train.py only reads them on report steps); only the handle's bookkeeping is left for .accs()
@@ -335,6 +349,13 @@ class _Deferred:
     def __init__(self, meta, buf, K1, applied, P=0, rerun=None):
         self._meta, self._buf, self._K1, self._applied, self._P, self._rerun = meta, buf, K1, applied, P, rerun
         self._accs = None
+
+    def __del__(self):
+        # an unread handle gives its pinned read-back slot back (Meta._readback): the copy into it was queued before any later step's copy
+        # on the same stream, so a later reuse cannot be overtaken by it
+        buf = getattr(self, '_buf', None)
+        if getattr(self, '_applied', False) and isinstance(buf, tuple):
+            buf[0][2] = False
 
     def accs(self):
         if self._accs is not None:

@@ -44,7 +44,7 @@ def _world(name, T, K=K):
         for t in range(T):
             seeds = [tuple(int(v) for v in s) for s in db._task_arrays(t)[col]]
             ob[tag].append(orc.Batch(og, seeds, [par[off[k]:off[k + 1]] for k in range(so[t], so[t + 1])]))
-    return dict(args=args, cfg=cfg, data=data, store=store, db=db, batch=batch, config=config, og=og, S=S, Q=Q, ob=ob, T=T, K=K, link=bool(cfg.get('link')))
+    return dict(name=name, args=args, cfg=cfg, data=data, store=store, db=db, batch=batch, config=config, og=og, S=S, Q=Q, ob=ob, T=T, K=K, link=bool(cfg.get('link')))
 
 
 @pytest.fixture(scope='module')
@@ -89,8 +89,13 @@ def _meta_vs_oracle(w, tol_grad=TOL):
         flat = np.concatenate([g.reshape(-1) for g in mg]).astype(np.float64)
         g_sum = flat if g_sum is None else g_sum + flat
     np.testing.assert_allclose(accs, np.mean(acc_t, axis=0), atol=1e-6)                       # corrects / task_num (meta.py:171)
-    np.testing.assert_allclose(m.last_stats['losses_q'], lq_sum / T, atol=TOL, rtol=1e-4)     # losses_q[k] / task_num
-    np.testing.assert_allclose(grads['g'], g_sum / T, atol=tol_grad, rtol=1e-3)               # theta.grad before Adam
+    # north_star: "within 1e-4 on logits/meta-grads" -- ABSOLUTE (rtol = 0); the observed margins go on record (pytest -s / the GPU log)
+    e_l = float(np.abs(np.asarray(m.last_stats['losses_q'], np.float64) - lq_sum / T).max())
+    e_g = float(np.abs(grads['g'].astype(np.float64) - g_sum / T).max())
+    print('[fullsize oracle] %s T=%d K=%d: max|losses_q - oracle| %.3g (|loss| <= %.3g), max|theta.grad - oracle| %.3g (|grad| <= %.3g)'
+          % (w.get('name', '?'), T, K, e_l, float(np.abs(lq_sum / T).max()), e_g, float(np.abs(g_sum / T).max())))
+    np.testing.assert_allclose(m.last_stats['losses_q'], lq_sum / T, atol=TOL, rtol=0)        # losses_q[k] / task_num
+    np.testing.assert_allclose(grads['g'], g_sum / T, atol=tol_grad, rtol=0)                  # theta.grad before Adam
     # per-task accuracies of every step (the [sets, K+1] block of gm_meta_step's output) through finetunning on the same theta
     return m, theta0
 
@@ -169,11 +174,14 @@ def test_arxiv_forward_backward_per_task_weights_match_oracle(arxiv, shape):
     for t in sorted({t_hub, (t_hub + 3) % T}):
         ob = w['ob']['qry'][t]
         lo, cache = orc.classifier_forward(ob, ob.features(w['data']['feats']), thetas[t], w['config'])
-        np.testing.assert_allclose(logits[so[t]:so[t + 1]], lo, atol=TOL, rtol=1e-4)
+        np.testing.assert_allclose(logits[so[t]:so[t + 1]], lo, atol=TOL, rtol=0)
         og = orc.classifier_backward(ob, thetas[t], w['config'], cache, dlog[so[t]:so[t + 1]])
         want = np.concatenate([g.reshape(-1) for g in og])
+        # (a raw per-task gradient under random unit-scale dlogits, entries up to `scale`: the bar is 1e-4 of the largest entry, no per-entry slack)
         scale = max(1.0, float(np.abs(want).max()))
-        np.testing.assert_allclose(dparams[t, :P], want, atol=TOL * scale, rtol=1e-3)
+        print('[fullsize oracle] per-task weights, task %d: max|logits - oracle| %.3g, max|dparams - oracle| %.3g at scale %.3g'
+              % (t, float(np.abs(logits[so[t]:so[t + 1]] - lo).max()), float(np.abs(dparams[t, :P] - want).max()), scale))
+        np.testing.assert_allclose(dparams[t, :P], want, atol=TOL * scale, rtol=0)
 
 
 @pytest.mark.parametrize('name', ['tissue', 'firstmm'])

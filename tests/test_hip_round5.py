@@ -1,0 +1,87 @@
+"""GPU (-m gpu): round-5 cases.
+
+* the compact-row-list aggregate launch (partial launches of the fused aggregate + GEMM passes) with a PARTIAL last wave window whose
+  source lane group is masked off -- the ds_bpermute-after-divergence bug the round-4 advisor found (list windows wider than a lane
+  group: width 64 from 32-row windows, width 128 with 64-row windows; the shipped shapes use 2..4-row windows and never hit it)."""
+import argparse
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class tuning:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        from gmeta_amd import _lib
+        self.lib = _lib.lib()
+        for k, (v, _) in self.kv.items():
+            _lib.check(self.lib.gm_set_tuning(k.encode(), v), 'set_tuning')
+        return self
+
+    def __exit__(self, *exc):
+        for k, (_, v0) in self.kv.items():
+            self.lib.gm_set_tuning(k.encode(), v0)
+        return False
+
+
+def _list_world(M, F0, hidden, seed=3):
+    """One directed graph of N = 4 M nodes: nodes [0, M) have exactly 5 in-edges from random nodes of [M, N), every other node has one
+    in-edge (from its successor).  Every subgraph is the WHOLE graph (from_nodes), so a batch of s subgraphs has s * M rows of in-degree
+    5 -- the rows of the partial launch's list -- out of 4 s M, and no hub rows."""
+    import gmeta_amd
+    rng = np.random.default_rng(seed)
+    N = 4 * M
+    src, dst = [], []
+    for v in range(M):
+        for u in rng.choice(np.arange(M, N), 5, replace=False):
+            src.append(int(u)); dst.append(v)
+    for v in range(M, N):
+        src.append(M + (v - M + 1) % (N - M)); dst.append(v)
+    feats = [rng.standard_normal((N, F0)).astype(np.float32)]
+    store = gmeta_amd.GraphStore([(N, np.asarray(src, np.int64), np.asarray(dst, np.int64))], feats)
+    nodes = np.arange(N, dtype=np.int64)
+
+    def batch(centres):
+        seeds = np.asarray([[0, c, -1] for c in centres], np.int32)
+        return gmeta_amd.SubgraphBatch.from_nodes(store, seeds, [0, len(centres)], [nodes] * len(centres), False)
+    args = argparse.Namespace(update_lr=0.01, meta_lr=1e-3, n_way=3, k_spt=1, k_qry=1, task_num=1, update_step=3, update_step_test=3, method='G-Meta',
+                              hoist_z1=0, serialize=0, sparse_bwd=0, cone=0)
+    config = [('GraphConv', [F0, hidden]), ('GraphConv', [hidden, hidden]), ('Linear', [hidden, 3])]
+    return store, feats, batch, args, config
+
+
+@pytest.mark.parametrize('M,win', [(27, 32), (27, 64), (11, 64), (43, 64)])
+def test_row_list_launch_with_a_partial_last_window_is_bitwise_the_full_launch(M, win):
+    """3 query subgraphs x M list rows: 3 M mod win = 17 (M = 27: width-64 layer, lane groups of 16) or 33 (M = 11 / 43: width-128 layer,
+    lane groups of 32) leaves the last window's next lane group without a row.  The list launch must write exactly what the all-rows launch
+    (GM_AGG_MID_LIST = 0) writes: same per-row arithmetic -- every loss and accuracy of finetunning AND of a training step bitwise."""
+    import gmeta_amd
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    out = {}
+    for use_list in (1, 0):
+        with tuning(GM_GEMM_SPLIT_MIN_TILES=(0, -1), GM_WGRAD_SPLIT_MIN_CHUNKS=(0, -1), GM_AGG_MID_LIST=(use_list, 1), GM_AGG_MID_WIN=(win, 0)):
+            store, feats, batch, args, config = _list_world(M, 64, 128)
+            S, Q = batch([0, 1, 2]), batch([3, 4, 5])
+            assert Q.rows == 12 * M
+            torch.manual_seed(7)
+            m = gmeta_amd.Meta(args, config).to('cuda')
+            ys = [torch.tensor([0, 1, 2])]; yq = [torch.tensor([0, 1, 2])]
+            ft = m.finetunning_batch([S], ys, [Q], yq)
+            lib.gm_profile_enable(1)
+            accs = m([S], ys, [Q], yq, None, None, None, None, None, None, feats)
+            ms, n, w = C.c_double(), C.c_int64(), C.c_int64()
+            lib.gm_profile_read(4, C.byref(ms), C.byref(n), C.byref(w))
+            lib.gm_profile_enable(0)
+            assert n.value > 0                                     # the split (fused aggregate + GEMM) kernels really ran
+            out[use_list] = (np.asarray(ft), np.asarray(accs), np.asarray(m.last_stats['losses_q']),
+                             torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy())
+    for a, b in zip(out[1], out[0]):
+        assert np.array_equal(a, b), float(np.abs(a - b).max())
+    assert np.isfinite(out[1][2]).all() and np.abs(out[1][3]).max() > 0
