@@ -107,6 +107,55 @@ def launch_classes(launches):
     return out
 
 
+def schedule_roofline(lib, maml, step, drain, n_steps, ms_per_step):
+    """Roofline accounting of a FLAGGED schedule (the receptive-field schedules): a few serialised steps with HIP events around every launch,
+    the aggregate priced on the rows each level actually touches (gm_profile_read category 0 under gm_hparams_t.cone: destination-level
+    row bounds + norms, the edges between the two levels, source-level rows read once, destination rows written once), the update GEMMs
+    and weight gradients on their level rows (A read once + C written once / A and G read once), and the split of the step's kernel time."""
+    def rd(cat):
+        ms, n, w = C.c_double(), C.c_int64(), C.c_int64()
+        lib.gm_profile_read(cat, C.byref(ms), C.byref(n), C.byref(w))
+        return ms.value, n.value, w.value
+    lib.gm_profile_enable(1)
+    ser0 = maml.serialize
+    maml.serialize = 1
+    step(0); drain()
+    tot = {c: [0.0, 0, 0] for c in (0, 1, 2, 4, 5, 6, 7, 13, 14, 15)}
+    for k in range(n_steps):
+        step(k); drain()
+        for c in tot:
+            ms, n, w = rd(c)
+            tot[c][0] += ms; tot[c][1] += n; tot[c][2] += w
+    maml.serialize = ser0
+    lib.gm_profile_enable(0)
+    per = lambda c, i: tot[c][i] / n_steps
+    agg_ms, agg_n, agg_by = per(0, 0), per(0, 1), per(0, 2)
+    g_ms = per(1, 0) + per(4, 0) + per(6, 0); g_fl = per(1, 2) + per(4, 2) + per(6, 2); g_n = per(1, 1) + per(4, 1) + per(6, 1)
+    w_ms = per(2, 0) + per(5, 0) + per(7, 0); w_fl = per(2, 2) + per(5, 2) + per(7, 2); w_n = per(2, 1) + per(5, 1) + per(7, 1)
+    g_by, w_by, h_ms, h_n = per(13, 2), per(14, 2), per(15, 0), per(15, 1)
+    ach = agg_by / (agg_ms * 1e-3) / 1e9 if agg_ms > 0 else None
+    t_hbm = (agg_by + g_by + w_by) / (HBM_PEAK_GBS * 1e9) * 1e3
+    t_mfma = (g_fl + w_fl) / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
+    return {
+        'roofline': {'bound': 'hbm', 'kernel': 'k_agg on the receptive-field levels (level-to-level compact CSRs)', 'achieved': round(ach, 1) if ach else None,
+                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None, 'launches_per_step': int(agg_n),
+                     'avg_launch_us': round(agg_ms / max(agg_n, 1) * 1e3, 2), 'algorithmic_bytes_per_step': int(agg_by),
+                     'priced_on': 'the rows each level touches: 4 (n_dst + 1) + 4 e + 4 n_dst + 4 F (n_src + n_dst) per launch (SURVEY 8(d) B_agg on level_rows / level_edges)',
+                     'measured': 'HIP events around every launch of %d serialised steps' % n_steps},
+        'update': {'gemm': {'launches_per_step': int(g_n), 'ms_per_step': round(g_ms, 4), 'gflop_per_step': round(g_fl / 1e9, 2), 'tflops': round(g_fl / (g_ms * 1e-3) / 1e12, 2) if g_ms > 0 else None,
+                            'a_plus_c_bytes_per_step': int(g_by), 'gb_per_s': round(g_by / (g_ms * 1e-3) / 1e9, 1) if g_ms > 0 else None,
+                            'frac_of_hbm_peak': round(g_by / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if g_ms > 0 else None},
+                   'wgrad': {'launches_per_step': int(w_n), 'ms_per_step': round(w_ms, 4), 'gflop_per_step': round(w_fl / 1e9, 2), 'tflops': round(w_fl / (w_ms * 1e-3) / 1e12, 2) if w_ms > 0 else None,
+                             'a_plus_g_bytes_per_step': int(w_by), 'gb_per_s': round(w_by / (w_ms * 1e-3) / 1e9, 1) if w_ms > 0 else None,
+                             'frac_of_hbm_peak': round(w_by / (w_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if w_ms > 0 else None}},
+        'kernel_time_ms_per_step': {'aggregate': round(agg_ms, 4), 'gemm': round(g_ms, 4), 'wgrad_incl_reduction': round(w_ms, 4), 'head_loss': round(h_ms, 4),
+                                    'head_loss_launches': int(h_n), 'sum_of_timed_launches': round(agg_ms + g_ms + w_ms + h_ms, 4),
+                                    'timed_launches_per_step': int(agg_n + g_n + w_n + h_n)},
+        'step_bound': {'ms_at_hbm_peak': round(t_hbm, 4), 'ms_at_f32_mfma_peak': round(t_mfma, 4), 'frac_of_serial_bound': round((t_hbm + t_mfma) / ms_per_step, 4),
+                       'note': 'every launch of this schedule is a few microseconds of work behind a dependent-launch boundary: the schedule is bound by its launch chain, not by a pipe'},
+    }
+
+
 def shard_bounds(T, world):
     """Contiguous task ranges of a meta-batch per rank (sizes differ by at most one)."""
     return np.linspace(0, T, world + 1).round().astype(int)
@@ -504,6 +553,8 @@ def main():
             torch.cuda.synchronize()
             ms_e = (time.perf_counter() - te) / a.extra_steps * 1e3
             extra[name] = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1)}
+            if kw.get('cone') and a.roofline_steps > 0:
+                extra[name].update(schedule_roofline(lib, maml, step, drain, a.roofline_steps, ms_e))
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
         if lib.gm_get_gemm_mode() == 1:      # the same dense schedule with every GEMM on the exact-fp32 MFMA kernels (include/gmeta_hip.h, gm_set_gemm_mode)
             lib.gm_set_gemm_mode(0)

@@ -53,6 +53,7 @@ PROTOTYPES = {
     'gm_meta_out_floats': (i64, [vp, vp, vp]),
     'gm_meta_step': (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, i64, vp]),
     'gm_meta_finish': (C.c_int, [vp, i64, i32, vp, vp, vp]),
+    'gm_meta_finish_adam': (C.c_int, [vp, i64, i32, vp, vp, vp, vp, vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp]),
     'gm_set_gemm_mode': (None, [i32]),
     'gm_get_gemm_mode': (i32, []),
     'gm_get_split_pieces': (i32, []),

@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libgmeta_hip.so')
-SOURCES = ['common.hip', 'store.hip', 'extract.hip', 'agg.hip', 'gemm.hip', 'model.hip', 'cone.hip']
+SOURCES = ['common.hip', 'store.hip', 'extract.hip', 'agg.hip', 'agg_stream.hip', 'gemm.hip', 'model.hip', 'cone.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wno-unused-result']
 
 

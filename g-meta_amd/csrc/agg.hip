@@ -494,6 +494,19 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
     GM_REQUIRE(!g.rowlist || win, GM_EINVAL, "aggregate: a row list needs the window kernel");
     if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; a.hub = nullptr; }      // the generic kernel walks every row itself
+    if (win && gm_knob().agg_stream && gm_stream_ok(g)) {
+        // LDS-DMA stream kernel for every row below the hub threshold; hub rows by whole workgroups (their rows carry no edges in the stream tables)
+        static const int dbg = getenv("GM_AGG_STREAM_DEBUG") ? atoi(getenv("GM_AGG_STREAM_DEBUG")) : 0;      // 1: no hub launch, 2: no stream launch (bring-up)
+        if (g.n_heavy > 0 && !(dbg & 1)) {
+            AggK h = a; h.sched = nullptr; h.hub = nullptr;
+            if (g.width == 64) hipLaunchKernelGGL((k_agg_heavy<16, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
+            else if (g.width == 128) hipLaunchKernelGGL((k_agg_heavy<32, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
+            else hipLaunchKernelGGL((k_agg_heavy<64, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
+        }
+        if (!(dbg & 2)) GM_TRY(gm_launch_stream(g, a.nt, s));
+        GM_HIP(hipGetLastError());
+        return GM_OK;
+    }
     if (win) {
         if (g.width == 64) launch_win<16, 1>(a, s);
         else if (g.width == 128) launch_win<32, 1>(a, s);
@@ -520,6 +533,12 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     return GM_OK;
 }
 
+void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather) {
+    if (!b->d_sindptr[o] || !b->d_sseg[o] || (gather && (o != 0 || !b->d_sed_feat))) return;
+    a.stream_indptr = b->d_sindptr[o]; a.stream_ed = gather ? b->d_sed_feat : b->d_sed[o]; a.stream_seg = b->d_sseg[o]; a.stream_nseg = b->stream_nseg;
+    a.stream_xrows = gather ? b->store->total_nodes : b->rows;
+}
+
 extern "C" int64_t gm_aggregate_bytes(const gm_batch_t* b, int32_t width) {
     // B_agg(n,e,F) = 4(n+1) [indptr] + 4e [indices] + 4n [norm] + 4nF [read X once] + 4nF [write Z]
     if (!b) return -1;
@@ -541,6 +560,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
     a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, transposed ? 1 : 0, (hipStream_t)stream));
+    if (a.e_w) gm_agg_stream_args(a, b, transposed ? 1 : 0, gather != 0);
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

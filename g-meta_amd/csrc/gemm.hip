@@ -533,6 +533,7 @@ int gm_launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
     const int cat = a.Bsplit ? (a.np == 2 ? GM_PROF_GEMM_SPLIT16 : GM_PROF_GEMM_SPLIT) : GM_PROF_GEMM;          // the pipe the launch runs on (bench.py prices each on its own peak)
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
     if (a.Bsplit) gm_prof_note(GM_PROF_GEMM_SPLIT_BYTES, 4 * a.rows * (int64_t)a.K + 4 * (a.row_scale_keep ? a.n_keep : a.rows) * (int64_t)a.N);      // compulsory A + C bytes
+    gm_prof_note(GM_PROF_GEMM_BYTES, 4 * a.rows * (int64_t)a.K + 4 * ((a.Bsplit && a.row_scale_keep) ? a.n_keep : a.rows) * (int64_t)a.N);
     const int rc = launch_gemm_nn(a, s);
     gm_prof_end(cat, s);
     return rc;
@@ -1284,6 +1285,7 @@ static bool wgrad_takes_split(const gm_wgrad_args& a) {
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const int cat = wgrad_takes_split(a) ? ((a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? GM_PROF_WGRAD_SPLIT16 : GM_PROF_WGRAD_SPLIT) : GM_PROF_WGRAD;
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
+    gm_prof_note(GM_PROF_WGRAD_BYTES, 4 * a.rows * ((int64_t)a.K + a.N));
     const int rc = launch_wgrad(a, s);
     gm_prof_end(cat, s);
     return rc;

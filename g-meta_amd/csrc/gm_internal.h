@@ -140,6 +140,10 @@ struct gm_batch {
     // instead of every row of the batch: 8 % of the rows of the arxiv query batch carry work in that launch, and a wave whose 16-row window holds
     // one of them runs its gathers one dependent batch at a time; with the list every wave window is full of rows that have work.
     int32_t* d_mid = nullptr; int32_t n_mid = 0, mid_win = 0;
+    // stream aggregate (agg_stream.hip), per orientation: row bounds in the stream edge table (hub rows hold no edges there; bit 31 of a hub row's
+    // end bound flags it), the interleaved {source row, weight} edge table in row order (d_sed_feat: sources = feature rows of the store, layer 1),
+    // and the cost-balanced row segments of the launch's waves
+    int32_t* d_sindptr[2] = {nullptr, nullptr}; int2* d_sed[2] = {nullptr, nullptr}; int2* d_sed_feat = nullptr; int2* d_sseg[2] = {nullptr, nullptr}; int32_t stream_nseg = 0;
     int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
@@ -193,6 +197,9 @@ struct gm_knobs {
     int wgrad_round_bias;          // weight-gradient chunking: percent of row-slot efficiency another round of chunks must gain over fewer, longer chunks
     int wgrad_split_min_chunks;    // GM_WGRAD_SPLIT_MIN_CHUNKS: smallest launch (row chunks) that takes the split weight-gradient kernel; -1: a quarter of the CUs
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
+    int agg_stream;                // GM_AGG_STREAM: eligible full aggregate launches take the LDS-DMA stream kernel (agg_stream.hip)
+    int agg_stream_wgs;            // GM_AGG_STREAM_WGS: its workgroups per CU (0 = 3)
+    int agg_stream_depth;          // GM_AGG_STREAM_DEPTH: KiB of gathers in flight per wave (8 / 12 / 16)
 };
 const gm_knobs& gm_knob();
 
@@ -284,7 +291,14 @@ struct gm_agg_args {
     int sched_len, sched_win;
     const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
     const int32_t* rowlist; int64_t n_list; int list_win;      // window kernel only: the wave windows walk rowlist[0 .. n_list) instead of every row (sched / sched_len then index list blocks)
+    // optional stream tables of this launch's batch / orientation (gm_agg_stream_args): eligible launches take the LDS-DMA stream kernel (agg_stream.hip)
+    const int32_t* stream_indptr; const int2* stream_ed; const int2* stream_seg; int stream_nseg; int64_t stream_xrows;
 };
+// fills the stream fields of `a` for orientation o of batch b (gather: the sources are rows of the store's feature table); a no-op without tables
+void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather);
+bool gm_stream_ok(const gm_agg_args& g);
+int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s);
+int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, hipStream_t s, gm_stager* sg);
 #define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
 #define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row
 const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)
@@ -438,7 +452,10 @@ static inline int gm_wgrad_chunk_rows(const std::vector<int32_t>& set_off, int n
 #define GM_PROF_EX_FINAL 10     // batch finalisation (launch tables, hub schedule, gains, per-edge / per-row tables): GPU span incl. the host round trips inside it
 #define GM_PROF_GEMM_SPLIT_BYTES 11   // work-only shadow of the split GEMM launches (categories 4 and 6): compulsory HBM bytes 4 rows (K + N) -- the A operand read once, C written once
 #define GM_PROF_AGG_BOUND 12          // work-only shadow of category 0 with the partial launches priced as in rounds 2-3 (sources = min(edges, rows), an upper bound)
-#define GM_PROF_CATS 13
+#define GM_PROF_GEMM_BYTES 13         // work-only shadow of EVERY grouped GEMM launch (categories 1, 4, 6): compulsory HBM bytes, A rows read once + the C rows it stores
+#define GM_PROF_WGRAD_BYTES 14        // ... of every weight-gradient launch (categories 2, 5, 7): the A and G rows read once
+#define GM_PROF_HEAD 15               // head + prototypical loss (+ head backward) launches: time; work = subgraphs
+#define GM_PROF_CATS 16
 void gm_prof_begin(int cat, hipStream_t s, int64_t work);
 void gm_prof_end(int cat, hipStream_t s);
 void gm_prof_reset(int n_cats = GM_PROF_CATS);

@@ -834,6 +834,19 @@ static int gcn_backward_sparse(GcnCtx& c, const float* params, int64_t pstride, 
 // The same layer formulas as gcn_forward/gcn_backward, evaluated only on the rows that can reach a centre
 // (cone.hip): layer l maps level l (sources) to level l+1 (destinations); all matrices are compact.
 
+// SURVEY 8(d)'s B_agg on the rows a level-to-level aggregate actually touches: the destination level's row bounds + norms, the edges between the
+// two levels, every source-level row read once (by construction each of them is the source of at least one of those edges), every
+// destination row written once
+static int64_t cone_agg_bytes(int64_t n_dst, int64_t n_src, int64_t nnz, int width) {
+    return 4 * (n_dst + 1) + 4 * nnz + 4 * n_dst + 4 * (n_src + n_dst) * (int64_t)width;
+}
+static int cone_launch_agg(const gm_agg_args& a, int64_t n_src, int64_t nnz, hipStream_t st) {
+    const int64_t by = cone_agg_bytes(a.rows, n_src, nnz, a.width);
+    gm_prof_agg_begin(st, by); gm_prof_note(GM_PROF_AGG_STRICT, by);
+    const int rc = gm_launch_aggregate(a, st);
+    gm_prof_agg_end(st);
+    return rc;
+}
 static gm_agg_args cone_agg(const gm_cone* cn, const gm_cone_level& up, int transposed) {
     gm_agg_args a{};
     a.indptr = transposed ? up.d_indptr_t : up.d_indptr; a.indices = transposed ? up.d_indices_t : up.d_indices;
@@ -859,13 +872,13 @@ static int cone_forward(GcnCtx& c, const float* params, int64_t pstride, float* 
             gm_agg_args a = cone_agg(cn, up, 0);
             a.x = c.Z[l]; a.ldx = fo; a.s_out = up.d_norm; a.bias = params + L.b_off[l]; a.bias_stride = pstride; a.set_row_off = up.d_set_off; a.n_sets = b->sets;
             a.relu = 1; a.out = c.H[l]; a.rows = up.n; a.width = fo;
-            GM_TRY(gm_launch_aggregate(a, st));
+            GM_TRY(cone_launch_agg(a, lo.n, up.nnz, st));
         } else {
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a = cone_agg(cn, up, 0);
                 a.s_in = lo.d_norm; a.out = c.Z[l]; a.rows = up.n; a.width = fi; a.ldx = fi;
                 if (l == 0) { a.x = b->store->d_feat; a.x_row = lo.d_feat_row; a.ldx = b->store->feat_ld; } else a.x = xin;
-                GM_TRY(gm_launch_aggregate(a, st));
+                GM_TRY(cone_launch_agg(a, lo.n, up.nnz, st));
                 if (l == 0) c.z1_valid = 1;
             }
             gm_gemm_args g{}; g.A = c.Z[l]; g.lda = fi; g.B = params + L.w_off[l]; g.b_stride = pstride; g.C = c.H[l]; g.ldc = fo; g.K = fi; g.N = fo;
@@ -901,7 +914,7 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
             // dY = A^T (norm * dQ) on the source level ; dW = (norm*X)^T dY ; db = colsum(dQ) ; dQ_prev = relu'(H_prev) * norm * (dY W^T)
             gm_agg_args a = cone_agg(cn, up, 1);
             a.x = dQ; a.ldx = fo; a.s_in = up.d_norm; a.out = T; a.rows = lo.n; a.width = fo;
-            GM_TRY(gm_launch_aggregate(a, st));
+            GM_TRY(cone_launch_agg(a, up.n, up.nnz, st));
             w.A = l > 0 ? c.H[l - 1] : c.X0; w.lda = fi; w.a_scale = lo.d_norm; w.G = T; w.ldg = fo; w.db = nullptr;
             w.rows = lo.n; w.chunks = lo.d_chunks; w.n_chunks = lo.n_chunks; w.set_chunk_off = lo.d_set_chunk_off;
             GM_TRY(gm_launch_wgrad(w, st));
@@ -923,7 +936,7 @@ static int cone_backward(GcnCtx& c, const float* params, int64_t pstride, const 
                 GM_TRY(gm_launch_gemm_nn(g, st));
                 gm_agg_args a = cone_agg(cn, up, 1);
                 a.x = T; a.ldx = fi; a.s_out = lo.d_norm; a.mask_h = maskprev; a.out = dQ; a.rows = lo.n; a.width = fi;
-                GM_TRY(gm_launch_aggregate(a, st));
+                GM_TRY(cone_launch_agg(a, up.n, up.nnz, st));
             }
         }
     }
@@ -1089,10 +1102,12 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     int nt = gm_knob().head_threads;
     if (nt != 256 && nt != 512) nt = 1024;
     const SgdK sg = bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f};
+    gm_prof_begin(GM_PROF_HEAD, st, b->subs);
     if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
     else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
     else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
     GM_HIP(hipGetLastError());
+    gm_prof_end(GM_PROF_HEAD, st);
     if (bwd && dQ && hk.dq_amax) c.dqv = true;
     return GM_OK;
 }
@@ -1385,6 +1400,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     }
     gm_prof_reset(GM_PROF_STEP_CATS);
     gm_prof_reset_cat(GM_PROF_GEMM_SPLIT_BYTES); gm_prof_reset_cat(GM_PROF_AGG_BOUND);
+    gm_prof_reset_cat(GM_PROF_GEMM_BYTES); gm_prof_reset_cat(GM_PROF_WGRAD_BYTES); gm_prof_reset_cat(GM_PROF_HEAD);
     tm.lap("plan");
     // Two streams: `st` carries the support chain (the serial dependency through the fast weights: forward -> loss ->
     // backward -> SGD, K times), `sq` carries the K+1 query evaluations, each of which only needs fw_k and the
@@ -1502,6 +1518,51 @@ __global__ void k_meta_finish(const float* head, int64_t P, int K1, float* grad,
 extern "C" int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream) {
     GM_REQUIRE(head && grad && found_inf && P >= 1 && K1 >= 1, GM_EINVAL, "meta_finish: bad arguments");
     hipLaunchKernelGGL(k_meta_finish, dim3((int)std::min<int64_t>(512, (P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, head, P, K1, grad, found_inf);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
+// The same guard AND the Adam step (meta.py:97,161-169: optim.Adam(lr = meta_lr), default betas / eps, no weight decay) in ONE launch: between two
+// meta-steps the stream otherwise carries k_meta_finish + three launches of torch's fused optimiser, and the host spends ~100 us inside
+// optimizer.step() -- on the small configurations (1.5 - 4 ms per meta-step) that is where the GPU sat empty.  torch's fused Adam rule, in fp32:
+//   m <- m + (1 - b1) (g - m);  v <- b2 v + (1 - b2) g g;  theta <- theta - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// with t = step + 1; a NaN reduced query loss leaves theta, m, v and the step count untouched (`if torch.isnan(loss_q): pass`).  steps[0 .. n_steps)
+// are the per-parameter step counters of the torch optimiser's state (all equal): read by every block, written by the LAST block to finish
+// (ticket), so that no block can see the incremented value.
+__global__ __launch_bounds__(256) void k_meta_finish_adam(const float* head, int64_t P, int K1, float* theta, float* m, float* v, float* grad, float* steps, int n_steps,
+                                                          float lr, float b1, float b2, float eps, float* found_inf, unsigned* ticket) {
+    const float cnt = head[P + 2 * K1];
+    const float l = head[P + K1 - 1] / cnt;
+    const bool skip = l != l;
+    const float t = steps[0] + 1.f;
+    const float bc1 = (float)(1.0 - pow((double)b1, (double)t)), bc2s = sqrtf((float)(1.0 - pow((double)b2, (double)t)));
+    const float step_size = lr / bc1;
+    for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < P; id += (int64_t)gridDim.x * blockDim.x) {
+        const float g = head[id] / cnt;
+        grad[id] = g;
+        if (skip) continue;
+        const float m0 = m[id], v0 = v[id];
+        const float m1 = m0 + (1.f - b1) * (g - m0);
+        const float v1 = b2 * v0 + (1.f - b2) * g * g;
+        m[id] = m1; v[id] = v1;
+        theta[id] -= step_size * (m1 / (sqrtf(v1) / bc2s + eps));
+    }
+    __syncthreads();                                       // every thread of this block has read steps[0]
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {      // every block has
+            *ticket = 0u;
+            *found_inf = skip ? 1.f : 0.f;
+            if (!skip) for (int i = 0; i < n_steps; ++i) steps[i] = t;
+        }
+    }
+}
+
+extern "C" int gm_meta_finish_adam(const float* head, int64_t P, int32_t K1, float* theta, float* exp_avg, float* exp_avg_sq, float* grad, float* steps, int32_t n_steps,
+                                   float lr, float beta1, float beta2, float eps, float* found_inf, uint32_t* ticket, void* stream) {
+    GM_REQUIRE(head && theta && exp_avg && exp_avg_sq && grad && steps && found_inf && ticket && P >= 1 && K1 >= 1 && n_steps >= 1, GM_EINVAL, "meta_finish_adam: bad arguments");
+    hipLaunchKernelGGL(k_meta_finish_adam, dim3((int)std::min<int64_t>(256, (P + 511) / 512)), dim3(256), 0, (hipStream_t)stream, head, P, (int)K1, theta, exp_avg, exp_avg_sq, grad,
+                       steps, (int)n_steps, lr, beta1, beta2, eps, found_inf, ticket);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

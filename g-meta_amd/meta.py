@@ -43,13 +43,14 @@ class Meta(nn.Module):
         self.sparse_bwd = int(getattr(args, 'sparse_bwd', 0))   # 1: exact row-sparse backward (flagged schedule)
         self.cone = int(getattr(args, 'cone', 0))               # 1: receptive-field schedule, forward and backward (flagged)
         self.last_stats = {}
+        self.fused_adam_kernel = True                           # False: gm_meta_finish + torch's own fused Adam launches (the rule is the same)
         self._ws = None
         self._keep = None
         self._flat_grad = None
         self._flat_theta_buf = None
         self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring', '_unchecked')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring', '_unchecked', '_adam_m', '_adam_v', '_adam_steps', '_adam_ticket')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -109,6 +110,41 @@ class Meta(nn.Module):
                     off += p.numel()
             setattr(self, attr, buf)
         return buf
+
+    def _bind_adam(self, dev):
+        """The optimiser state of torch.optim.Adam (meta_optim.state[p] = {'step', 'exp_avg', 'exp_avg_sq'}) as views of flat buffers laid out like
+        the flat parameter vector, so that gm_meta_finish_adam updates them in place and meta_optim (state_dict, deepcopy, a later plain
+        meta_optim.step()) keeps seeing the true state.  Re-bound -- values preserved -- whenever something broke the aliasing (deepcopy,
+        load_state_dict, .to())."""
+        params = list(self.net.parameters())
+        P = sum(p.numel() for p in params)
+        st = self.meta_optim.state
+        m_, v_, steps = getattr(self, '_adam_m', None), getattr(self, '_adam_v', None), getattr(self, '_adam_steps', None)
+        ok = m_ is not None and m_.numel() == P and m_.device == dev and steps.numel() == len(params)
+        if ok:
+            off = 0
+            for i, p in enumerate(params):
+                s = st.get(p)
+                if (not s or s['exp_avg'].data_ptr() != m_.data_ptr() + 4 * off or s['exp_avg_sq'].data_ptr() != v_.data_ptr() + 4 * off or
+                        s['step'].data_ptr() != steps.data_ptr() + 4 * i):
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            m_ = torch.zeros(P, dtype=torch.float32, device=dev); v_ = torch.zeros(P, dtype=torch.float32, device=dev)
+            steps = torch.zeros(len(params), dtype=torch.float32, device=dev)
+            off = 0
+            with torch.no_grad():
+                for i, p in enumerate(params):
+                    s = st.get(p) or {}
+                    mv, vv, sv = m_[off:off + p.numel()].view_as(p), v_[off:off + p.numel()].view_as(p), steps[i:i + 1].view(())
+                    if 'exp_avg' in s:
+                        mv.copy_(s['exp_avg']); vv.copy_(s['exp_avg_sq']); sv.fill_(float(s['step']))
+                    st[p] = {'step': sv, 'exp_avg': mv, 'exp_avg_sq': vv}
+                    off += p.numel()
+            self._adam_m, self._adam_v, self._adam_steps = m_, v_, steps
+            self._adam_ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        return m_, v_, steps, self._adam_ticket
 
     def _bind_grads(self, dev):
         return self._bind_flat('_flat_grad', dev, True)
@@ -244,15 +280,29 @@ class Meta(nn.Module):
             # The read-back of [losses_q | corrects | count | per-task | violation] is queued BEFORE the guard and the optimiser kernels (it does not
             # depend on them): the host gets the accuracies ~50 us earlier and prepares the next meta-step while Adam still runs
             rb = self._readback(out[P:])
-            # mean + NaN guard on the device (gm_meta_finish), then the fused Adam with `found_inf`: the kernel skips the
-            # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)
             fg = self._bind_grads(head.device)               # (stands for meta_optim.zero_grad(); loss_q.backward())
             if getattr(self, '_found_inf', None) is None or self._found_inf.device != head.device:
                 self._found_inf = torch.zeros((), dtype=torch.float32, device=head.device)      # 0-dim: what GradScaler hands a fused optimiser
-            _lib.check(_lib.lib().gm_meta_finish(_lib.ptr(head), P, K1, _lib.ptr(fg), _lib.ptr(self._found_inf), _lib.stream_ptr()), 'gm_meta_finish')
-            self.meta_optim.found_inf = self._found_inf
-            self.meta_optim.grad_scale = None
-            self.meta_optim.step()
+            g = self.meta_optim.param_groups[0]
+            own = (self.fused_adam_kernel and 'step' not in vars(self.meta_optim) and len(self.meta_optim.param_groups) == 1 and not g.get('amsgrad') and
+                   not g.get('maximize') and g.get('weight_decay', 0) == 0 and not isinstance(g['lr'], torch.Tensor))
+            if own:
+                # mean + NaN guard + the Adam rule in ONE launch (gm_meta_finish_adam) on the optimiser's own state tensors (views of flat
+                # buffers): between two meta-steps the stream carries one kernel instead of four, and the host does not spend ~100 us inside
+                # optimizer.step() -- on the small configurations that gap was where the GPU sat empty
+                m_, v_, steps, ticket = self._bind_adam(head.device)
+                theta = self._flat_theta()
+                _lib.check(_lib.lib().gm_meta_finish_adam(_lib.ptr(head), P, K1, _lib.ptr(theta), _lib.ptr(m_), _lib.ptr(v_), _lib.ptr(fg), _lib.ptr(steps), steps.numel(),
+                                                          float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), _lib.ptr(self._found_inf),
+                                                          _lib.ptr(ticket), _lib.stream_ptr()), 'gm_meta_finish_adam')
+            else:
+                # (a caller that hooked meta_optim.step -- the usual way to look at the meta-gradient -- or changed the optimiser's options:)
+                # mean + NaN guard on the device (gm_meta_finish), then torch's fused Adam with `found_inf`: the kernel skips the
+                # update and the step counter is rolled back when the flag is set == `if torch.isnan(loss_q): pass` (meta.py:163-169)
+                _lib.check(_lib.lib().gm_meta_finish(_lib.ptr(head), P, K1, _lib.ptr(fg), _lib.ptr(self._found_inf), _lib.stream_ptr()), 'gm_meta_finish')
+                self.meta_optim.found_inf = self._found_inf
+                self.meta_optim.grad_scale = None
+                self.meta_optim.step()
             d = _Deferred(self, rb, K1, applied=True, rerun=rerun)
             if rerun is not None:
                 self._unchecked = d          # (strong reference: checked at the start of the next step even if the caller drops the handle)

@@ -202,6 +202,13 @@ int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const int32_t* y_
  * found_inf: device fp32 [1] <- 1.0 if losses_q[K] / task count is NaN else 0.0 (a fused Adam skips its step on 1.0, which
  * is the reference's `if torch.isnan(loss_q): pass`).  K1 = update_step + 1. */
 int gm_meta_finish(const float* head, int64_t P, int32_t K1, float* grad, float* found_inf, void* stream);
+/* gm_meta_finish AND the Adam step of meta.py:97,161-169 (optim.Adam(lr = meta_lr): betas (0.9, 0.999), eps 1e-8, no weight decay) in one launch.
+ * theta / exp_avg / exp_avg_sq: device fp32 [P], updated in place -- the parameters and the optimiser state torch.optim.Adam keeps (the host mirror
+ * makes them views of flat buffers); steps: device fp32 [n_steps], the optimiser's per-parameter step counters (all equal), incremented together;
+ * grad <- head[0..P) / task count as in gm_meta_finish; a NaN reduced query loss leaves theta, the state and the counters untouched and sets
+ * found_inf = 1 (`if torch.isnan(loss_q): pass`).  ticket: device uint32 [1], zero before the first call (the kernel leaves it zero). */
+int gm_meta_finish_adam(const float* head, int64_t P, int32_t K1, float* theta, float* exp_avg, float* exp_avg_sq, float* grad, float* steps, int32_t n_steps,
+                        float lr, float beta1, float beta2, float eps, float* found_inf, uint32_t* ticket, void* stream);
 
 /* Update-GEMM arithmetic (the reference multiplies in fp32: torch.matmul(feat, weight), learner.py:36,47).
  * mode 0: exact fp32 on v_mfma_f32_32x32x2_f32 everywhere.  mode 1 (default): large N = 128 / 256 launches run on the bf16 matrix cores
@@ -246,7 +253,11 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
  * (not reset by gm_meta_step; gm_profile_enable resets them): 8 = k_nodes (h-hop expansion, sampling, node lists, induced degrees),
  * 9 = k_fill (the batched CSR in both orientations), work = subgraphs; 10 = batch finalisation (GPU span including its host round trips).
  * 12 = work-only: bytes by which the rounds-2/3 pricing of the partial aggregate launches (sources = min(edges, rows)) exceeds the exact count.
- * 11 = work-only shadow of categories 4 + 6: compulsory HBM bytes of the split GEMM launches, 4 rows (K + N) (A read once, C written once). */
+ * 11 = work-only shadow of categories 4 + 6: compulsory HBM bytes of the split GEMM launches, 4 rows (K + N) (A read once, C written once).
+ * 13 / 14 = work-only: compulsory HBM bytes of EVERY grouped GEMM launch (A read once + the C rows stored) / of every weight-gradient launch
+ * (A and G read once); 15 = the head + prototypical-loss launches (k_head_loss; work = subgraphs).  Under the receptive-field schedule
+ * (gm_hparams_t.cone) category 0 is priced on the rows each level-to-level aggregate touches: destination-level row bounds and norms, the
+ * edges between the two levels, every source-level row read once, every destination row written once. */
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 /* The same per launch: ms[k] / work[k] of the k-th timed launch of the category since the last reset (at most cap); returns their number (< 0: error). */
 int gm_profile_read_launches(int32_t category, double* ms, int64_t* work, int32_t cap);

@@ -39,7 +39,7 @@ def fixture_meta(fx):
     return m
 
 
-def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0, cone=0):
+def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0, cone=0, fused_adam_kernel=True):
     """Meta.forward on the fixture's meta-batch.  Returns accs, the meta-gradient that reached Adam,
     the updated weights and the node lists."""
     store = make_store(fx)
@@ -48,18 +48,14 @@ def hip_meta_step(fx, replay=True, hoist=0, sparse_bwd=0, cone=0):
     m.hoist_z1 = hoist
     m.sparse_bwd = sparse_bwd
     m.cone = cone
-    grads = {}
-    orig = m.meta_optim.step
-
-    def step(*a, **k):
-        grads['g'] = torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy().copy()
-        return orig(*a, **k)
-    m.meta_optim.step = step
+    m.fused_adam_kernel = bool(fused_adam_kernel)
     ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]
     yq = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_qry']]
     xs, xq = S.views(), Q.views()
     accs = m(xs, ys, xq, yq, None, None, None, None, None, None, fx.feats)
-    res = {'accs': accs, 'grad': grads.get('g'), 'vars1': [p.detach().cpu().numpy() for p in m.net.parameters()],
+    # the meta-gradient that reached Adam = p.grad after the step (views of the flat buffer gm_meta_finish[_adam] wrote: the mean over the tasks)
+    grad = torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy().copy()
+    res = {'accs': accs, 'grad': grad, 'vars1': [p.detach().cpu().numpy() for p in m.net.parameters()],
            'spt_parent': S.parent().astype(np.int64), 'qry_parent': Q.parent().astype(np.int64), 'stats': m.last_stats,
            'S': S, 'Q': Q, 'meta': m, 'store': store}
     return res

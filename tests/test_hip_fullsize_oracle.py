@@ -67,36 +67,51 @@ def _check_extraction_sample(w, stride):
     return n_sampled
 
 
-def _meta_vs_oracle(w, tol_grad=TOL):
+def _oracle_step(w):
+    """The oracle's meta-step on every task of the world (cached in w): mean accuracies, mean losses_q, mean first-order meta-gradient."""
+    if 'oracle_step' not in w:
+        K, T, b = w['K'], w['T'], w['batch']
+        torch.manual_seed(11)
+        import gmeta_amd
+        m = gmeta_amd.Meta(w['args'], w['config'])        # (the initial weights every schedule below starts from)
+        theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+        ys = [np.asarray(y) for y in b[1]]; yq = [np.asarray(y) for y in b[3]]
+        lq_sum, g_sum, acc_t = np.zeros(K + 1), None, []
+        for t in range(T):
+            bs, bq = w['ob']['spt'][t], w['ob']['qry'][t]
+            lq, aq, mg = orc.task_inner_loop(bs, bq, bs.features(w['data']['feats']), bq.features(w['data']['feats']), ys[t], yq[t], theta0, w['config'],
+                                             w['args'].k_spt, w['args'].update_lr, K, True)
+            lq_sum += lq; acc_t.append(aq)
+            flat = np.concatenate([g.reshape(-1) for g in mg]).astype(np.float64)
+            g_sum = flat if g_sum is None else g_sum + flat
+        w['oracle_step'] = (theta0, np.mean(acc_t, axis=0), lq_sum / T, g_sum / T)
+    return w['oracle_step']
+
+
+def _meta_vs_oracle(w, tol_grad=TOL, **schedule):
+    """Meta.forward (any flagged schedule: hoist_z1 / sparse_bwd / cone = 1) on the world's meta-batch against the oracle's per-task loop."""
     import gmeta_amd
-    K = w['K']
-    torch.manual_seed(11)
+    K, T = w['K'], w['T']
+    theta0, o_acc, o_lq, o_g = _oracle_step(w)
     m = gmeta_amd.Meta(w['args'], w['config']).to('cuda')
-    theta0 = [p.detach().cpu().numpy().copy() for p in m.net.parameters()]
+    with torch.no_grad():
+        for p, v in zip(m.net.parameters(), theta0):
+            p.copy_(torch.from_numpy(v))
+    for k, v in schedule.items():
+        setattr(m, k, v)
     grads = {}
     orig = m.meta_optim.step
     m.meta_optim.step = lambda *a, **k: (grads.setdefault('g', torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy().copy()), orig(*a, **k))[1]
     b = w['batch']
     accs = m(*b, w['data']['feats'])
-    ys = [np.asarray(y) for y in b[1]]; yq = [np.asarray(y) for y in b[3]]
-    T = w['T']
-    lq_sum, g_sum, acc_t = np.zeros(K + 1), None, []
-    for t in range(T):
-        bs, bq = w['ob']['spt'][t], w['ob']['qry'][t]
-        lq, aq, mg = orc.task_inner_loop(bs, bq, bs.features(w['data']['feats']), bq.features(w['data']['feats']), ys[t], yq[t], theta0, w['config'],
-                                         w['args'].k_spt, w['args'].update_lr, K, True)
-        lq_sum += lq; acc_t.append(aq)
-        flat = np.concatenate([g.reshape(-1) for g in mg]).astype(np.float64)
-        g_sum = flat if g_sum is None else g_sum + flat
-    np.testing.assert_allclose(accs, np.mean(acc_t, axis=0), atol=1e-6)                       # corrects / task_num (meta.py:171)
+    np.testing.assert_allclose(accs, o_acc, atol=1e-6)                                         # corrects / task_num (meta.py:171)
     # north_star: "within 1e-4 on logits/meta-grads" -- ABSOLUTE (rtol = 0); the observed margins go on record (pytest -s / the GPU log)
-    e_l = float(np.abs(np.asarray(m.last_stats['losses_q'], np.float64) - lq_sum / T).max())
-    e_g = float(np.abs(grads['g'].astype(np.float64) - g_sum / T).max())
-    print('[fullsize oracle] %s T=%d K=%d: max|losses_q - oracle| %.3g (|loss| <= %.3g), max|theta.grad - oracle| %.3g (|grad| <= %.3g)'
-          % (w.get('name', '?'), T, K, e_l, float(np.abs(lq_sum / T).max()), e_g, float(np.abs(g_sum / T).max())))
-    np.testing.assert_allclose(m.last_stats['losses_q'], lq_sum / T, atol=TOL, rtol=0)        # losses_q[k] / task_num
-    np.testing.assert_allclose(grads['g'], g_sum / T, atol=tol_grad, rtol=0)                  # theta.grad before Adam
-    # per-task accuracies of every step (the [sets, K+1] block of gm_meta_step's output) through finetunning on the same theta
+    e_l = float(np.abs(np.asarray(m.last_stats['losses_q'], np.float64) - o_lq).max())
+    e_g = float(np.abs(grads['g'].astype(np.float64) - o_g).max())
+    print('[fullsize oracle] %s T=%d K=%d %s: max|losses_q - oracle| %.3g (|loss| <= %.3g), max|theta.grad - oracle| %.3g (|grad| <= %.3g)'
+          % (w.get('name', '?'), T, K, schedule or 'dense', e_l, float(np.abs(o_lq).max()), e_g, float(np.abs(o_g).max())))
+    np.testing.assert_allclose(m.last_stats['losses_q'], o_lq, atol=TOL, rtol=0)               # losses_q[k] / task_num
+    np.testing.assert_allclose(grads['g'], o_g, atol=tol_grad, rtol=0)                         # theta.grad before Adam
     return m, theta0
 
 
@@ -124,6 +139,10 @@ def test_arxiv_headline_config_matches_oracle():
     assert w['args'].task_num == 32 and w['args'].update_step == 10
     assert w['Q'].rows > 1_000_000
     _meta_vs_oracle(w)
+    # ... and the flagged receptive-field schedule bench.py reports as extra.cone+hoist_z1 (layer l only on the rows that reach a centre,
+    # learner.py:165-175; the loop-invariant layer-1 aggregate computed once) against the SAME oracle numbers, same bar
+    _meta_vs_oracle(w, cone=1, hoist_z1=1)
+    _meta_vs_oracle(w, cone=1)
 
 
 @pytest.mark.parametrize('shape', ['config', '256-128', '128-128'])

@@ -85,3 +85,79 @@ def test_row_list_launch_with_a_partial_last_window_is_bitwise_the_full_launch(M
     for a, b in zip(out[1], out[0]):
         assert np.array_equal(a, b), float(np.abs(a - b).max())
     assert np.isfinite(out[1][2]).all() and np.abs(out[1][3]).max() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------- guard + Adam in one launch
+def _adam_state(m):
+    return [(float(s['step']), s['exp_avg'].detach().cpu().numpy().copy(), s['exp_avg_sq'].detach().cpu().numpy().copy())
+            for s in (m.meta_optim.state[p] for p in m.net.parameters())]
+
+
+@pytest.mark.parametrize('case', ['g2_shared', 'g1_sampled_h2', 'g3_linkpred', 'g6_nan_skip'])
+def test_fused_finish_adam_kernel_equals_torch_fused_adam(case):
+    """gm_meta_finish_adam (mean + NaN guard + Adam, one launch, the default) against gm_meta_finish + torch.optim.Adam(fused=True) on the same
+    meta-batches, three consecutive steps: parameters, exp_avg, exp_avg_sq to a few ulp, step counters equal; the NaN fixture leaves weights,
+    state and counters untouched on both paths; meta_optim.state_dict() of the kernel path is a regular Adam state."""
+    from golden_util import Fixture
+    from hip_util import fixture_batches, fixture_meta, make_store
+    fx = Fixture(case)
+    store = make_store(fx)
+    S, Q = fixture_batches(fx, store, True)
+    ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]; yq = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_qry']]
+    res = {}
+    for own in (True, False):
+        m = fixture_meta(fx)
+        m.fused_adam_kernel = own
+        m(S.views(), ys, Q.views(), yq, None, None, None, None, None, None, fx.feats)
+        one = ([p.detach().cpu().numpy().copy() for p in m.net.parameters()], _adam_state(m))
+        for _ in range(2):
+            m(S.views(), ys, Q.views(), yq, None, None, None, None, None, None, fx.feats)
+        res[own] = ([p.detach().cpu().numpy().copy() for p in m.net.parameters()], _adam_state(m), m, one)
+    # after ONE step (identical inputs on both paths): every parameter and both moments to a few ulp (torch evaluates 1 - beta in double, the kernel in fp32:
+    # relative 1.3e-5 on exp_avg_sq, which cancels against the bias correction in the update)
+    for a, b in zip(res[True][3][0], res[False][3][0]):
+        np.testing.assert_allclose(a, b, atol=2e-9, rtol=0)
+    for (s1, m1, v1), (s0, m0, v0) in zip(res[True][3][1], res[False][3][1]):
+        assert s1 == s0 == (0.0 if case == 'g6_nan_skip' else 1.0)
+        np.testing.assert_allclose(m1, m0, atol=1e-12, rtol=1e-6); np.testing.assert_allclose(v1, v0, atol=1e-20, rtol=3e-5)
+    # after three steps the two runs see meta-gradients that differ in the last bits; the head's bias is left out (its gradient is identically zero up to fp
+    # noise -- prototype distances are shift invariant -- so Adam moves it by sign(noise) * lr: DESIGN.md section 3)
+    for a, b in zip(res[True][0][:-1], res[False][0][:-1]):
+        np.testing.assert_allclose(a, b, atol=2e-6, rtol=0)
+    for (s1, _, _), (s0, _, _) in zip(res[True][1], res[False][1]):
+        assert s1 == s0 == (0.0 if case == 'g6_nan_skip' else 3.0)
+    if case == 'g6_nan_skip':
+        for a, v0 in zip(res[True][0], fx.vars0):
+            assert np.array_equal(a, v0)
+    sd = res[True][2].meta_optim.state_dict()
+    assert len(sd['state']) == len(fx.vars0) and all(set(v) == {'step', 'exp_avg', 'exp_avg_sq'} for v in sd['state'].values())
+
+
+def test_fused_adam_state_survives_deepcopy_and_a_plain_optimizer_step():
+    """train.py:87,127 deep-copies the Meta object: the copy owns its own optimiser state (values preserved, re-bound to new flat buffers at its next
+    step) and the original is unaffected; a caller may still call meta_optim.step() itself on the kernel path's state."""
+    import copy
+    from golden_util import Fixture
+    from hip_util import fixture_batches, fixture_meta, make_store
+    fx = Fixture('g2_shared')
+    store = make_store(fx)
+    S, Q = fixture_batches(fx, store, True)
+    ys = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_spt']]; yq = [torch.from_numpy(y.astype(np.int64)) for y in fx.z['y_qry']]
+    inp = (S.views(), ys, Q.views(), yq, None, None, None, None, None, None, fx.feats)
+    m = fixture_meta(fx)
+    m(*inp); m(*inp)
+    snap = copy.deepcopy(m)
+    st_m, st_s = _adam_state(m), _adam_state(snap)
+    for (s1, m1, v1), (s0, m0, v0) in zip(st_m, st_s):
+        assert s1 == s0 == 2.0 and np.array_equal(m1, m0) and np.array_equal(v1, v0)
+    m(*inp)                                                             # the original moves on ...
+    assert all(s == 3.0 for s, _, _ in _adam_state(m)) and all(s == 2.0 for s, _, _ in _adam_state(snap))
+    snap(*inp)                                                          # ... and so does the copy, from ITS state: same third step
+    for p, q in zip(m.net.parameters(), snap.net.parameters()):
+        assert torch.equal(p.detach(), q.detach())
+    for (s1, m1, v1), (s0, m0, v0) in zip(_adam_state(m), _adam_state(snap)):
+        assert s1 == s0 == 3.0 and np.array_equal(m1, m0) and np.array_equal(v1, v0)
+    before = [p.detach().clone() for p in m.net.parameters()]
+    m.meta_optim.step()                                                 # a plain torch step on the same state (p.grad still holds the last meta-gradient)
+    assert all(s == 4.0 for s, _, _ in _adam_state(m))
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, m.net.parameters()))
