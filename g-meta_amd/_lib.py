@@ -66,6 +66,8 @@ PROTOTYPES = {
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
     'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),
     'gm_profile_read_launches': (C.c_int, [i32, vp, vp, i32]),
+    'gm_debug_stamp': (C.c_int, [vp, vp]),
+    'gm_stream_debug': (C.c_int, [i32, vp, i32]),
 }
 
 _lib = None

@@ -494,19 +494,7 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     const bool win = vec4 && bias_ok && mask_ok && (g.width == 64 || g.width == 128 || g.width == 256 || g.width == 512) && agg_variant() != 1;
     GM_REQUIRE(!g.rowlist || win, GM_EINVAL, "aggregate: a row list needs the window kernel");
     if (!win) { a.heavy = nullptr; a.n_heavy = 0; a.sched = nullptr; a.hub = nullptr; }      // the generic kernel walks every row itself
-    if (win && gm_knob().agg_stream && gm_stream_ok(g)) {
-        // LDS-DMA stream kernel for every row below the hub threshold; hub rows by whole workgroups (their rows carry no edges in the stream tables)
-        static const int dbg = getenv("GM_AGG_STREAM_DEBUG") ? atoi(getenv("GM_AGG_STREAM_DEBUG")) : 0;      // 1: no hub launch, 2: no stream launch (bring-up)
-        if (g.n_heavy > 0 && !(dbg & 1)) {
-            AggK h = a; h.sched = nullptr; h.hub = nullptr;
-            if (g.width == 64) hipLaunchKernelGGL((k_agg_heavy<16, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
-            else if (g.width == 128) hipLaunchKernelGGL((k_agg_heavy<32, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
-            else hipLaunchKernelGGL((k_agg_heavy<64, 1>), dim3(g.n_heavy), dim3(AGG_HEAVY_BLOCK), 0, s, h);
-        }
-        if (!(dbg & 2)) GM_TRY(gm_launch_stream(g, a.nt, s));
-        GM_HIP(hipGetLastError());
-        return GM_OK;
-    }
+    if (win && gm_knob().agg_stream && gm_stream_ok(g)) return gm_launch_stream(g, a.nt, s);      // LDS-DMA stream kernel (row segments + hub parts in one launch)
     if (win) {
         if (g.width == 64) launch_win<16, 1>(a, s);
         else if (g.width == 128) launch_win<32, 1>(a, s);
@@ -534,8 +522,8 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
 }
 
 void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather) {
-    if (!b->d_sindptr[o] || !b->d_sseg[o] || (gather && (o != 0 || !b->d_sed_feat))) return;
-    a.stream_indptr = b->d_sindptr[o]; a.stream_ed = gather ? b->d_sed_feat : b->d_sed[o]; a.stream_seg = b->d_sseg[o]; a.stream_nseg = b->stream_nseg;
+    if (!b->d_sptr[o] || !b->d_sseg[o] || (gather && (o != 0 || !b->d_su_feat))) return;
+    a.stream = b; a.stream_o = o; a.stream_feat = gather ? 1 : 0;
     a.stream_xrows = gather ? b->store->total_nodes : b->rows;
 }
 

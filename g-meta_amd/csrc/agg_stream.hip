@@ -8,191 +8,283 @@
 //   * every gathered source row is ONE `global_load_lds_dwordx4` (1 KiB per instruction at width 256) into a wave-private ring of R
 //     slots; the wave's in-order VM counter is the ring's only synchronisation (`s_waitcnt vmcnt(R - 1)` before slot i is read,
 //     R - 1 younger gathers stay in flight): no destination registers, no barrier, R KiB in flight per wave;
-//   * edge descriptors {source row, weight} come through the SCALAR cache (s_load_dwordx4 from an interleaved per-edge table laid out in
-//     row order, one 4-edge block ahead), row bounds likewise (16 rows at a time, parked in the lanes of one VGPR), so the vector memory
-//     queue carries nothing but gathers and the output stores -- nothing the compiler would wait `vmcnt(0)` for;
+//   * edge descriptors ride the same queue: the per-edge tables (sources for the issuing side, weights -- R edges behind -- for the consuming
+//     side, laid out in row order) arrive 64 edges at a time by `global_load_lds_dword` into two small per-wave rings, a chunk ahead of
+//     their use, and are read back four at a time with broadcast ds_read_b128 -- they never sit in asm-loaded registers the compiler could
+//     copy before the data lands; row bounds come through the scalar cache (16 rows per round trip, parked in the lanes of one VGPR).  The
+//     vector memory queue carries nothing but DMA and the output stores -- nothing the compiler would wait `vmcnt(0)` for;
 //   * a wave owns a contiguous run of rows (cost-balanced segments built with the batch, XCD-contiguous like the window kernel's blocks),
-//     accumulates a row in edge order with the same fma chain as k_agg_win (bitwise the same rows) and writes it once.
-// ~24 VGPRs and R KiB of LDS per wave: one 4-wave workgroup (48 KiB) fits next to a persistent GEMM workgroup (101 KiB, 480 VGPRs), several fit
-// an otherwise empty CU.  Hub rows (in-degree above the batch's hub threshold) are left out of the stream tables (their row bound carries a
-// flag) and written by whole workgroups as before.
+//     accumulates a row in edge order with the same fma chain as k_agg_win (bitwise the same rows) and writes it once;
+//   * hub rows (in-degree above the batch's hub threshold, up to ~1000 edges) hold no edges in the row-ordered part of the tables (their
+//     row bound carries a flag); their edges follow behind it and are streamed in parts of ~128 edges by the launch's FIRST workgroups, one
+//     wave per part: partial rows through write-through stores, an arrival ticket, and the last arriver sums the parts in part order
+//     (deterministic) -- the scheme of agg.hip's hub blocks on the stream engine.
+// <= 32 VGPRs and R KiB of LDS per wave: one 4-wave workgroup (48 KiB) fits next to a persistent GEMM workgroup (101 KiB, 480 VGPRs of 512), several
+// fit an otherwise empty CU.
 #include <algorithm>
+#include <stdlib.h>
+#include <type_traits>
 #include "gm_internal.h"
 
 typedef int as_i4 __attribute__((ext_vector_type(4)));
 
 #define AS_WAVES 4                      // waves per workgroup: one per SIMD
 
-// ---- scalar-cache loads (SMEM returns out of order and the compiler does not count asm loads: every use is behind an explicit lgkmcnt(0))
-__device__ __forceinline__ int as_sload(const void* p, int byte_off) {      // one dword, waited for
+// ---- scalar-cache loads.  SMEM returns out of order and the compiler does not count asm loads: every use sits behind an explicit lgkmcnt(0).
+// Addresses are formed in full by scalar arithmetic (no register offset operand).
+__device__ __forceinline__ int as_sload(const void* p) {            // one dword, waited for
     int r;
-    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p), "s"(byte_off) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
     return r;
 }
-// 8 dwords at p (4-byte aligned), issued only
-__device__ __forceinline__ void as_sload8(const void* p, as_i4& a, as_i4& b) {
-    asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x10" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
-}
-__device__ __forceinline__ void as_swait8(as_i4& a, as_i4& b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b) :: "memory");
-}
-// 16 dwords at p (4-byte aligned), issued only
-__device__ __forceinline__ void as_sload16(const void* p, as_i4& a, as_i4& b, as_i4& c, as_i4& d) {
+__device__ __forceinline__ void as_sload16(const void* p, as_i4& a, as_i4& b, as_i4& c, as_i4& d) {      // 16 dwords at p (4-byte aligned), issued only
     asm volatile("s_load_dwordx4 %0, %4, 0x0\n\ts_load_dwordx4 %1, %4, 0x10\n\ts_load_dwordx4 %2, %4, 0x20\n\ts_load_dwordx4 %3, %4, 0x30"
                  : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(p) : "memory");
 }
 __device__ __forceinline__ void as_swait16(as_i4& a, as_i4& b, as_i4& c, as_i4& d) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b), "+s"(c), "+s"(d) :: "memory");
 }
-
-// v_writelane_b32 with a run-time lane (no clang builtin; on gfx950 the value and the lane select cannot both be SGPRs, the select may be M0):
-// lane `lane` of v <- val, both wave-uniform and set by scalar instructions; ignores EXEC.  M0 is the compiler's: saved and restored.
-__device__ __forceinline__ void as_writelane(int& v, int val, int lane) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %1, %2, m0\n\ts_mov_b32 m0, %0" : "=&s"(keep), "+v"(v) : "s"(val), "s"(lane));
-}
+// lane LANE (a constant) of v <- val (wave-uniform); ignores EXEC
+#define AS_WRITELANE(V, VAL, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(V) : "s"(VAL))
 
 struct AggS {
-    const int32_t* indptr_s;            // [rows + 1 (+ pad)] row bounds in the stream edge table; bit 31 of entry r + 1: row r is a hub row (not written here)
-    const int2* ed;                     // stream edge table, row order: {source row of x, weight bits}
-    const float* x; unsigned row_bytes; // gathered matrix, bytes per row (ldx * 4; rows * row_bytes < 4 GiB)
+    const int32_t* sptr;                // [rows + 1 (+ pad)] row bounds in the stream edge tables; bit 31 of entry r + 1: row r is a hub row (not written by its segment)
+    const int32_t* su; const float* sw; // stream edge tables: source row of x / weight per edge -- the rows' edges in row order, then the hub rows' edges in hub order
+    const float* x; unsigned row_bytes; // gathered matrix, bytes per row (ldx * 4; rows * row_bytes < 2 GiB)
     float* out; int width; int nt;      // [rows, width]
     const int32_t* rowlist;             // optional: output row of stream row i (list launches)
-    const int2* seg; int n_seg;         // per wave: rows [x, y) of the stream tables
+    const int2* seg; int n_seg;         // row segments [x, y) of the non-hub workgroups' waves
+    int hub_wgs;                        // blocks [0, hub_wgs): hub workgroups (a multiple of the XCD count)
+    const int32_t* heavy; const int32_t* hcum; int n_heavy; int e_norm;      // hub rows, prefix of their edge counts; their edges start at su / sw[e_norm + hcum[h]]
+    const int32_t* hub; float* hub_scratch; int hub_part, hub_ld, n_parts;   // gm_agg_schedule's part table (NULL: one part per hub row), partial rows
+    int prio;                           // s_setprio of the waves (GM_AGG_STREAM_PRIO): beside a GEMM workgroup whose feeder waves run at 2 / 3
+    unsigned long long* dbg;            // timeline probe (tools/coreside_probe.py): [2 * blocks] start / end of every workgroup on the device's constant clock
 };
 
-// One gather: the edge's weight is parked in lane wlane of wring, then LDS[slot .. slot + LPR * 16) <- x[voff .. ), 16 bytes per lane of the
-// lower LPR lanes (M0 = the slot's LDS byte address; EXEC is all ones around this statement: the kernel's control flow is wave-uniform).
+// One gather: LDS[slot .. slot + LPR * 16) <- x[voff .. ), 16 bytes per lane of the lower LPR lanes (M0 = the slot's LDS byte address; EXEC is
+// all ones around this statement: the kernel's control flow is wave-uniform).  M0 is the compiler's: saved and restored.
 template <int LPR>
-__device__ __forceinline__ void as_issue(int& wring, int w, int wlane, unsigned lds_slot, const float* xbase, unsigned voff) {
+__device__ __forceinline__ void as_issue(unsigned lds_slot, const float* xbase, unsigned voff) {
     unsigned keep;
     if constexpr (LPR == 64)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %1, %2, m0\n\ts_mov_b32 m0, %6\n\ts_nop 0\n\t"
-                     "global_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(wring) : "s"(w), "s"(wlane), "v"(voff), "s"(xbase), "s"(lds_slot) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot) : "memory");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %1, %2, m0\n\ts_mov_b32 m0, %6\n\t"
-                     "s_mov_b32 exec_lo, %7\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
-                     "global_load_lds_dwordx4 %4, %5\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep), "+v"(wring) : "s"(w), "s"(wlane), "v"(voff), "s"(xbase), "s"(lds_slot), "s"(LPR == 32 ? 0xffffffffu : 0xffffu) : "memory");
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot), "s"(LPR == 32 ? 0xffffffffu : 0xffffu) : "memory");
+}
+
+// 64 descriptors (256 bytes): LDS[dst .. dst + 256) <- base[voff .. ), 4 bytes per lane, all 64 lanes
+__device__ __forceinline__ void as_issue_desc(unsigned lds_dst, const void* base, unsigned voff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(base), "s"(lds_dst) : "memory");
 }
 
 template <int LPR, int R>
 __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
+    static_assert(R % 4 == 0 && R >= 8 && R <= 60, "ring depth: whole descriptor blocks, within the 6-bit VM counter");
     constexpr int SLOT = LPR * 16;                                  // bytes per ring slot = one row
-    __shared__ __attribute__((aligned(16))) char ring_all[AS_WAVES * R * SLOT];
+    constexpr int RB = R / 4;                                       // the consuming side runs RB descriptor blocks behind the issuing side
+    constexpr int WAVE_LDS = R * SLOT + 1024;                       // the gather ring + two 128-entry descriptor rings (sources, weights)
+    // DYNAMIC shared memory on purpose: with a static size hipcc derives an occupancy bound from it (3-4 workgroups per CU) and then pads the kernel's
+    // register allocation up to what that occupancy leaves (amdhsa_next_free_vgpr 129 instead of 32) -- which is exactly what must not happen to a
+    // kernel meant to fit into the 32 registers a persistent GEMM workgroup leaves per SIMD lane
+    extern __shared__ __attribute__((aligned(16))) char ring_all[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // XCD-contiguous segment order: hardware block b runs on XCD b % 8
-    const int nwg = gridDim.x, b = blockIdx.x;
-    const int sidx = ((b % GM_NXCD) * (nwg / GM_NXCD) + b / GM_NXCD) * AS_WAVES + wave;
-    if (sidx >= a.n_seg) return;
-    const int r_begin = as_sload(a.seg, sidx * 8), r_end = as_sload(a.seg, sidx * 8 + 4);
-    if (r_begin >= r_end) return;
-    const bool act = lane < LPR;                                    // narrow rows: the upper lanes only carry parked scalars (no early return: the compiler may
-                                                                    // drop the contents of lanes it believes dead)
-    const int e_lo = as_sload(a.indptr_s, r_begin * 4) & 0x7fffffff, e_hi = as_sload(a.indptr_s, r_end * 4) & 0x7fffffff;
-    char* ring = ring_all + wave * (R * SLOT);
+    const bool act = lane < LPR;                                    // narrow rows: the upper lanes idle (no early return: all control flow stays wave-uniform)
+    char* ring = ring_all + wave * WAVE_LDS;
     const unsigned ring_lds = (unsigned)(uintptr_t)((__attribute__((address_space(3))) char*)ring);
+    const int* su_l = reinterpret_cast<const int*>(ring + R * SLOT);          // sources of edges e: entry e & 127
+    const int* sw_l = su_l + 128;                                             // weights, same indexing
+    const unsigned lane4 = (unsigned)lane * 4u;
     const unsigned lane16 = act ? (unsigned)lane * 16u : 0u;
-
-    // ---- row walk of the consuming side: rc = current row, p1 = its end (flagged), bounds of 16 rows at a time parked in lanes (row & 31) of vp1
-    int vp1 = 0;
-    auto win_load = [&](int r16) {                                  // bounds of rows [r16, r16 + 16) -> lanes (r16 & 31) ... of vp1 (a scalar-cache round
-        as_i4 q0, q1, q2, q3;                                       // trip every 16 rows; not prefetched: 16 more live SGPRs cost more than they hide)
-        as_sload16(a.indptr_s + r16 + 1, q0, q1, q2, q3);
-        as_swait16(q0, q1, q2, q3);
-        const int l0 = r16 & 31;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { as_writelane(vp1, q0[k], l0 + k); as_writelane(vp1, q1[k], l0 + 4 + k); as_writelane(vp1, q2[k], l0 + 8 + k); as_writelane(vp1, q3[k], l0 + 12 + k); }
-    };
-    int rc = r_begin;
-    win_load(rc & ~15);
-    int p1 = __builtin_amdgcn_readlane(vp1, rc & 31);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto row_done = [&]() {                                         // write row rc (unless a hub row), move to the next
-        if (p1 >= 0 && act) {
-            const int64_t orow = a.rowlist ? (int64_t)as_sload(a.rowlist, rc * 4) : (int64_t)rc;
-            float4* dst = reinterpret_cast<float4*>(a.out + orow * a.width + lane * 4);
-            if (a.nt) {
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                const f4v vv = {acc.x, acc.y, acc.z, acc.w};
-                __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
-            } else *dst = acc;
+
+    // ---- row walk of the consuming side (row segments only): rc = current row, p1 = its end bound (flagged); the bounds of 16 rows at a time
+    // are parked in lanes (row & 31) of vp1 (a scalar-cache round trip every 16 rows; not prefetched: 16 more live SGPRs cost more than they hide)
+    int vp1 = 0, rc = 0, p1 = 0, r_end = 0;
+    auto win_load = [&](int r16) {
+        as_i4 q0, q1, q2, q3;
+        as_sload16(a.sptr + r16 + 1, q0, q1, q2, q3);
+        as_swait16(q0, q1, q2, q3);
+        if (r16 & 16) {
+            AS_WRITELANE(vp1, q0[0], 16); AS_WRITELANE(vp1, q0[1], 17); AS_WRITELANE(vp1, q0[2], 18); AS_WRITELANE(vp1, q0[3], 19);
+            AS_WRITELANE(vp1, q1[0], 20); AS_WRITELANE(vp1, q1[1], 21); AS_WRITELANE(vp1, q1[2], 22); AS_WRITELANE(vp1, q1[3], 23);
+            AS_WRITELANE(vp1, q2[0], 24); AS_WRITELANE(vp1, q2[1], 25); AS_WRITELANE(vp1, q2[2], 26); AS_WRITELANE(vp1, q2[3], 27);
+            AS_WRITELANE(vp1, q3[0], 28); AS_WRITELANE(vp1, q3[1], 29); AS_WRITELANE(vp1, q3[2], 30); AS_WRITELANE(vp1, q3[3], 31);
+        } else {
+            AS_WRITELANE(vp1, q0[0], 0); AS_WRITELANE(vp1, q0[1], 1); AS_WRITELANE(vp1, q0[2], 2); AS_WRITELANE(vp1, q0[3], 3);
+            AS_WRITELANE(vp1, q1[0], 4); AS_WRITELANE(vp1, q1[1], 5); AS_WRITELANE(vp1, q1[2], 6); AS_WRITELANE(vp1, q1[3], 7);
+            AS_WRITELANE(vp1, q2[0], 8); AS_WRITELANE(vp1, q2[1], 9); AS_WRITELANE(vp1, q2[2], 10); AS_WRITELANE(vp1, q2[3], 11);
+            AS_WRITELANE(vp1, q3[0], 12); AS_WRITELANE(vp1, q3[1], 13); AS_WRITELANE(vp1, q3[2], 14); AS_WRITELANE(vp1, q3[3], 15);
         }
+    };
+    auto store_row = [&](int64_t orow) {
+        if (!act) return;
+        float4* dst = reinterpret_cast<float4*>(a.out + orow * a.width + lane * 4);
+        if (a.nt) {
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            const f4v vv = {acc.x, acc.y, acc.z, acc.w};
+            __builtin_nontemporal_store(vv, reinterpret_cast<f4v*>(dst));
+        } else *dst = acc;
+    };
+    auto row_done = [&]() {                                         // write row rc (unless a hub row), move to the next
+        if (p1 >= 0) store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + rc) : (int64_t)rc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         ++rc;
         if ((rc & 15) == 0 && rc < r_end) win_load(rc);
         p1 = __builtin_amdgcn_readlane(vp1, rc & 31);
     };
 
-    // ---- the gather pipeline
-    int wring = 0;                                                  // weight of edge e parked in lane e & 63 until it is consumed (R <= 64)
-    int slot = 0;                                                   // ring slot of the edge being issued == of the edge being consumed (e and e - R)
-    auto consume = [&](int ec, bool steady) {
-        while (ec == (p1 & 0x7fffffff)) row_done();                 // rows that end before this edge (empty rows included)
-        if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R - 1) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const float4 v = *reinterpret_cast<const float4*>(ring + slot * SLOT + lane16);
-        const float w = __int_as_float(__builtin_amdgcn_readlane(wring, ec & 63));
-        acc.x = __fmaf_rn(v.x, w, acc.x); acc.y = __fmaf_rn(v.y, w, acc.y); acc.z = __fmaf_rn(v.z, w, acc.z); acc.w = __fmaf_rn(v.w, w, acc.w);
-    };
-    auto step = [&](int e, int u, int w) {
-        if (e - R >= e_lo) consume(e - R, true);                    // frees the slot edge e lands in
-        as_issue<LPR>(wring, w, e & 63, ring_lds + (unsigned)(slot * SLOT), a.x, (unsigned)u * a.row_bytes + lane16);
-        slot = slot + 1 == R ? 0 : slot + 1;
-    };
-    if (e_hi > e_lo) {
-        const int kb0 = e_lo >> 2, kb1 = (e_hi - 1) >> 2;           // descriptor blocks of 4 edges (32 bytes), one block ahead
-        as_i4 d0, d1, n0, n1;
-        as_sload8(a.ed + (int64_t)kb0 * 4, d0, d1);
-        as_swait8(d0, d1);
-        for (int kb = kb0; kb <= kb1; ++kb) {
-            if (kb < kb1) as_sload8(a.ed + (int64_t)(kb + 1) * 4, n0, n1);
+    // ---- the gather pipeline over edges [e_lo, e_hi) of the stream tables; ROWS: rows end inside the run (a row segment), else everything is one sum (a hub part)
+    auto run = [&](const int e_lo, const int e_hi, auto rows_tag) {
+        constexpr bool ROWS = decltype(rows_tag)::value;
+        if (e_hi <= e_lo) return;
+        int slot = 0;                                               // byte offset of the ring slot of step (kb, J): edge e and edge e - R share slot ((e - 4 kb0) % R)
+        auto consume = [&](int ec, float w, bool steady) {
+            if constexpr (ROWS) { while (ec == (p1 & 0x7fffffff)) row_done(); }      // rows that end before this edge (empty rows included)
+            if (steady) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(R - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float4 v = *reinterpret_cast<const float4*>(ring + slot + lane16);
+            acc.x = __fmaf_rn(v.x, w, acc.x); acc.y = __fmaf_rn(v.y, w, acc.y); acc.z = __fmaf_rn(v.z, w, acc.z); acc.w = __fmaf_rn(v.w, w, acc.w);
+        };
+        auto issue = [&](int u) { as_issue<LPR>(ring_lds + (unsigned)slot, a.x, (unsigned)u * a.row_bytes + lane16); };
+        auto next_slot = [&]() { slot = slot + SLOT == R * SLOT ? 0 : slot + SLOT; };
+        // descriptor chunk c (64 edges) -> half (c & 1) of the wave's source / weight rings
+        auto load_su = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + (c & 1) * 256), a.su, (unsigned)c * 256u + lane4); };
+        auto load_sw = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + 512 + (c & 1) * 256), a.sw, (unsigned)c * 256u + lane4); };
+        const int kb0 = e_lo >> 2, kb1 = (e_hi - 1) >> 2;           // blocks of 4 edges; the loop runs RB blocks past the last one to drain the ring
+        const int c0 = e_lo >> 6;
+        load_su(c0); load_su(c0 + 1); load_sw(c0); load_sw(c0 + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int kb = kb0; kb <= kb1 + RB; ++kb) {
             const int e0 = kb * 4;
-#define AS_STEP(J, D, K) if (e0 + J >= e_lo && e0 + J < e_hi) step(e0 + J, D[K], D[K + 1]);
-            AS_STEP(0, d0, 0) AS_STEP(1, d0, 2) AS_STEP(2, d1, 0) AS_STEP(3, d1, 2)
+            // the next chunks, a chunk ahead of their first reader: sources when the issuing side enters a chunk, weights when the consuming side (R edges
+            // behind) does -- each lands in the half its side has just left; >= 64 - R later gathers are waited for before either is read
+            if ((e0 & 63) == 0 && e0 > e_lo) load_su((e0 >> 6) + 1);
+            if ((e0 & 63) == R && e0 - R > e_lo) load_sw(((e0 - R) >> 6) + 1);
+            // four sources / four weights, broadcast reads; moved to SGPRs at once (wave-uniform values: eight VGPRs less across the block's steps --
+            // the kernel has to stay within 32 VGPRs to fit beside a persistent GEMM workgroup)
+            const int4 u4 = *reinterpret_cast<const int4*>(su_l + (e0 & 127));
+            const int4 w4 = *reinterpret_cast<const int4*>(sw_l + ((e0 - R) & 127));
+            const int u0 = __builtin_amdgcn_readfirstlane(u4.x), u1 = __builtin_amdgcn_readfirstlane(u4.y), u2 = __builtin_amdgcn_readfirstlane(u4.z), u3 = __builtin_amdgcn_readfirstlane(u4.w);
+            const float w0 = __int_as_float(__builtin_amdgcn_readfirstlane(w4.x)), w1 = __int_as_float(__builtin_amdgcn_readfirstlane(w4.y));
+            const float w2 = __int_as_float(__builtin_amdgcn_readfirstlane(w4.z)), w3 = __int_as_float(__builtin_amdgcn_readfirstlane(w4.w));
+            if (e0 - R >= e_lo && e0 + 3 < e_hi) {                  // every edge of the issued and of the consumed block is inside the run
+                consume(e0 - R, w0, true); issue(u0); next_slot();
+                consume(e0 + 1 - R, w1, true); issue(u1); next_slot();
+                consume(e0 + 2 - R, w2, true); issue(u2); next_slot();
+                consume(e0 + 3 - R, w3, true); issue(u3); next_slot();
+            } else {
+#define AS_STEP(J, U, W) { const int e = e0 + J;                                                        \
+                     if (e - R >= e_lo && e - R < e_hi) consume(e - R, W, e <= e_hi);                   \
+                     if (e >= e_lo && e < e_hi) issue(U);                                                \
+                     next_slot(); }
+                AS_STEP(0, u0, w0) AS_STEP(1, u1, w1) AS_STEP(2, u2, w2) AS_STEP(3, u3, w3)
 #undef AS_STEP
-            if (kb < kb1) { as_swait8(n0, n1); d0 = n0; d1 = n1; }
+            }
         }
-        // drain: the last min(R, edges) gathers
-        int ec = e_hi - R > e_lo ? e_hi - R : e_lo;
-        slot = (ec - e_lo) % R;
-        for (; ec < e_hi; ++ec) { consume(ec, false); slot = slot + 1 == R ? 0 : slot + 1; }
+    };
+
+    const int b = blockIdx.x;
+    if (a.prio > 0) { if (a.prio == 1) __builtin_amdgcn_s_setprio(1); else if (a.prio == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+    if (a.dbg && threadIdx.x == 0) a.dbg[2 * b] = wall_clock64();
+    struct Stamp { unsigned long long* p; __device__ ~Stamp() { if (p) *p = wall_clock64(); } } stamp_end{(a.dbg && threadIdx.x == 0) ? a.dbg + 2 * b + 1 : nullptr};
+    if (b >= a.hub_wgs) {
+        // ================= row segments (XCD-contiguous order: hardware block b runs on XCD b % 8; hub_wgs is a multiple of 8)
+        const int bn = b - a.hub_wgs, nwg = gridDim.x - a.hub_wgs;
+        const int sidx = ((bn % GM_NXCD) * (nwg / GM_NXCD) + bn / GM_NXCD) * AS_WAVES + wave;
+        if (sidx >= a.n_seg) return;
+        rc = as_sload(&a.seg[sidx].x); r_end = as_sload(&a.seg[sidx].y);
+        if (rc >= r_end) return;
+        const int e_lo = as_sload(a.sptr + rc) & 0x7fffffff, e_hi = as_sload(a.sptr + r_end) & 0x7fffffff;
+        win_load(rc & ~15);
+        p1 = __builtin_amdgcn_readlane(vp1, rc & 31);
+        run(e_lo, e_hi, std::true_type{});
+        while (rc < r_end) row_done();                              // the last row with edges and the empty rows behind it
+        return;
     }
-    while (rc < r_end) row_done();                                  // the last row with edges and the empty rows behind it
+    // ================= hub parts: wave hw of the hub workgroups takes parts hw, hw + HW, ...
+    const int HW = a.hub_wgs * AS_WAVES, hw = b * AS_WAVES + wave;
+    for (int g = hw; g < a.n_parts; g += HW) {
+        int h = g, p = 0, P = 1;
+        if (a.hub) { h = as_sload(a.hub + a.n_heavy + 1 + g); const int o0 = as_sload(a.hub + h); p = g - o0; P = as_sload(a.hub + h + 1) - o0; }
+        const int row = as_sload(a.heavy + h);
+        int eb = a.e_norm + as_sload(a.hcum + h), ee = a.e_norm + as_sload(a.hcum + h + 1);
+        if (P > 1) { eb += p * a.hub_part; if (p < P - 1) ee = eb + a.hub_part; }      // the last part takes the remainder (up to 1.5 parts)
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        run(eb, ee, std::false_type{});
+        if (P == 1) { store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + row) : (int64_t)row); continue; }
+        // partial row -> scratch with write-through (sc1) stores, drained; one relaxed agent-scope ticket; the last arriver does ONE agent-scope acquire
+        // and sums the P partial rows in part order
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        if (act) {
+            float* dst = a.hub_scratch + (int64_t)g * a.hub_ld + lane * 4;
+            const f4v val = {acc.x, acc.y, acc.z, acc.w};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(val) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int* ctr = const_cast<int*>(a.hub) + a.n_heavy + 1 + a.n_parts + h;
+        int last = 0;
+        if (lane == 0) {
+            const int old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == P - 1) {
+                __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                last = 1;
+            }
+        }
+        last = __builtin_amdgcn_readfirstlane(last);
+        if (!last) continue;
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) {
+            const float* sc = a.hub_scratch + (int64_t)(g - p) * a.hub_ld + lane * 4;
+            for (int k = 0; k < P; ++k) { const float4 t = *reinterpret_cast<const float4*>(sc + (int64_t)k * a.hub_ld); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+        }
+        store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + row) : (int64_t)row);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- tables (built with the batch)
-// Row bounds of the stream edge table: the batch's CSR bounds minus the edges of the hub rows before each row (hub rows keep no edges
-// here; bit 31 of a hub row's END bound flags it).  hubs: ascending hub rows, cum[k] = edges of the hub rows before hub k (cum[n] = all).
-__global__ void k_stream_bounds(const int32_t* indptr, int64_t rows, const int32_t* hubs, const int32_t* cum, int n_hubs, int32_t* indptr_s, int pad) {
+// Row bounds of the stream edge tables: the batch's CSR bounds minus the edges of the hub rows before each row (hub rows keep no edges in the
+// row-ordered part; bit 31 of a hub row's END bound flags it).  hubs: ascending hub rows, cum[k] = edges of the hub rows before hub k (cum[n] = all).
+__global__ void k_stream_bounds(const int32_t* indptr, int64_t rows, const int32_t* hubs, const int32_t* cum, int n_hubs, int32_t* sptr, int pad) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;         // entry r (r = rows: the end of the last row)
     if (r > rows + pad) return;
-    if (r > rows) { indptr_s[r] = 0; return; }
+    if (r > rows) { sptr[r] = 0; return; }
     int lo = 0, hi = n_hubs;                                                  // hubs before row r
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (hubs[mid] < r) lo = mid + 1; else hi = mid; }
     const bool prev_is_hub = r > 0 && lo > 0 && hubs[lo - 1] == r - 1;
-    indptr_s[r] = (indptr[r] - cum[lo]) | (prev_is_hub ? (int)0x80000000 : 0);
+    sptr[r] = (indptr[r] - cum[lo]) | (prev_is_hub ? (int)0x80000000 : 0);
 }
-// {source, weight} of every non-hub edge at its stream position; one thread per row
-__global__ void k_stream_edges(const int32_t* indptr, const int32_t* indptr_s, int64_t rows, const int32_t* src, const float* wgt, int2* ed) {
+// sources / weights of every edge at its stream position: one thread per row (a hub row's thread walks up to ~1000 edges to e_norm + cum[hub]:
+// a few hundred such rows, once per batch)
+__global__ void k_stream_edges(const int32_t* indptr, const int32_t* sptr, int64_t rows, const int32_t* hubs, const int32_t* cum, int n_hubs, int e_norm,
+                               const int32_t* src, const int32_t* src2, const float* wgt, int32_t* su, int32_t* su2, float* sw) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    if (indptr_s[r + 1] < 0) return;                                          // hub row
-    const int p0 = indptr[r], n = indptr[r + 1] - p0, o = indptr_s[r] & 0x7fffffff;
-    for (int j = 0; j < n; ++j) ed[o + j] = make_int2(src[p0 + j], __float_as_int(wgt ? wgt[p0 + j] : 1.f));
+    const int p0 = indptr[r], n = indptr[r + 1] - p0;
+    int o = sptr[r] & 0x7fffffff;
+    if (sptr[r + 1] < 0) {                                                    // hub row: its position in the hub list
+        int lo = 0, hi = n_hubs;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (hubs[mid] < r) lo = mid + 1; else hi = mid; }
+        o = e_norm + cum[lo];
+    }
+    for (int j = 0; j < n; ++j) { su[o + j] = src[p0 + j]; if (su2) su2[o + j] = src2[p0 + j]; sw[o + j] = wgt ? wgt[p0 + j] : 1.f; }
 }
 // Wave segments: segment k starts at the first row whose cost prefix (stream edges + rows before it) reaches k / n_seg of the total
-__global__ void k_stream_segs(const int32_t* indptr_s, int64_t rows, int n_seg, int2* seg) {
+__global__ void k_stream_segs(const int32_t* sptr, int64_t rows, int n_seg, int2* seg) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_seg) return;
-    const int64_t total = (int64_t)(indptr_s[rows] & 0x7fffffff) + rows;
+    const int64_t total = (int64_t)(sptr[rows] & 0x7fffffff) + rows;
     auto first_row = [&](int kk) -> int {
         if (kk >= n_seg) return (int)rows;
         const int64_t target = total * kk / n_seg;
         int64_t lo = 0, hi = rows;
-        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)(indptr_s[mid] & 0x7fffffff) + mid < target) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)(sptr[mid] & 0x7fffffff) + mid < target) lo = mid + 1; else hi = mid; }
         return (int)lo;
     };
     seg[k] = make_int2(first_row(k), first_row(k + 1));
@@ -200,55 +292,85 @@ __global__ void k_stream_segs(const int32_t* indptr_s, int64_t rows, int n_seg, 
 
 int gm_stream_wgs() {                                               // workgroups of a stream launch: a multiple of the XCD count
     const int per_cu = gm_knob().agg_stream_wgs > 0 ? gm_knob().agg_stream_wgs : 3;
-    return std::max(GM_NXCD, gm_num_cus() * per_cu / GM_NXCD * GM_NXCD);
+    return std::max(2 * GM_NXCD, gm_num_cus() * per_cu / GM_NXCD * GM_NXCD);
 }
 
 // Stream tables of one orientation (o = 0: by destination; 1: by source).  hubs_host / deg_host: the orientation's ascending hub rows and
-// their degrees (host copies from the finalisation's round trip).  Needs the batch's per-edge tables (d_enorm, d_efeat).
-int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, hipStream_t s, gm_stager* sg) {
+// their degrees (host copies from the finalisation's round trip); n_parts: hub parts of the orientation's part table (the hub count when the
+// rows are not split).  Needs the batch's per-edge tables (d_enorm, d_efeat).
+int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg) {
     if (b->rows <= 0 || b->edges <= 0 || !b->d_enorm[o]) return GM_OK;
     const int32_t* indptr = o ? b->d_indptr_t : b->d_indptr;
     std::vector<int32_t> cum(n_hubs + 1, 0);
     for (int k = 0; k < n_hubs; ++k) cum[k + 1] = cum[k] + deg_host[k];
-    int32_t *d_cum = nullptr, *d_hubs = nullptr;
-    GM_TRY(gm_balloc(b, &d_cum, cum.size(), s)); GM_TRY(sg->upload(d_cum, cum));
+    int32_t* d_hubs = nullptr;
+    GM_TRY(gm_balloc(b, &b->d_scum[o], cum.size(), s)); GM_TRY(sg->upload(b->d_scum[o], cum));
     GM_TRY(gm_balloc(b, &d_hubs, (size_t)std::max(n_hubs, 1), s));
     if (n_hubs > 0) GM_TRY(sg->upload((void*)d_hubs, (const void*)hubs_host, sizeof(int32_t) * (size_t)n_hubs));
     const int pad = 48;                                             // the 16-row bound windows read up to 31 entries past the end
-    GM_TRY(gm_balloc(b, &b->d_sindptr[o], (size_t)b->rows + 1 + pad, s));
-    hipLaunchKernelGGL(k_stream_bounds, dim3((unsigned)((b->rows + 1 + pad + 255) / 256)), dim3(256), 0, s, indptr, (int64_t)b->rows, d_hubs, d_cum, n_hubs, b->d_sindptr[o], pad);
-    const size_t n_ed = (size_t)(b->edges - cum[n_hubs]) + 16;     // (+ the tail of the last 8-edge descriptor block)
-    GM_TRY(gm_balloc(b, &b->d_sed[o], n_ed, s));
-    hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, indptr, b->d_sindptr[o], (int64_t)b->rows,
-                       o ? b->d_indices_t : b->d_indices, b->d_enorm[o], b->d_sed[o]);
-    if (o == 0 && b->d_efeat) {                                     // layer 1 gathers rows of the store's feature table
-        GM_TRY(gm_balloc(b, &b->d_sed_feat, n_ed, s));
-        hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, indptr, b->d_sindptr[o], (int64_t)b->rows, b->d_efeat, b->d_enorm[o], b->d_sed_feat);
+    const int e_norm = (int)(b->edges - cum[n_hubs]);
+    b->stream_enorm[o] = e_norm;
+    GM_TRY(gm_balloc(b, &b->d_sptr[o], (size_t)b->rows + 1 + pad, s));
+    hipLaunchKernelGGL(k_stream_bounds, dim3((unsigned)((b->rows + 1 + pad + 255) / 256)), dim3(256), 0, s, indptr, (int64_t)b->rows, d_hubs, b->d_scum[o], n_hubs, b->d_sptr[o], pad);
+    const size_t n_ed = (size_t)b->edges + 192;                     // (+ the tail of the last 64-edge descriptor chunks)
+    GM_TRY(gm_balloc(b, &b->d_su[o], n_ed, s)); GM_TRY(gm_balloc(b, &b->d_sw[o], n_ed, s));
+    const bool feat = o == 0 && b->d_efeat;                         // layer 1 gathers rows of the store's feature table
+    if (feat) GM_TRY(gm_balloc(b, &b->d_su_feat, n_ed, s));
+    hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, indptr, b->d_sptr[o], (int64_t)b->rows, d_hubs, b->d_scum[o], n_hubs, e_norm,
+                       o ? b->d_indices_t : b->d_indices, feat ? b->d_efeat : nullptr, b->d_enorm[o], b->d_su[o], feat ? b->d_su_feat : nullptr, b->d_sw[o]);
+    // workgroups: the hub parts' share of the launch by their share of its work (in whole XCD rounds), the rest for the row segments
+    const int nwg = gm_stream_wgs();
+    int hub_wgs = 0;
+    if (n_parts > 0) {
+        const double share = (double)cum[n_hubs] / (double)(b->edges + b->rows);
+        hub_wgs = std::max(GM_NXCD, (int)(nwg * share / GM_NXCD + 0.5) * GM_NXCD);
+        hub_wgs = std::min(hub_wgs, std::min(nwg / 2 / GM_NXCD * GM_NXCD, (n_parts + AS_WAVES * GM_NXCD - 1) / (AS_WAVES * GM_NXCD) * GM_NXCD));
     }
-    b->stream_nseg = gm_stream_wgs() * AS_WAVES;
-    GM_TRY(gm_balloc(b, &b->d_sseg[o], (size_t)b->stream_nseg, s));
-    hipLaunchKernelGGL(k_stream_segs, dim3((b->stream_nseg + 255) / 256), dim3(256), 0, s, b->d_sindptr[o], (int64_t)b->rows, b->stream_nseg, b->d_sseg[o]);
+    b->stream_hubwg[o] = hub_wgs; b->stream_nwg[o] = nwg; b->stream_nparts[o] = n_parts;
+    b->stream_nseg[o] = (nwg - hub_wgs) * AS_WAVES;
+    GM_TRY(gm_balloc(b, &b->d_sseg[o], (size_t)b->stream_nseg[o], s));
+    hipLaunchKernelGGL(k_stream_segs, dim3((b->stream_nseg[o] + 255) / 256), dim3(256), 0, s, b->d_sptr[o], (int64_t)b->rows, b->stream_nseg[o], b->d_sseg[o]);
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
 
+static unsigned long long* g_stream_dbg = nullptr; static int g_stream_dbg_n = 0;
+// enable != 0: every later stream launch stamps its workgroups' start / end clocks (2 x uint64 each) into a device buffer of n entries; out != NULL: copy
+// the buffer to the host (after the caller has synchronised)
+extern "C" int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t n) {
+    if (enable && !g_stream_dbg) { GM_HIP(hipMalloc((void**)&g_stream_dbg, sizeof(unsigned long long) * (size_t)n)); g_stream_dbg_n = n; GM_HIP(hipMemset(g_stream_dbg, 0, sizeof(unsigned long long) * (size_t)n)); }
+    if (out && g_stream_dbg) GM_HIP(hipMemcpy(out, g_stream_dbg, sizeof(unsigned long long) * (size_t)std::min(n, g_stream_dbg_n), hipMemcpyDeviceToHost));
+    if (!enable && g_stream_dbg) { (void)hipFree(g_stream_dbg); g_stream_dbg = nullptr; g_stream_dbg_n = 0; }
+    return GM_OK;
+}
+
 template <int LPR, int R>
-static void launch_stream(const AggS& a, hipStream_t s) {
-    hipLaunchKernelGGL((k_agg_stream<LPR, R>), dim3(a.n_seg / AS_WAVES), dim3(AS_WAVES * 64), 0, s, a);
+static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
+    hipLaunchKernelGGL((k_agg_stream<LPR, R>), dim3(nwg), dim3(AS_WAVES * 64), AS_WAVES * (R * LPR * 16 + 1024), s, a);      // (<= 64 KiB: no attribute needed)
 }
 
 // The stream launch of a full aggregate over the batch the tables belong to; false: not eligible (the caller takes the window kernel)
 bool gm_stream_ok(const gm_agg_args& g) {
-    return g.stream_indptr && g.stream_ed && g.stream_seg && !g.s_out && !g.bias && !g.mask_h && !g.mask_b && !g.relu && !g.relu_bits && !g.skip_on && !g.rowlist &&
+    return g.stream && !g.s_out && !g.bias && !g.mask_h && !g.mask_b && !g.relu && !g.relu_bits && !g.skip_on && !g.rowlist &&
            (g.width == 64 || g.width == 128 || g.width == 256) && g.ldx % 4 == 0 && (((uintptr_t)g.x | (uintptr_t)g.out) & 15) == 0 &&
-           (uint64_t)g.stream_xrows * (uint64_t)g.ldx * 4u < ((uint64_t)1 << 32);
+           (uint64_t)g.stream_xrows * (uint64_t)g.ldx * 4u < ((uint64_t)1 << 31) && g.stream_xrows < (1 << 24);
 }
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s) {
-    AggS a{g.stream_indptr, g.stream_ed, g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, nullptr, g.stream_seg, g.stream_nseg};
-    const int depth = gm_knob().agg_stream_depth;
-    if (g.width == 256) { if (depth == 8) launch_stream<64, 8>(a, s); else if (depth == 16) launch_stream<64, 16>(a, s); else launch_stream<64, 12>(a, s); }
-    else if (g.width == 128) { if (depth == 8) launch_stream<32, 16>(a, s); else if (depth == 16) launch_stream<32, 32>(a, s); else launch_stream<32, 24>(a, s); }
-    else { if (depth == 8) launch_stream<16, 32>(a, s); else launch_stream<16, 48>(a, s); }
+    const gm_batch* b = g.stream; const int o = g.stream_o;
+    const bool split = b->d_hub[o] != nullptr;
+    AggS a{b->d_sptr[o], g.stream_feat ? b->d_su_feat : b->d_su[o], b->d_sw[o], g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, nullptr, b->d_sseg[o], b->stream_nseg[o],
+           b->stream_hubwg[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
+           split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], 0, nullptr};
+    { static const int pr = getenv("GM_AGG_STREAM_PRIO") ? atoi(getenv("GM_AGG_STREAM_PRIO")) : 0; a.prio = pr; }
+    if (g_stream_dbg && 2 * b->stream_nwg[o] <= g_stream_dbg_n) a.dbg = g_stream_dbg;
+    static const int dbg = getenv("GM_AGG_STREAM_DEBUG") ? atoi(getenv("GM_AGG_STREAM_DEBUG")) : 0;      // bring-up: 1 = no hub parts, 2 = no row segments
+    if (dbg & 1) a.n_parts = 0;
+    if (dbg & 2) a.n_seg = 0;
+    const int depth = gm_knob().agg_stream_depth, nwg = b->stream_nwg[o];
+    // (ring depths: 8 / 12 KiB of gathers in flight per wave; beyond ~15 KiB per wave the workgroup's LDS would pass 64 KiB -- the reach of M0's 16-bit DMA base)
+    if (g.width == 256) { if (depth == 8) launch_stream<64, 8>(a, nwg, s); else launch_stream<64, 12>(a, nwg, s); }
+    else if (g.width == 128) { if (depth == 8) launch_stream<32, 16>(a, nwg, s); else launch_stream<32, 24>(a, nwg, s); }
+    else { if (depth == 8) launch_stream<16, 32>(a, nwg, s); else launch_stream<16, 48>(a, nwg, s); }
     GM_HIP(hipGetLastError());
     return GM_OK;
 }

@@ -222,6 +222,16 @@ extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t
     return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);
 }
 
+// Timeline probe for tools/: one thread writes the 100 MHz constant clock to *out when the stream reaches this point (stamps of different streams
+// are comparable, HIP event times of different streams are not)
+__global__ void k_debug_stamp(unsigned long long* out) { *out = wall_clock64(); }
+extern "C" int gm_debug_stamp(void* out, void* stream) {
+    GM_REQUIRE(out, GM_EINVAL, "debug_stamp: NULL argument");
+    hipLaunchKernelGGL(k_debug_stamp, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)out);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
 static gm_knobs g_knobs;
 static std::once_flag g_knobs_once;
 const gm_knobs& gm_knob() {

@@ -140,10 +140,12 @@ struct gm_batch {
     // instead of every row of the batch: 8 % of the rows of the arxiv query batch carry work in that launch, and a wave whose 16-row window holds
     // one of them runs its gathers one dependent batch at a time; with the list every wave window is full of rows that have work.
     int32_t* d_mid = nullptr; int32_t n_mid = 0, mid_win = 0;
-    // stream aggregate (agg_stream.hip), per orientation: row bounds in the stream edge table (hub rows hold no edges there; bit 31 of a hub row's
-    // end bound flags it), the interleaved {source row, weight} edge table in row order (d_sed_feat: sources = feature rows of the store, layer 1),
-    // and the cost-balanced row segments of the launch's waves
-    int32_t* d_sindptr[2] = {nullptr, nullptr}; int2* d_sed[2] = {nullptr, nullptr}; int2* d_sed_feat = nullptr; int2* d_sseg[2] = {nullptr, nullptr}; int32_t stream_nseg = 0;
+    // stream aggregate (agg_stream.hip), per orientation: row bounds in the stream edge tables (hub rows hold no edges in the row-ordered part; bit 31 of a
+    // hub row's end bound flags it), the per-edge source / weight tables in row order with the hub rows' edges behind (d_su_feat: sources = feature rows
+    // of the store, layer 1), the prefix of the hub rows' edge counts, the cost-balanced row segments of the launch's waves and its grid split
+    int32_t* d_sptr[2] = {nullptr, nullptr}; int32_t* d_su[2] = {nullptr, nullptr}; int32_t* d_su_feat = nullptr; float* d_sw[2] = {nullptr, nullptr};
+    int32_t* d_scum[2] = {nullptr, nullptr}; int2* d_sseg[2] = {nullptr, nullptr};
+    int32_t stream_nseg[2] = {0, 0}, stream_nwg[2] = {0, 0}, stream_hubwg[2] = {0, 0}, stream_nparts[2] = {0, 0}, stream_enorm[2] = {0, 0};
     int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
@@ -291,14 +293,14 @@ struct gm_agg_args {
     int sched_len, sched_win;
     const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
     const int32_t* rowlist; int64_t n_list; int list_win;      // window kernel only: the wave windows walk rowlist[0 .. n_list) instead of every row (sched / sched_len then index list blocks)
-    // optional stream tables of this launch's batch / orientation (gm_agg_stream_args): eligible launches take the LDS-DMA stream kernel (agg_stream.hip)
-    const int32_t* stream_indptr; const int2* stream_ed; const int2* stream_seg; int stream_nseg; int64_t stream_xrows;
+    // optional: the batch / orientation whose stream tables this launch may use (gm_agg_stream_args): eligible launches take the LDS-DMA stream kernel (agg_stream.hip)
+    const gm_batch* stream; int stream_o; int stream_feat; int64_t stream_xrows;
 };
 // fills the stream fields of `a` for orientation o of batch b (gather: the sources are rows of the store's feature table); a no-op without tables
 void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather);
 bool gm_stream_ok(const gm_agg_args& g);
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s);
-int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, hipStream_t s, gm_stager* sg);
+int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg);
 #define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
 #define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row
 const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)

@@ -613,6 +613,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st, c.hub_set)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
+                if (a.e_w) gm_agg_stream_args(a, b, 0, gather);             // full launches may take the LDS-DMA stream kernel (agg_stream.hip)
                 if (fuse) {
                     // only the rows the fused kernel does not form itself (more than GM_FUSE_MAXDEG sources): a partial launch
                     a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
