@@ -55,7 +55,8 @@ struct AggS {
     const int32_t* rowlist;             // optional: output row of stream row i (list launches)
     const int2* seg; int n_seg;         // row segments [x, y) of the non-hub workgroups' waves
     int hub_wgs;                        // blocks [0, hub_wgs): hub workgroups (a multiple of the XCD count)
-    const int32_t* heavy; const int32_t* hcum; int n_heavy; int e_norm;      // hub rows, prefix of their edge counts; their edges start at su / sw[e_norm + hcum[h]]
+    const int32_t* hsu; const float* hsw;                                    // the tables holding the hub rows' edges (the full launch's own; a list launch borrows the batch's)
+    const int32_t* heavy; const int32_t* hcum; int n_heavy; int e_norm;      // hub rows, prefix of their edge counts; their edges start at hsu / hsw[e_norm + hcum[h]]
     const int32_t* hub; float* hub_scratch; int hub_part, hub_ld, n_parts;   // gm_agg_schedule's part table (NULL: one part per hub row), partial rows
     int prio;                           // s_setprio of the waves (GM_AGG_STREAM_PRIO): beside a GEMM workgroup whose feeder waves run at 2 / 3
     unsigned long long* dbg;            // timeline probe (tools/coreside_probe.py): [2 * blocks] start / end of every workgroup on the device's constant clock
@@ -105,9 +106,24 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
 
     // ---- row walk of the consuming side (row segments only): rc = current row, p1 = its end bound (flagged); the bounds of 16 rows at a time
     // are parked in lanes (row & 31) of vp1 (a scalar-cache round trip every 16 rows; not prefetched: 16 more live SGPRs cost more than they hide)
-    int vp1 = 0, rc = 0, p1 = 0, r_end = 0;
+    int vp1 = 0, vrow = 0, rc = 0, p1 = 0, r_end = 0;
     auto win_load = [&](int r16) {
         as_i4 q0, q1, q2, q3;
+        if (a.rowlist) {                                            // list launches: the output rows of the window's 16 list entries, parked the same way
+            as_sload16(a.rowlist + r16, q0, q1, q2, q3);
+            as_swait16(q0, q1, q2, q3);
+            if (r16 & 16) {
+                AS_WRITELANE(vrow, q0[0], 16); AS_WRITELANE(vrow, q0[1], 17); AS_WRITELANE(vrow, q0[2], 18); AS_WRITELANE(vrow, q0[3], 19);
+                AS_WRITELANE(vrow, q1[0], 20); AS_WRITELANE(vrow, q1[1], 21); AS_WRITELANE(vrow, q1[2], 22); AS_WRITELANE(vrow, q1[3], 23);
+                AS_WRITELANE(vrow, q2[0], 24); AS_WRITELANE(vrow, q2[1], 25); AS_WRITELANE(vrow, q2[2], 26); AS_WRITELANE(vrow, q2[3], 27);
+                AS_WRITELANE(vrow, q3[0], 28); AS_WRITELANE(vrow, q3[1], 29); AS_WRITELANE(vrow, q3[2], 30); AS_WRITELANE(vrow, q3[3], 31);
+            } else {
+                AS_WRITELANE(vrow, q0[0], 0); AS_WRITELANE(vrow, q0[1], 1); AS_WRITELANE(vrow, q0[2], 2); AS_WRITELANE(vrow, q0[3], 3);
+                AS_WRITELANE(vrow, q1[0], 4); AS_WRITELANE(vrow, q1[1], 5); AS_WRITELANE(vrow, q1[2], 6); AS_WRITELANE(vrow, q1[3], 7);
+                AS_WRITELANE(vrow, q2[0], 8); AS_WRITELANE(vrow, q2[1], 9); AS_WRITELANE(vrow, q2[2], 10); AS_WRITELANE(vrow, q2[3], 11);
+                AS_WRITELANE(vrow, q3[0], 12); AS_WRITELANE(vrow, q3[1], 13); AS_WRITELANE(vrow, q3[2], 14); AS_WRITELANE(vrow, q3[3], 15);
+            }
+        }
         as_sload16(a.sptr + r16 + 1, q0, q1, q2, q3);
         as_swait16(q0, q1, q2, q3);
         if (r16 & 16) {
@@ -132,7 +148,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         } else *dst = acc;
     };
     auto row_done = [&]() {                                         // write row rc (unless a hub row), move to the next
-        if (p1 >= 0) store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + rc) : (int64_t)rc);
+        if (p1 >= 0) store_row(a.rowlist ? (int64_t)__builtin_amdgcn_readlane(vrow, rc & 31) : (int64_t)rc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         ++rc;
         if ((rc & 15) == 0 && rc < r_end) win_load(rc);
@@ -140,7 +156,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
     };
 
     // ---- the gather pipeline over edges [e_lo, e_hi) of the stream tables; ROWS: rows end inside the run (a row segment), else everything is one sum (a hub part)
-    auto run = [&](const int e_lo, const int e_hi, auto rows_tag) {
+    auto run = [&](const int32_t* tsu, const float* tsw, const int e_lo, const int e_hi, auto rows_tag) {
         constexpr bool ROWS = decltype(rows_tag)::value;
         if (e_hi <= e_lo) return;
         int slot = 0;                                               // byte offset of the ring slot of step (kb, J): edge e and edge e - R share slot ((e - 4 kb0) % R)
@@ -154,8 +170,8 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         auto issue = [&](int u) { as_issue<LPR>(ring_lds + (unsigned)slot, a.x, (unsigned)u * a.row_bytes + lane16); };
         auto next_slot = [&]() { slot = slot + SLOT == R * SLOT ? 0 : slot + SLOT; };
         // descriptor chunk c (64 edges) -> half (c & 1) of the wave's source / weight rings
-        auto load_su = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + (c & 1) * 256), a.su, (unsigned)c * 256u + lane4); };
-        auto load_sw = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + 512 + (c & 1) * 256), a.sw, (unsigned)c * 256u + lane4); };
+        auto load_su = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + (c & 1) * 256), tsu, (unsigned)c * 256u + lane4); };
+        auto load_sw = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + 512 + (c & 1) * 256), tsw, (unsigned)c * 256u + lane4); };
         const int kb0 = e_lo >> 2, kb1 = (e_hi - 1) >> 2;           // blocks of 4 edges; the loop runs RB blocks past the last one to drain the ring
         const int c0 = e_lo >> 6;
         load_su(c0); load_su(c0 + 1); load_sw(c0); load_sw(c0 + 1);
@@ -203,7 +219,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         const int e_lo = as_sload(a.sptr + rc) & 0x7fffffff, e_hi = as_sload(a.sptr + r_end) & 0x7fffffff;
         win_load(rc & ~15);
         p1 = __builtin_amdgcn_readlane(vp1, rc & 31);
-        run(e_lo, e_hi, std::true_type{});
+        run(a.su, a.sw, e_lo, e_hi, std::true_type{});
         while (rc < r_end) row_done();                              // the last row with edges and the empty rows behind it
         return;
     }
@@ -216,8 +232,8 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         int eb = a.e_norm + as_sload(a.hcum + h), ee = a.e_norm + as_sload(a.hcum + h + 1);
         if (P > 1) { eb += p * a.hub_part; if (p < P - 1) ee = eb + a.hub_part; }      // the last part takes the remainder (up to 1.5 parts)
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        run(eb, ee, std::false_type{});
-        if (P == 1) { store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + row) : (int64_t)row); continue; }
+        run(a.hsu, a.hsw, eb, ee, std::false_type{});
+        if (P == 1) { store_row((int64_t)row); continue; }
         // partial row -> scratch with write-through (sc1) stores, drained; one relaxed agent-scope ticket; the last arriver does ONE agent-scope acquire
         // and sums the P partial rows in part order
         typedef float f4v __attribute__((ext_vector_type(4)));
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
             const float* sc = a.hub_scratch + (int64_t)(g - p) * a.hub_ld + lane * 4;
             for (int k = 0; k < P; ++k) { const float4 t = *reinterpret_cast<const float4*>(sc + (int64_t)k * a.hub_ld); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
         }
-        store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + row) : (int64_t)row);
+        store_row((int64_t)row);
     }
 }
 
@@ -290,6 +306,54 @@ __global__ void k_stream_segs(const int32_t* sptr, int64_t rows, int n_seg, int2
     seg[k] = make_int2(first_row(k), first_row(k + 1));
 }
 
+// ---- list launches (the partial aggregate launch of a fused aggregate + GEMM pass: rows of in-degree 3 .. hub threshold, gm_batch::d_mid): the same
+// tables over the list -- bounds by a block scan of the listed rows' degrees, their edges copied in list order
+#define SL_BLOCK 1024
+__global__ __launch_bounds__(SL_BLOCK) void k_list_blocksum(const int32_t* indptr, const int32_t* list, int n, int32_t* bsum) {
+    __shared__ int ws[SL_BLOCK / 64];
+    const int i = blockIdx.x * SL_BLOCK + threadIdx.x;
+    int d = 0;
+    if (i < n) { const int r = list[i]; d = indptr[r + 1] - indptr[r]; }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < SL_BLOCK / 64; ++k) t += ws[k]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void k_list_scan(int32_t* v, int n) {      // exclusive scan in place, one block
+    __shared__ int part[1024];
+    const int per = (n + 1023) / 1024, a = threadIdx.x * per, b = min(n, a + per);
+    int t = 0;
+    for (int k = a; k < b; ++k) t += v[k];
+    part[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 1024; ++k) { const int x = part[k]; part[k] = run; run += x; } }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int k = a; k < b; ++k) { const int x = v[k]; v[k] = run; run += x; }
+}
+// sptr_m[i] = edges of the listed rows before entry i (entry n: all; pad entries zero); the rows' edges -> the list tables
+__global__ __launch_bounds__(SL_BLOCK) void k_list_tables(const int32_t* indptr, const int32_t* list, int n, const int32_t* boff, int pad, const int32_t* src, const int32_t* src2,
+                                                          const float* wgt, int32_t* sptr_m, int32_t* su, int32_t* su2, float* sw) {
+    __shared__ int ws[SL_BLOCK / 64];
+    const int i = blockIdx.x * SL_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int p0 = 0, d = 0;
+    if (i < n) { const int r = list[i]; p0 = indptr[r]; d = indptr[r + 1] - p0; }
+    int inc = d;                                                              // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    int base = boff[blockIdx.x];
+    for (int k = 0; k < wv; ++k) base += ws[k];
+    const int o0 = base + inc - d;
+    if (i < n) {
+        sptr_m[i] = o0;
+        for (int j = 0; j < d; ++j) { su[o0 + j] = src[p0 + j]; if (su2) su2[o0 + j] = src2[p0 + j]; sw[o0 + j] = wgt[p0 + j]; }
+        if (i == n - 1) { sptr_m[n] = o0 + d; for (int k = 1; k <= pad; ++k) sptr_m[n + k] = 0; }
+    }
+}
+
 int gm_stream_wgs() {                                               // workgroups of a stream launch: a multiple of the XCD count
     const int per_cu = gm_knob().agg_stream_wgs > 0 ? gm_knob().agg_stream_wgs : 3;
     return std::max(2 * GM_NXCD, gm_num_cus() * per_cu / GM_NXCD * GM_NXCD);
@@ -300,6 +364,10 @@ int gm_stream_wgs() {                                               // workgroup
 // rows are not split).  Needs the batch's per-edge tables (d_enorm, d_efeat).
 int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg) {
     if (b->rows <= 0 || b->edges <= 0 || !b->d_enorm[o]) return GM_OK;
+    // Where the stream kernel pays (measured): sparse induced subgraphs (the arxiv shape: ~2 in-edges per row -- a gather per ~0.5 KiB of
+    // output) in batches large enough to fill its pipelines.  Dense batches (Tissue shape, ~24 in-edges per row: 5.6 vs 3.2 ms per meta-step) and small ones
+    // (FirstMM shape) keep the window kernel, whose resident rows share their sources through L2.
+    if (b->edges > 8 * b->rows || b->rows < gm_knob().agg_stream_min_rows) return GM_OK;
     const int32_t* indptr = o ? b->d_indptr_t : b->d_indptr;
     std::vector<int32_t> cum(n_hubs + 1, 0);
     for (int k = 0; k < n_hubs; ++k) cum[k + 1] = cum[k] + deg_host[k];
@@ -344,6 +412,28 @@ extern "C" int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t 
     return GM_OK;
 }
 
+// List tables of the forward orientation (after gm_stream_tables(b, 0, ...)): e_mid = edges of the listed rows (host count from the finalisation's round trip)
+int gm_stream_list_tables(gm_batch* b, int64_t e_mid, hipStream_t s) {
+    if (!b->d_mid || b->n_mid <= 0 || !b->d_sptr[0] || !b->d_enorm[0] || e_mid <= 0) return GM_OK;
+    const int n = b->n_mid, nb = (n + SL_BLOCK - 1) / SL_BLOCK, pad = 48;
+    int32_t* d_bsum = nullptr;
+    GM_TRY(gm_alloc(&d_bsum, (size_t)nb, s));
+    const size_t n_ed = (size_t)e_mid + 192;
+    GM_TRY(gm_balloc(b, &b->d_lptr, (size_t)n + 1 + pad, s));
+    GM_TRY(gm_balloc(b, &b->d_lsu, n_ed, s)); GM_TRY(gm_balloc(b, &b->d_lsw, n_ed, s));
+    if (b->d_efeat) GM_TRY(gm_balloc(b, &b->d_lsu_feat, n_ed, s));
+    hipLaunchKernelGGL(k_list_blocksum, dim3(nb), dim3(SL_BLOCK), 0, s, b->d_indptr, b->d_mid, n, d_bsum);
+    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, s, d_bsum, nb);
+    hipLaunchKernelGGL(k_list_tables, dim3(nb), dim3(SL_BLOCK), 0, s, b->d_indptr, b->d_mid, n, d_bsum, pad, b->d_indices, b->d_efeat, b->d_enorm[0], b->d_lptr, b->d_lsu,
+                       b->d_efeat ? b->d_lsu_feat : nullptr, b->d_lsw);
+    gm_dev_free(d_bsum, s);
+    b->list_nseg = (b->stream_nwg[0] - b->stream_hubwg[0]) * AS_WAVES;
+    GM_TRY(gm_balloc(b, &b->d_lseg, (size_t)b->list_nseg, s));
+    hipLaunchKernelGGL(k_stream_segs, dim3((b->list_nseg + 255) / 256), dim3(256), 0, s, b->d_lptr, (int64_t)n, b->list_nseg, b->d_lseg);
+    GM_HIP(hipGetLastError());
+    return GM_OK;
+}
+
 template <int LPR, int R>
 static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
     hipLaunchKernelGGL((k_agg_stream<LPR, R>), dim3(nwg), dim3(AS_WAVES * 64), AS_WAVES * (R * LPR * 16 + 1024), s, a);      // (<= 64 KiB: no attribute needed)
@@ -351,21 +441,23 @@ static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
 
 // The stream launch of a full aggregate over the batch the tables belong to; false: not eligible (the caller takes the window kernel)
 bool gm_stream_ok(const gm_agg_args& g) {
-    return g.stream && !g.s_out && !g.bias && !g.mask_h && !g.mask_b && !g.relu && !g.relu_bits && !g.skip_on && !g.rowlist &&
+    if (!g.stream || g.s_out || g.bias || g.mask_h || g.mask_b || g.relu || g.relu_bits) return false;
+    if (g.rowlist) { if (!(gm_knob().agg_stream_list && g.stream_list && g.stream->d_lptr && g.stream_o == 0 && g.rowlist == g.stream->d_mid && (!g.stream_feat || g.stream->d_lsu_feat))) return false; }
+    else if (g.skip_on) return false;
+    return
            (g.width == 64 || g.width == 128 || g.width == 256) && g.ldx % 4 == 0 && (((uintptr_t)g.x | (uintptr_t)g.out) & 15) == 0 &&
            (uint64_t)g.stream_xrows * (uint64_t)g.ldx * 4u < ((uint64_t)1 << 31) && g.stream_xrows < (1 << 24);
 }
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s) {
     const gm_batch* b = g.stream; const int o = g.stream_o;
     const bool split = b->d_hub[o] != nullptr;
-    AggS a{b->d_sptr[o], g.stream_feat ? b->d_su_feat : b->d_su[o], b->d_sw[o], g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, nullptr, b->d_sseg[o], b->stream_nseg[o],
-           b->stream_hubwg[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
+    const bool list = g.rowlist != nullptr;                                    // the partial launch of a fused pass: the list's own tables, the batch's hub parts
+    AggS a{list ? b->d_lptr : b->d_sptr[o], list ? (g.stream_feat ? b->d_lsu_feat : b->d_lsu) : (g.stream_feat ? b->d_su_feat : b->d_su[o]), list ? b->d_lsw : b->d_sw[o],
+           g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, list ? b->d_mid : nullptr, list ? b->d_lseg : b->d_sseg[o], list ? b->list_nseg : b->stream_nseg[o],
+           b->stream_hubwg[o], g.stream_feat ? b->d_su_feat : b->d_su[o], b->d_sw[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
            split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], 0, nullptr};
     { static const int pr = getenv("GM_AGG_STREAM_PRIO") ? atoi(getenv("GM_AGG_STREAM_PRIO")) : 0; a.prio = pr; }
     if (g_stream_dbg && 2 * b->stream_nwg[o] <= g_stream_dbg_n) a.dbg = g_stream_dbg;
-    static const int dbg = getenv("GM_AGG_STREAM_DEBUG") ? atoi(getenv("GM_AGG_STREAM_DEBUG")) : 0;      // bring-up: 1 = no hub parts, 2 = no row segments
-    if (dbg & 1) a.n_parts = 0;
-    if (dbg & 2) a.n_seg = 0;
     const int depth = gm_knob().agg_stream_depth, nwg = b->stream_nwg[o];
     // (ring depths: 8 / 12 KiB of gathers in flight per wave; beyond ~15 KiB per wave the workgroup's LDS would pass 64 KiB -- the reach of M0's 16-bit DMA base)
     if (g.width == 256) { if (depth == 8) launch_stream<64, 8>(a, nwg, s); else launch_stream<64, 12>(a, nwg, s); }

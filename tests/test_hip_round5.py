@@ -1,5 +1,8 @@
 """GPU (-m gpu): round-5 cases.
 
+* the LDS-DMA stream aggregate (agg_stream.hip: the kernel of the full forward aggregate launches on large sparse batches) against the oracle and
+  against the window kernel on the arxiv-shape query batch of a 4-task shard (141 k rows, hub rows up to ~900 in-edges), every width / orientation /
+  the layer-1 feature gather; and the whole meta-step with it on and off;
 * the compact-row-list aggregate launch (partial launches of the fused aggregate + GEMM passes) with a PARTIAL last wave window whose
   source lane group is masked off -- the ds_bpermute-after-divergence bug the round-4 advisor found (list windows wider than a lane
   group: width 64 from 32-row windows, width 128 with 64-row windows; the shipped shapes use 2..4-row windows and never hit it)."""
@@ -161,3 +164,90 @@ def test_fused_adam_state_survives_deepcopy_and_a_plain_optimizer_step():
     m.meta_optim.step()                                                 # a plain torch step on the same state (p.grad still holds the last meta-gradient)
     assert all(s == 4.0 for s, _, _ in _adam_state(m))
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, m.net.parameters()))
+
+
+# ---------------------------------------------------------------------------------------------------------------- the stream aggregate
+@pytest.fixture(scope='module')
+def arxiv4():
+    import random
+    import gmeta_amd
+    from gmeta_amd import synth
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=4)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=4, args=args, adjs=store, h=cfg['h'],
+                             tables=data['tables'], verbose=False)
+    batch = db.get_batch([0, 1, 2, 3])
+    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
+    return dict(args=args, cfg=cfg, data=data, store=store, batch=batch, config=config, Q=batch[2][0].view_of)
+
+
+@pytest.mark.parametrize('width,transposed,gather', [(256, 0, 0), (256, 1, 0), (128, 0, 0), (128, 1, 0), (128, 0, 1), (64, 0, 0), (64, 1, 0)])
+def test_stream_aggregate_matches_oracle_and_window_kernel(arxiv4, width, transposed, gather):
+    """out[v] = sum over in-edges (u -> v) of norm[u] x[u] (learner.py:29-32,38-39: the scaled copy_src / sum of an aggregate-first layer) on the 141 k-row
+    query batch: the stream kernel against the oracle's aggregate (1e-5) and against the window kernel -- BITWISE on every row below the hub threshold (same
+    fma chain in edge order), hub rows (summed in parts, another order) to 1e-4 of the row's scale; deterministic run to run."""
+    import gmeta_oracle as orc
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    Q = arxiv4['Q']
+    assert Q.rows >= 32768
+    ptr, idx = (np.asarray(a) for a in Q.csr()[:2])
+    n = Q.rows
+    deg_in = np.diff(ptr)
+    norm = (np.maximum(deg_in, 1).astype(np.float32)) ** np.float32(-0.5)
+    rng = np.random.default_rng(width + transposed)
+    if gather:
+        feats = arxiv4['data']['feats'][0]
+        assert feats.shape[1] == width
+        x = feats[np.asarray(Q.parent(), np.int64)]
+    else:
+        x = rng.standard_normal((n, width)).astype(np.float32)
+    if transposed:
+        order = np.argsort(idx, kind='stable')
+        dst = np.repeat(np.arange(n), deg_in)
+        ptr_o = np.concatenate([[0], np.cumsum(np.bincount(idx, minlength=n))]).astype(ptr.dtype); idx_o = dst[order]
+    else:
+        ptr_o, idx_o = ptr, idx
+    ref = orc.agg(ptr_o, idx_o.astype(np.int64), x * norm[:, None])
+    pn = C.c_void_p(); lib.gm_batch_device_ptr(Q.handle, _lib.F_NORM, C.byref(pn))
+    dx = None if gather else torch.from_numpy(x).cuda()
+    outs = {}
+    for mode in (1, 0, 1):
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', mode), 'set_tuning')
+        o = torch.full((n, width), 3.0, device='cuda')
+        _lib.check(lib.gm_aggregate(Q.handle, transposed, gather, None if gather else _lib.ptr(dx), width, pn, None, _lib.ptr(o), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        if mode == 1 and 1 in outs:
+            assert torch.equal(o, outs[1])                     # deterministic (fixed order of the hub parts)
+        outs[mode] = o
+    _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 1), 'set_tuning')
+    s_new, s_old = outs[1].cpu().numpy(), outs[0].cpu().numpy()
+    np.testing.assert_allclose(s_new, ref, atol=2e-5, rtol=1e-5)
+    deg = np.diff(ptr_o)
+    hubs = deg > 32
+    assert hubs.sum() > 50 and deg.max() > 500
+    assert np.array_equal(s_new[~hubs], s_old[~hubs])
+    scale = np.abs(s_old[hubs]).max(axis=1, keepdims=True) + 1e-6
+    assert float((np.abs(s_new[hubs] - s_old[hubs]) / scale).max()) < 1e-4
+
+
+def test_meta_step_with_and_without_the_stream_aggregate(arxiv4):
+    """The 4-task arxiv shard through Meta.forward with the stream kernel on (default: its query batch qualifies) and off: the same accuracies, losses and
+    meta-gradient to summation order of the hub rows; the tables are really there and really used (launch count of the kernel is not observable here, so the
+    knob is flipped both ways on the SAME batch)."""
+    import gmeta_amd
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    res = {}
+    for mode in (1, 0):
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', mode), 'set_tuning')
+        torch.manual_seed(5)
+        m = gmeta_amd.Meta(arxiv4['args'], arxiv4['config']).to('cuda')
+        accs = m(*arxiv4['batch'], arxiv4['data']['feats'])
+        res[mode] = (np.asarray(accs), np.asarray(m.last_stats['losses_q']), torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).cpu().numpy())
+    _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 1), 'set_tuning')
+    np.testing.assert_allclose(res[1][0], res[0][0], atol=1e-6)
+    np.testing.assert_allclose(res[1][1], res[0][1], atol=1e-5, rtol=0)
+    np.testing.assert_allclose(res[1][2], res[0][2], atol=1e-5, rtol=0)
