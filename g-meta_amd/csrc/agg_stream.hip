@@ -106,24 +106,9 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
 
     // ---- row walk of the consuming side (row segments only): rc = current row, p1 = its end bound (flagged); the bounds of 16 rows at a time
     // are parked in lanes (row & 31) of vp1 (a scalar-cache round trip every 16 rows; not prefetched: 16 more live SGPRs cost more than they hide)
-    int vp1 = 0, vrow = 0, rc = 0, p1 = 0, r_end = 0;
+    int vp1 = 0, rc = 0, p1 = 0, r_end = 0;
     auto win_load = [&](int r16) {
         as_i4 q0, q1, q2, q3;
-        if (a.rowlist) {                                            // list launches: the output rows of the window's 16 list entries, parked the same way
-            as_sload16(a.rowlist + r16, q0, q1, q2, q3);
-            as_swait16(q0, q1, q2, q3);
-            if (r16 & 16) {
-                AS_WRITELANE(vrow, q0[0], 16); AS_WRITELANE(vrow, q0[1], 17); AS_WRITELANE(vrow, q0[2], 18); AS_WRITELANE(vrow, q0[3], 19);
-                AS_WRITELANE(vrow, q1[0], 20); AS_WRITELANE(vrow, q1[1], 21); AS_WRITELANE(vrow, q1[2], 22); AS_WRITELANE(vrow, q1[3], 23);
-                AS_WRITELANE(vrow, q2[0], 24); AS_WRITELANE(vrow, q2[1], 25); AS_WRITELANE(vrow, q2[2], 26); AS_WRITELANE(vrow, q2[3], 27);
-                AS_WRITELANE(vrow, q3[0], 28); AS_WRITELANE(vrow, q3[1], 29); AS_WRITELANE(vrow, q3[2], 30); AS_WRITELANE(vrow, q3[3], 31);
-            } else {
-                AS_WRITELANE(vrow, q0[0], 0); AS_WRITELANE(vrow, q0[1], 1); AS_WRITELANE(vrow, q0[2], 2); AS_WRITELANE(vrow, q0[3], 3);
-                AS_WRITELANE(vrow, q1[0], 4); AS_WRITELANE(vrow, q1[1], 5); AS_WRITELANE(vrow, q1[2], 6); AS_WRITELANE(vrow, q1[3], 7);
-                AS_WRITELANE(vrow, q2[0], 8); AS_WRITELANE(vrow, q2[1], 9); AS_WRITELANE(vrow, q2[2], 10); AS_WRITELANE(vrow, q2[3], 11);
-                AS_WRITELANE(vrow, q3[0], 12); AS_WRITELANE(vrow, q3[1], 13); AS_WRITELANE(vrow, q3[2], 14); AS_WRITELANE(vrow, q3[3], 15);
-            }
-        }
         as_sload16(a.sptr + r16 + 1, q0, q1, q2, q3);
         as_swait16(q0, q1, q2, q3);
         if (r16 & 16) {
@@ -148,7 +133,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         } else *dst = acc;
     };
     auto row_done = [&]() {                                         // write row rc (unless a hub row), move to the next
-        if (p1 >= 0) store_row(a.rowlist ? (int64_t)__builtin_amdgcn_readlane(vrow, rc & 31) : (int64_t)rc);
+        if (p1 >= 0) store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + rc) : (int64_t)rc);      // (list launches: one scalar-cache round trip per row of >= 3 gathers)
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         ++rc;
         if ((rc & 15) == 0 && rc < r_end) win_load(rc);
@@ -258,7 +243,8 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) {
             const float* sc = a.hub_scratch + (int64_t)(g - p) * a.hub_ld + lane * 4;
-            for (int k = 0; k < P; ++k) { const float4 t = *reinterpret_cast<const float4*>(sc + (int64_t)k * a.hub_ld); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }
+#pragma unroll 1
+            for (int k = 0; k < P; ++k) { const float4 t = *reinterpret_cast<const float4*>(sc + (int64_t)k * a.hub_ld); acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w; }      // (one at a time: 32 VGPRs)
         }
         store_row((int64_t)row);
     }

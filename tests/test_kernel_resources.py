@@ -1,0 +1,67 @@
+"""CPU: resource budget of the stream aggregate kernel, read from the KERNEL DESCRIPTORS of the built object (not from the metadata: hipcc pads
+`amdhsa_next_free_vgpr` beyond the registers the code uses when it can derive an occupancy bound, e.g. from a static LDS size -- that is exactly how
+the first version of this kernel ended up with 136 registers per wave and never ran beside anything).
+
+k_agg_stream exists to fit into what a persistent split-GEMM workgroup leaves of a CU (tools/coreside_micro.hip: 16 waves x 120 VGPRs leave 32 registers
+per SIMD lane; a workgroup that needs 35 waits for the GEMM to end): every instantiation must allocate <= 32 VGPRs, and the GEMM must not grow past 120."""
+import os
+import re
+import struct
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = '/opt/rocm/lib/llvm/bin'
+
+
+def _device_elf(obj, tmp):
+    fb, dev = os.path.join(tmp, 'fb.bin'), os.path.join(tmp, 'dev.o')
+    subprocess.run([os.path.join(LLVM, 'llvm-objcopy'), '--dump-section', '.hip_fatbin=' + fb, obj], check=True)
+    subprocess.run([os.path.join(LLVM, 'clang-offload-bundler'), '--unbundle', '--type=o', '--input=' + fb, '--targets=hipv4-amdgcn-amd-amdhsa--gfx950',
+                    '--output=' + dev], check=True, cwd=tmp)
+    return dev
+
+
+def _kernel_vgprs(dev):
+    """{kernel: allocated VGPRs} from compute_pgm_rsrc1 of every <kernel>.kd (granulated count in bits 5:0, granule 8 on gfx950)."""
+    sec = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '-S', '-W', dev], check=True, capture_output=True, text=True).stdout
+    m = re.search(r'\]\s+\.rodata\s+PROGBITS\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)', sec)
+    addr, off, size = (int(x, 16) for x in m.groups())
+    data = open(dev, 'rb').read()
+    out = {}
+    sym = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '-s', '-W', dev], check=True, capture_output=True, text=True).stdout
+    for line in sym.splitlines():
+        f = line.split()
+        if len(f) >= 8 and f[-1].endswith('.kd'):
+            a = int(f[1], 16)
+            assert addr <= a < addr + size
+            rsrc1 = struct.unpack_from('<I', data, off + (a - addr) + 48)[0]
+            out[f[-1][:-3]] = ((rsrc1 & 0x3f) + 1) * 8
+    return out
+
+
+@pytest.fixture(scope='module')
+def objs():
+    build = os.path.join(ROOT, 'g-meta_amd', 'csrc', 'build')
+    if not os.path.exists(os.path.join(build, 'agg_stream.o')):
+        import __graft_entry__
+        __graft_entry__.build()
+    return build
+
+
+def test_stream_aggregate_allocates_at_most_32_vgprs(objs):
+    with tempfile.TemporaryDirectory() as tmp:
+        regs = _kernel_vgprs(_device_elf(os.path.join(objs, 'agg_stream.o'), tmp))
+    stream = {k: v for k, v in regs.items() if 'k_agg_stream' in k}
+    assert len(stream) >= 4
+    assert all(v <= 32 for v in stream.values()), stream
+
+
+def test_persistent_split_gemm_leaves_32_vgprs_per_simd_lane(objs):
+    with tempfile.TemporaryDirectory() as tmp:
+        regs = _kernel_vgprs(_device_elf(os.path.join(objs, 'gemm.o'), tmp))
+    big = {k: v for k, v in regs.items() if 'k_gemm_split_pILb' in k and 'Li2ELi4ELi3E' in k}      # the 128 x 256 three-piece tiles of the large launches
+    assert len(big) == 2
+    assert all(4 * v + 32 <= 512 for v in big.values()), big                                        # 16 waves = 4 per SIMD
