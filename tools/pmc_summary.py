@@ -40,12 +40,12 @@ def main(argv):
             if 'k_agg' in k:
                 for c, v in acc[k].items():
                     tot[c] += v
-                if 'k_agg_win' in k or 'k_agg<' in k:
+                if 'k_agg_win' in k or 'k_agg<' in k or 'k_agg_stream' in k:
                     launches += len(cnt[k].get('FETCH_SIZE', ()))
         fetch_raw = tot['FETCH_SIZE'] * 1024 / launches; write = tot['WRITE_SIZE'] * 1024 / launches
         json.dump({'hbm_bytes_per_launch': int(2 * fetch_raw + write), 'fetch_raw_bytes_per_launch': int(fetch_raw), 'write_bytes_per_launch': int(write),
                    'launches': launches, 'taken': taken,
-                   'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the aggregate kernels (k_agg_win, hub rows included since round 2) of '
+                   'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over the aggregate kernels (k_agg_win and, since round 5, k_agg_stream; hub rows ride in both) of '
                            'bench.py --serialize 1 --steps 1 --warmup 1; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests '
                            'at 64 B; Infinity-Cache hits are included, so this is fabric-side traffic, an upper bound on HBM bytes); KB -> bytes x1024'},
                   sys.stdout, indent=1)
