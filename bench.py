@@ -512,7 +512,18 @@ def main():
     bound_extra = ov_bound
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
+    one_stream_ms = None
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
+        # the same step on ONE stream (no events): what the two queues buy -- kernels of the support chain and of the query evaluations side by side,
+        # the stream aggregate's workgroups inside the CUs a persistent GEMM workgroup of the other queue occupies
+        maml.serialize = 1
+        step(0); drain()
+        torch.cuda.synchronize(); te = time.perf_counter()
+        for k in range(a.roofline_steps):
+            step(k)
+        drain(); torch.cuda.synchronize()
+        one_stream_ms = (time.perf_counter() - te) / a.roofline_steps * 1e3
+        maml.serialize = 0
         lib.gm_profile_enable(1)
         step(0); drain()                                    # one two-stream step with events: the aggregate's rate while it shares the GPU
         ov_ms, ov_n, ov_bytes = prof_read()
@@ -771,7 +782,8 @@ def main():
                        'parallelism': 'tasks sharded over %d rank(s) (rank 0: %d of %d), one all-reduce of the meta-gradient per step' % (world, hi - lo, T),
                        'rows_per_rank': int(rows), 'edges_per_rank': int(edges),
                        'extract_ms_per_meta_batch_rank0': round(float(np.min(ext_ms)), 2), 'last_accs': [round(float(x), 4) for x in accs]},
-            'roofline': {'bound': 'hbm', 'kernel': 'k_agg (batched subgraph message passing, all widths)',
+            'roofline': {'bound': 'hbm', 'kernel': 'k_agg_win + k_agg_stream (batched subgraph message passing, all widths: the full forward launches of large sparse batches '
+                                                     'take the LDS-DMA stream kernel, every other launch the window kernel)',
                          'achieved': round(ach, 1) if ach else None, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': round(ach / HBM_PEAK_GBS, 4) if ach else None, 'traffic': traffic, 'traffic_source': traffic_source,
                          'strict_hbm_achieved': round(strict, 1) if strict else None,
@@ -842,6 +854,12 @@ def main():
                                      'labelled_extra_ms_if_all_flops_ran_at_fp32_mfma_peak': round(t_f32, 2),
                                      'note': 'split launches priced at 6 (bf16, three pieces) or 3 (fp16, two pieces) MFMA flops per fp32 flop on the 2.5 PFLOP/s pipe, exact-fp32 launches at 157.3 TFLOP/s; '
                                              'the last field is the bound an all-exact-fp32 implementation would have (context only)'}
+        if one_stream_ms:
+            out['two_queues'] = {'ms_per_step_two_streams': round(ms_per_step, 3), 'ms_per_step_one_stream': round(one_stream_ms, 3),
+                                 'gain': round(1.0 - ms_per_step / one_stream_ms, 4), 'stream_aggregate': bool(lib.gm_get_tuning(b'GM_AGG_STREAM')),
+                                 'what': 'the same step with the query evaluations on the support chain\'s stream; the difference is what side-by-side execution buys. '
+                                         'A persistent split-GEMM workgroup owns 480 of the 512 VGPRs of each SIMD lane and 101 KiB of LDS: only a kernel of <= 32 VGPRs '
+                                         'and <= 59 KiB starts beside it (profiles/r05_coreside_micro.log) -- the stream aggregate (30 VGPRs, 52 KiB) is built to that budget'}
         if allreduce:
             out['allreduce'] = allreduce
         if rank_report:

@@ -59,6 +59,7 @@ PROTOTYPES = {
     'gm_get_split_pieces': (i32, []),
     'gm_set_split_pieces': (None, [i32]),
     'gm_set_tuning': (C.c_int, [C.c_char_p, i32]),
+    'gm_get_tuning': (i32, [C.c_char_p]),
     'gm_tuning_epoch': (i32, []),
     'gm_set_fuse_agg': (None, [i32]),
     'gm_get_fuse_agg': (i32, []),

@@ -292,8 +292,7 @@ const gm_knobs& gm_knob() {
 static std::atomic<int> g_tuning_epoch{0};
 // counts the changes made through gm_set_tuning: callers that cache sizes derived from the knobs (the host mirror's workspace sizes) key on it
 extern "C" int32_t gm_tuning_epoch(void) { return g_tuning_epoch.load(std::memory_order_relaxed); }
-extern "C" int gm_set_tuning(const char* name, int32_t value) {
-    GM_REQUIRE(name, GM_EINVAL, "set_tuning: NULL name");
+static int gm_knobs::* gm_find_knob(const char* name) {
     (void)gm_knob();
     static const struct { const char* name; int gm_knobs::*field; } tab[] = {
         {"GM_AGG_MIN_WAVES", &gm_knobs::agg_min_waves}, {"GM_AGG_MIN_WIN", &gm_knobs::agg_min_win}, {"GM_AGG_UNR", &gm_knobs::agg_unr}, {"GM_AGG_NT", &gm_knobs::agg_nt},
@@ -304,9 +303,20 @@ extern "C" int gm_set_tuning(const char* name, int32_t value) {
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)
-        if (!strcmp(name, e.name)) { g_knobs.*(e.field) = value; g_tuning_epoch.fetch_add(1, std::memory_order_relaxed); return GM_OK; }
-    gm_set_error("set_tuning: unknown or start-up-only knob %s", name);
-    return GM_EINVAL;
+        if (!strcmp(name, e.name)) return e.field;
+    return nullptr;
+}
+extern "C" int gm_set_tuning(const char* name, int32_t value) {
+    GM_REQUIRE(name, GM_EINVAL, "set_tuning: NULL name");
+    int gm_knobs::* f = gm_find_knob(name);
+    GM_REQUIRE(f, GM_EINVAL, "set_tuning: unknown or start-up-only knob %s", name);
+    g_knobs.*f = value; g_tuning_epoch.fetch_add(1, std::memory_order_relaxed);
+    return GM_OK;
+}
+// current value of a knob gm_set_tuning knows (0 for an unknown name)
+extern "C" int32_t gm_get_tuning(const char* name) {
+    int gm_knobs::* f = name ? gm_find_knob(name) : nullptr;
+    return f ? g_knobs.*f : 0;
 }
 
 int gm_heavy_deg() { return gm_knob().heavy_deg > 0 ? std::max(2, gm_knob().heavy_deg) : 64; }

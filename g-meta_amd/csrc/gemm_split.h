@@ -13,7 +13,7 @@
 // rows are staged into LDS; the (small, per-task) weights are split once per launch by k_split_w into three bf16 planes
 // stored [n][k] (k contiguous), so the B tiles are DMA-ed straight into LDS in MFMA fragment order.
 //
-// Second arithmetic (template parameter NP = 2, what gm_meta_step runs where magnitude bounds are recorded; DESIGN.md section 6c): two fp16
+// Second arithmetic (template parameter NP = 2, what gm_meta_step runs where magnitude bounds are recorded; DESIGN.md section 8): two fp16
 // pieces per operand under per-set power-of-two scales (gm_bound.h, gs_scale_of) and THREE products a_h b_h + a_h b_m + a_m b_h on
 // v_mfma_f32_32x32x16_f16 -- 22 significand bits per operand, measured error vs fp64 below the three-piece kernel's; half the matrix work,
 // two thirds of the LDS / weight-plane traffic.  Same kernel body: plane counts, the split in the feeders and the MFMA type are the only
@@ -100,7 +100,7 @@ __device__ __forceinline__ void gs_split4(const float4 v, uint2& h, uint2& m, ui
 // Two-piece fp16 split (NP == 2): with s a power of two such that |x| s <= 2^15,  x s = h + m + r,  h = fp16(x s) (11 significant bits,
 // round to nearest), m = fp16(x s - h) (the next 11 bits; the subtraction is exact), |r| <= max(2^-23 |x s|, 2^-25): fp16 keeps 2^-24
 // absolute (subnormals), i.e. 2^-39 of the bound.  a b ~= (a_h b_h + a_h b_m + a_m b_h) / (s_a s_b): the dropped terms are bounded by
-// ~2^-21.4 |a||b| -- three fp32 roundings' worth, against the K roundings of an fp32 dot product (DESIGN.md section 4).
+// ~2^-21.4 |a||b| -- three fp32 roundings' worth, against the K roundings of an fp32 dot product (DESIGN.md section 8).
 __device__ __forceinline__ float gs_scale_of(float bound) {
     // largest power of two s with bound * s <= 2^15, clamped to [2^-40, 2^40]; bound = 0 (or not finite) -> 1
     const unsigned e = (__float_as_uint(bound) >> 23) & 0xffu;               // bound < 2^(e - 126)

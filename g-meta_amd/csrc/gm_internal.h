@@ -181,7 +181,7 @@ template <class T> static inline int gm_balloc(gm_batch* b, T** p, size_t n, hip
 // that work instead of relying on the host having synchronised (deferred read-back, prefetch threads).
 void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
 
-// ---- tuning / debug knobs (DESIGN.md section 7): every GM_* environment variable is read ONCE, under std::call_once, into this
+// ---- tuning / debug knobs (DESIGN.md section 9): every GM_* environment variable is read ONCE, under std::call_once, into this
 // struct (the prefetch thread and the training thread both enter the library); per-device quantities are derived at the call site.
 struct gm_knobs {
     int agg_min_waves, agg_min_win, agg_sched, agg_hub_part, agg_unr, agg_nt, agg_variant, agg_edge_tables, heavy_deg;

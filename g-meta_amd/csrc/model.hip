@@ -415,7 +415,7 @@ struct PlaneDir {
     // Weight bound for the two-piece fp16 planes (gm_bound.h): wam[l * GM_BOUND_PAD] = bit pattern of max |W_l| of THETA, taken once per
     // meta-step; every weight vector of the step (theta and the fast weights fw_1..fw_K of every task) is split under GM_W_HEADROOM x that
     // bound -- the planes of fw_k are written by the reduction that produces fw_k, before its own maximum could be known.  A weight that
-    // outgrows theta's largest by that factor inside one inner loop turns into inf / NaN losses, which the caller sees (DESIGN.md section 4).
+    // outgrows theta's largest by that factor inside one inner loop turns into inf / NaN losses, which the caller sees (DESIGN.md section 8).
     unsigned* wam = nullptr; const float* theta = nullptr;
     unsigned* viol = nullptr;                                               // the step's violation word (gm_bound.h)
     bool w_bound(const float* params, int l, gm_bound& bd) const {

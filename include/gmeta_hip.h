@@ -226,9 +226,10 @@ void gm_set_gemm_mode(int32_t mode);
 int32_t gm_get_gemm_mode(void);
 void gm_set_split_pieces(int32_t pieces);   /* 2, 3, or -1 = back to the environment variable (default 3) */
 int32_t gm_get_split_pieces(void);
-/* Tuning knob by the name of its environment variable (DESIGN.md section 7), after start-up; GM_EINVAL for unknown names.  Tests use it to
+/* Tuning knob by the name of its environment variable (DESIGN.md section 9), after start-up; GM_EINVAL for unknown names.  Tests use it to
  * force the large-launch kernels onto small fixtures (GM_GEMM_SPLIT_MIN_TILES, GM_SPLIT16_MIN_ROWS); not synchronised with concurrent calls. */
 int gm_set_tuning(const char* name, int32_t value);
+int32_t gm_get_tuning(const char* name);      /* current value of such a knob (0 for an unknown name) */
 int32_t gm_tuning_epoch(void);   /* number of gm_set_tuning changes so far (cache key for sizes that depend on the knobs) */
 
 /* Fused aggregate + update for forward passes nobody differentiates (the query evaluations of the inner steps in gm_meta_step,
