@@ -52,7 +52,7 @@ struct AggS {
     const int32_t* su; const float* sw; // stream edge tables: source row of x / weight per edge -- the rows' edges in row order, then the hub rows' edges in hub order
     const float* x; unsigned row_bytes; // gathered matrix, bytes per row (ldx * 4; rows * row_bytes < 2 GiB)
     float* out; int width; int nt;      // [rows, width]
-    const int32_t* rowlist;             // optional: output row of stream row i (list launches)
+    const int32_t* rowlist;             // optional: output row of stream row i (tables over a compact row list; not used by the shipped dispatch)
     const int2* seg; int n_seg;         // row segments [x, y) of the non-hub workgroups' waves
     int hub_wgs;                        // blocks [0, hub_wgs): hub workgroups (a multiple of the XCD count)
     const int32_t* hsu; const float* hsw;                                    // the tables holding the hub rows' edges (the full launch's own; a list launch borrows the batch's)
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         } else *dst = acc;
     };
     auto row_done = [&]() {                                         // write row rc (unless a hub row), move to the next
-        if (p1 >= 0) store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + rc) : (int64_t)rc);      // (list launches: one scalar-cache round trip per row of >= 3 gathers)
+        if (p1 >= 0) store_row(a.rowlist ? (int64_t)as_sload(a.rowlist + rc) : (int64_t)rc);
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         ++rc;
         if ((rc & 15) == 0 && rc < r_end) win_load(rc);
@@ -291,57 +291,16 @@ __global__ void k_stream_segs(const int32_t* sptr, int64_t rows, int n_seg, int2
     seg[k] = make_int2(first_row(k), first_row(k + 1));
 }
 
-// ---- list launches (the partial aggregate launch of a fused aggregate + GEMM pass: rows of in-degree 3 .. hub threshold, gm_batch::d_mid): the same
-// tables over the list -- bounds by a block scan of the listed rows' degrees, their edges copied in list order
-#define SL_BLOCK 1024
-__global__ __launch_bounds__(SL_BLOCK) void k_list_blocksum(const int32_t* indptr, const int32_t* list, int n, int32_t* bsum) {
-    __shared__ int ws[SL_BLOCK / 64];
-    const int i = blockIdx.x * SL_BLOCK + threadIdx.x;
-    int d = 0;
-    if (i < n) { const int r = list[i]; d = indptr[r + 1] - indptr[r]; }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) d += __shfl_xor(d, o);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = d;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < SL_BLOCK / 64; ++k) t += ws[k]; bsum[blockIdx.x] = t; }
-}
-__global__ __launch_bounds__(1024) void k_list_scan(int32_t* v, int n) {      // exclusive scan in place, one block
-    __shared__ int part[1024];
-    const int per = (n + 1023) / 1024, a = threadIdx.x * per, b = min(n, a + per);
-    int t = 0;
-    for (int k = a; k < b; ++k) t += v[k];
-    part[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int k = 0; k < 1024; ++k) { const int x = part[k]; part[k] = run; run += x; } }
-    __syncthreads();
-    int run = part[threadIdx.x];
-    for (int k = a; k < b; ++k) { const int x = v[k]; v[k] = run; run += x; }
-}
-// sptr_m[i] = edges of the listed rows before entry i (entry n: all; pad entries zero); the rows' edges -> the list tables
-__global__ __launch_bounds__(SL_BLOCK) void k_list_tables(const int32_t* indptr, const int32_t* list, int n, const int32_t* boff, int pad, const int32_t* src, const int32_t* src2,
-                                                          const float* wgt, int32_t* sptr_m, int32_t* su, int32_t* su2, float* sw) {
-    __shared__ int ws[SL_BLOCK / 64];
-    const int i = blockIdx.x * SL_BLOCK + threadIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int p0 = 0, d = 0;
-    if (i < n) { const int r = list[i]; p0 = indptr[r]; d = indptr[r + 1] - p0; }
-    int inc = d;                                                              // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) ws[wv] = inc;
-    __syncthreads();
-    int base = boff[blockIdx.x];
-    for (int k = 0; k < wv; ++k) base += ws[k];
-    const int o0 = base + inc - d;
-    if (i < n) {
-        sptr_m[i] = o0;
-        for (int j = 0; j < d; ++j) { su[o0 + j] = src[p0 + j]; if (su2) su2[o0 + j] = src2[p0 + j]; sw[o0 + j] = wgt[p0 + j]; }
-        if (i == n - 1) { sptr_m[n] = o0 + d; for (int k = 1; k <= pad; ++k) sptr_m[n + k] = 0; }
-    }
-}
-
-int gm_stream_wgs() {                                               // workgroups of a stream launch: a multiple of the XCD count
-    const int per_cu = gm_knob().agg_stream_wgs > 0 ? gm_knob().agg_stream_wgs : 3;
-    return std::max(2 * GM_NXCD, gm_num_cus() * per_cu / GM_NXCD * GM_NXCD);
+// Workgroups of a stream launch over a table of `cost` (edges + rows): a multiple of the XCD count.  Waves get SHORT runs (~GM_AGG_STREAM_COST cost units each, about
+// 30 rows and their edges): the workgroups resident on an XCD at one time then sweep a few dozen consecutive subgraphs, and the second gather of a source row -- by
+// another row of its subgraph -- still finds it in that XCD's L2 (1.14 M-row launch at width 256: 534 us with 768 long-lived workgroups, 437 us with 6,144;
+// window kernel 494-518).  Too short and a wave's start-up (descriptor chunk + first round trip) dominates (142 k-row launch: best at ~1,500 workgroups).
+int gm_stream_wgs(int64_t cost) {
+    const int per_cu = gm_knob().agg_stream_wgs;
+    if (per_cu > 0) return std::max(2 * GM_NXCD, gm_num_cus() * per_cu / GM_NXCD * GM_NXCD);
+    const int64_t per_wave = std::max(16, gm_knob().agg_stream_cost);
+    const int64_t wgs = (cost / per_wave + AS_WAVES - 1) / AS_WAVES;
+    return (int)std::min<int64_t>(65536, std::max<int64_t>(gm_num_cus() * 3 / GM_NXCD * GM_NXCD, (wgs + GM_NXCD - 1) / GM_NXCD * GM_NXCD));
 }
 
 // Stream tables of one orientation (o = 0: by destination; 1: by source).  hubs_host / deg_host: the orientation's ascending hub rows and
@@ -375,7 +334,7 @@ int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t
         hipLaunchKernelGGL(k_stream_hub_edges, dim3(n_hubs), dim3(64), 0, s, indptr, d_hubs, b->d_scum[o], e_norm, o ? b->d_indices_t : b->d_indices, feat ? b->d_efeat : nullptr,
                            b->d_enorm[o], b->d_su[o], feat ? b->d_su_feat : nullptr, b->d_sw[o]);
     // workgroups: the hub parts' share of the launch by their share of its work (in whole XCD rounds), the rest for the row segments
-    const int nwg = gm_stream_wgs();
+    const int nwg = gm_stream_wgs(b->edges + b->rows);
     int hub_wgs = 0;
     if (n_parts > 0) {
         const double share = (double)cum[n_hubs] / (double)(b->edges + b->rows);
@@ -400,28 +359,6 @@ extern "C" int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t 
     return GM_OK;
 }
 
-// List tables of the forward orientation (after gm_stream_tables(b, 0, ...)): e_mid = edges of the listed rows (host count from the finalisation's round trip)
-int gm_stream_list_tables(gm_batch* b, int64_t e_mid, hipStream_t s) {
-    if (!b->d_mid || b->n_mid <= 0 || !b->d_sptr[0] || !b->d_enorm[0] || e_mid <= 0) return GM_OK;
-    const int n = b->n_mid, nb = (n + SL_BLOCK - 1) / SL_BLOCK, pad = 48;
-    int32_t* d_bsum = nullptr;
-    GM_TRY(gm_alloc(&d_bsum, (size_t)nb, s));
-    const size_t n_ed = (size_t)e_mid + 192;
-    GM_TRY(gm_balloc(b, &b->d_lptr, (size_t)n + 1 + pad, s));
-    GM_TRY(gm_balloc(b, &b->d_lsu, n_ed, s)); GM_TRY(gm_balloc(b, &b->d_lsw, n_ed, s));
-    if (b->d_efeat) GM_TRY(gm_balloc(b, &b->d_lsu_feat, n_ed, s));
-    hipLaunchKernelGGL(k_list_blocksum, dim3(nb), dim3(SL_BLOCK), 0, s, b->d_indptr, b->d_mid, n, d_bsum);
-    hipLaunchKernelGGL(k_list_scan, dim3(1), dim3(1024), 0, s, d_bsum, nb);
-    hipLaunchKernelGGL(k_list_tables, dim3(nb), dim3(SL_BLOCK), 0, s, b->d_indptr, b->d_mid, n, d_bsum, pad, b->d_indices, b->d_efeat, b->d_enorm[0], b->d_lptr, b->d_lsu,
-                       b->d_efeat ? b->d_lsu_feat : nullptr, b->d_lsw);
-    gm_dev_free(d_bsum, s);
-    b->list_nseg = (b->stream_nwg[0] - b->stream_hubwg[0]) * AS_WAVES;
-    GM_TRY(gm_balloc(b, &b->d_lseg, (size_t)b->list_nseg, s));
-    hipLaunchKernelGGL(k_stream_segs, dim3((b->list_nseg + 255) / 256), dim3(256), 0, s, b->d_lptr, (int64_t)n, b->list_nseg, b->d_lseg);
-    GM_HIP(hipGetLastError());
-    return GM_OK;
-}
-
 template <int LPR, int R>
 static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
     hipLaunchKernelGGL((k_agg_stream<LPR, R>), dim3(nwg), dim3(AS_WAVES * 64), AS_WAVES * (R * LPR * 16 + 1024), s, a);      // (<= 64 KiB: no attribute needed)
@@ -430,8 +367,8 @@ static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
 // The stream launch of a full aggregate over the batch the tables belong to; false: not eligible (the caller takes the window kernel)
 bool gm_stream_ok(const gm_agg_args& g) {
     if (!g.stream || g.s_out || g.bias || g.mask_h || g.mask_b || g.relu || g.relu_bits) return false;
-    if (g.rowlist) { if (!(gm_knob().agg_stream_list && g.stream_list && g.stream->d_lptr && g.stream_o == 0 && g.rowlist == g.stream->d_mid && (!g.stream_feat || g.stream->d_lsu_feat))) return false; }
-    else if (g.skip_on) return false;
+    if (g.stream_feat && !gm_knob().agg_stream_gather) return false;
+    if (g.rowlist || g.skip_on) return false;                                  // partial launches stay on the window kernel (measured: profiles/r05_experiments_not_shipped.txt C.1)
     return
            (g.width == 64 || g.width == 128 || g.width == 256) && g.ldx % 4 == 0 && (((uintptr_t)g.x | (uintptr_t)g.out) & 15) == 0 &&
            (uint64_t)g.stream_xrows * (uint64_t)g.ldx * 4u < ((uint64_t)1 << 31) && g.stream_xrows < (1 << 24);
@@ -439,10 +376,9 @@ bool gm_stream_ok(const gm_agg_args& g) {
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s) {
     const gm_batch* b = g.stream; const int o = g.stream_o;
     const bool split = b->d_hub[o] != nullptr;
-    const bool list = g.rowlist != nullptr;                                    // the partial launch of a fused pass: the list's own tables, the batch's hub parts
-    AggS a{list ? b->d_lptr : b->d_sptr[o], list ? (g.stream_feat ? b->d_lsu_feat : b->d_lsu) : (g.stream_feat ? b->d_su_feat : b->d_su[o]), list ? b->d_lsw : b->d_sw[o],
-           g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, list ? b->d_mid : nullptr, list ? b->d_lseg : b->d_sseg[o], list ? b->list_nseg : b->stream_nseg[o],
-           b->stream_hubwg[o], g.stream_feat ? b->d_su_feat : b->d_su[o], b->d_sw[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
+    const int32_t* su = g.stream_feat ? b->d_su_feat : b->d_su[o];
+    AggS a{b->d_sptr[o], su, b->d_sw[o], g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, nullptr, b->d_sseg[o], b->stream_nseg[o],
+           b->stream_hubwg[o], su, b->d_sw[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
            split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], 0, nullptr};
     { static const int pr = getenv("GM_AGG_STREAM_PRIO") ? atoi(getenv("GM_AGG_STREAM_PRIO")) : 0; a.prio = pr; }
     if (g_stream_dbg && 2 * b->stream_nwg[o] <= g_stream_dbg_n) a.dbg = g_stream_dbg;

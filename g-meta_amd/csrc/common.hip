@@ -279,9 +279,10 @@ const gm_knobs& gm_knob() {
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
         k.wgrad_split_min_chunks = env("GM_WGRAD_SPLIT_MIN_CHUNKS", -1);
         k.agg_stream = env("GM_AGG_STREAM", 1);
-        k.agg_stream_list = env("GM_AGG_STREAM_LIST", 0);
         k.agg_stream_min_rows = env("GM_AGG_STREAM_MIN_ROWS", 32768);
         k.agg_stream_wgs = env("GM_AGG_STREAM_WGS", 0);
+        k.agg_stream_cost = env("GM_AGG_STREAM_COST", 96);
+        k.agg_stream_gather = env("GM_AGG_STREAM_GATHER", 1);
         k.agg_stream_depth = env("GM_AGG_STREAM_DEPTH", 12);
     });
     return k;
@@ -299,7 +300,7 @@ static int gm_knobs::* gm_find_knob(const char* name) {
         {"GM_AGG_VARIANT", &gm_knobs::agg_variant}, {"GM_GEMM_SPLIT_MIN_TILES", &gm_knobs::gemm_split_min_tiles}, {"GM_GEMM_SPLIT_GRID", &gm_knobs::gemm_split_grid},
         {"GM_GEMM_FUSED_ROUNDS", &gm_knobs::gemm_fused_rounds}, {"GM_GEMM_PLAIN_ROUNDS", &gm_knobs::gemm_plain_rounds}, {"GM_CENTRE_STORE", &gm_knobs::centre_store}, {"GM_GEMM_HALF_TILES", &gm_knobs::gemm_half_tiles},
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
-        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list}, {"GM_AGG_MID_WIN", &gm_knobs::agg_mid_win}, {"GM_AGG_STREAM", &gm_knobs::agg_stream}, {"GM_AGG_STREAM_DEPTH", &gm_knobs::agg_stream_depth}, {"GM_AGG_STREAM_LIST", &gm_knobs::agg_stream_list}, {"GM_AGG_STREAM_MIN_ROWS", &gm_knobs::agg_stream_min_rows},
+        {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list}, {"GM_AGG_MID_WIN", &gm_knobs::agg_mid_win}, {"GM_AGG_STREAM", &gm_knobs::agg_stream}, {"GM_AGG_STREAM_DEPTH", &gm_knobs::agg_stream_depth}, {"GM_AGG_STREAM_MIN_ROWS", &gm_knobs::agg_stream_min_rows},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
     };
     for (const auto& e : tab)

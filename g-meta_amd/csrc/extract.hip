@@ -806,7 +806,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
             const int nb = (int)((b->rows + MID_BLOCK - 1) / MID_BLOCK);
             int32_t* d_bcnt = nullptr;
             GM_TRY(gm_alloc(&d_bcnt, (size_t)nb, s));
-            GM_TRY(gm_balloc(b, &b->d_mid, (size_t)n_mid + 32, s));      // (+ the tail of the stream kernel's last 16-entry window)
+            GM_TRY(gm_balloc(b, &b->d_mid, (size_t)n_mid, s));
             hipLaunchKernelGGL(k_mid_count, dim3(nb), dim3(MID_BLOCK), 0, s, b->d_indptr, (int64_t)b->rows, GM_FUSE_MAXDEG + 1, b->heavy_deg, d_bcnt);
             hipLaunchKernelGGL(k_mid_scan, dim3(1), dim3(1024), 0, s, d_bcnt, nb);
             hipLaunchKernelGGL(k_mid_scatter, dim3(nb), dim3(MID_BLOCK), 0, s, b->d_indptr, (int64_t)b->rows, GM_FUSE_MAXDEG + 1, b->heavy_deg, d_bcnt, b->d_mid, (int)n_mid);
@@ -823,11 +823,6 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
                 std::vector<int32_t> pos(heavy0.size());
                 for (size_t k = 0; k < heavy0.size(); ++k) pos[k] = (int32_t)std::min<int64_t>(n_mid - 1, (int64_t)heavy0[k] * n_mid / b->rows);
                 GM_TRY(gm_agg_schedule_flat(b, n_mid, win, pos.data(), (int)heavy0.size(), tab0, &b->d_sched_mid, &b->sched_len_mid, s, &sg));
-            }
-            if (gm_knob().agg_stream && gm_knob().agg_stream_list) {      // the list's own stream tables (edges of the listed rows = the unfused edges minus the hub rows')
-                int64_t hub_e = 0;
-                for (int k = 0; k < b->n_heavy[0] && k < first; ++k) hub_e += h_hdeg[0][k];
-                if (b->n_heavy[0] <= first) GM_TRY(gm_stream_list_tables(b, b->unfused_edges - hub_e, s));
             }
         }
     }

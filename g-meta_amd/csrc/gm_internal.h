@@ -146,8 +146,6 @@ struct gm_batch {
     int32_t* d_sptr[2] = {nullptr, nullptr}; int32_t* d_su[2] = {nullptr, nullptr}; int32_t* d_su_feat = nullptr; float* d_sw[2] = {nullptr, nullptr};
     int32_t* d_scum[2] = {nullptr, nullptr}; int2* d_sseg[2] = {nullptr, nullptr};
     int32_t stream_nseg[2] = {0, 0}, stream_nwg[2] = {0, 0}, stream_hubwg[2] = {0, 0}, stream_nparts[2] = {0, 0}, stream_enorm[2] = {0, 0};
-    // ... and over the compact row list d_mid (the partial launch of a fused pass, forward orientation): bounds, edge tables in list order, segments
-    int32_t* d_lptr = nullptr; int32_t* d_lsu = nullptr; int32_t* d_lsu_feat = nullptr; float* d_lsw = nullptr; int2* d_lseg = nullptr; int32_t list_nseg = 0;
     int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
@@ -202,10 +200,11 @@ struct gm_knobs {
     int wgrad_split_min_chunks;    // GM_WGRAD_SPLIT_MIN_CHUNKS: smallest launch (row chunks) that takes the split weight-gradient kernel; -1: a quarter of the CUs
     int cu_mask_support;           // CUs per XCD reserved for the support chain's stream (0: no CU masks)
     int agg_stream;                // GM_AGG_STREAM: eligible full aggregate launches take the LDS-DMA stream kernel (agg_stream.hip)
-    int agg_stream_wgs;            // GM_AGG_STREAM_WGS: its workgroups per CU (0 = 3)
+    int agg_stream_wgs;            // GM_AGG_STREAM_WGS: its workgroups per CU (0 = by the batch's size: agg_stream_cost)
+    int agg_stream_cost;           // GM_AGG_STREAM_COST: edges + rows per wave of a stream launch
+    int agg_stream_gather;         // GM_AGG_STREAM_GATHER: the layer-1 launches (sources = rows of the store's feature table) take the stream kernel too
     int agg_stream_depth;          // GM_AGG_STREAM_DEPTH: KiB of gathers in flight per wave (8 / 12)
     int agg_stream_min_rows;       // GM_AGG_STREAM_MIN_ROWS: smallest batch (rows) that builds stream tables; dense batches (more than 8 edges per row) never do
-    int agg_stream_list;           // GM_AGG_STREAM_LIST: the partial (row-list) launches of the fused passes also take the stream kernel (measured slower: off)
 };
 const gm_knobs& gm_knob();
 
@@ -298,13 +297,12 @@ struct gm_agg_args {
     const int32_t* hub; float* hub_scratch; int hub_part;     // with sched: hub rows split over several blocks (gm_agg_sched)
     const int32_t* rowlist; int64_t n_list; int list_win;      // window kernel only: the wave windows walk rowlist[0 .. n_list) instead of every row (sched / sched_len then index list blocks)
     // optional: the batch / orientation whose stream tables this launch may use (gm_agg_stream_args): eligible launches take the LDS-DMA stream kernel (agg_stream.hip)
-    const gm_batch* stream; int stream_o; int stream_feat; int64_t stream_xrows; int stream_list;      // stream_list: a row-list launch may use the list tables
+    const gm_batch* stream; int stream_o; int stream_feat; int64_t stream_xrows;
 };
 // fills the stream fields of `a` for orientation o of batch b (gather: the sources are rows of the store's feature table); a no-op without tables
 void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather);
 bool gm_stream_ok(const gm_agg_args& g);
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s);
-int gm_stream_list_tables(gm_batch* b, int64_t e_mid, hipStream_t s);
 int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg);
 #define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
 #define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row

@@ -619,7 +619,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                     a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
                     if (b->d_mid && c.hub_set == 0 && gm_knob().agg_mid_list && (b->n_heavy[0] == 0 || b->d_sched_mid)) {
                         // ... walking the compact list of those rows (hub rows keep their blocks; the schedule is the list's)
-                        a.rowlist = b->d_mid; a.n_list = b->n_mid; a.list_win = b->mid_win; a.stream_list = 1;
+                        a.rowlist = b->d_mid; a.n_list = b->n_mid; a.list_win = b->mid_win;
                         if (b->n_heavy[0] > 0) { a.sched = b->d_sched_mid; a.sched_len = b->sched_len_mid; a.sched_win = b->mid_win; }
                         else { a.sched = nullptr; a.sched_len = 0; }
                     }
