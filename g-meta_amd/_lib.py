@@ -69,6 +69,7 @@ PROTOTYPES = {
     'gm_profile_read_launches': (C.c_int, [i32, vp, vp, i32]),
     'gm_debug_stamp': (C.c_int, [vp, vp]),
     'gm_stream_debug': (C.c_int, [i32, vp, i32]),
+    'gm_head_loss_debug': (C.c_int, [i32, vp]),
 }
 
 _lib = None

@@ -6,8 +6,9 @@
 // while it runs, no aggregate wave fits beside it, the two queues of a meta-step time-slice the chip and the HBM-bound aggregate never
 // overlaps the matrix-bound update.  Here a wave keeps its gathers in flight in LDS instead of in registers:
 //   * every gathered source row is ONE `global_load_lds_dwordx4` (1 KiB per instruction at width 256) into a wave-private ring of R
-//     slots; the wave's in-order VM counter is the ring's only synchronisation (`s_waitcnt vmcnt(R - 1)` before slot i is read,
-//     R - 1 younger gathers stay in flight): no destination registers, no barrier, R KiB in flight per wave;
+//     slots; the wave's in-order VM counter orders a read behind its gather (`s_waitcnt vmcnt(R - 1)` before slot i is read: the R - 1
+//     younger gathers stay in flight) and an lgkmcnt(0) orders the gather that refills the slot behind that read (as_issue): no
+//     destination registers, no barrier, R KiB in flight per wave;
 //   * edge descriptors ride the same queue: the per-edge tables (sources for the issuing side, weights -- R edges behind -- for the consuming
 //     side, laid out in row order) arrive 64 edges at a time by `global_load_lds_dword` into two small per-wave rings, a chunk ahead of
 //     their use, and are read back four at a time with broadcast ds_read_b128 -- they never sit in asm-loaded registers the compiler could
@@ -17,9 +18,9 @@
 //     accumulates a row in edge order with the same fma chain as k_agg_win (bitwise the same rows) and writes it once;
 //   * hub rows (in-degree above the batch's hub threshold, up to ~1000 edges) hold no edges in the row-ordered part of the tables (their
 //     row bound carries a flag); their edges follow behind it and are streamed in parts of ~128 edges by the launch's FIRST workgroups, one
-//     wave per part: partial rows through write-through stores, an arrival ticket, and the last arriver sums the parts in part order
-//     (deterministic) -- the scheme of agg.hip's hub blocks on the stream engine.
-// <= 32 VGPRs and R KiB of LDS per wave: one 4-wave workgroup (48 KiB) fits next to a persistent GEMM workgroup (101 KiB, 480 VGPRs of 512), several
+//     wave per part, all parts of a row on one XCD: partial rows through write-through stores, an arrival ticket, and the last arriver sums
+//     the parts in part order (deterministic) -- the scheme of agg.hip's hub blocks on the stream engine.
+// <= 32 VGPRs and R + 1 KiB of LDS per wave: one 4-wave workgroup (52 KiB) fits next to a persistent GEMM workgroup (101 KiB, 480 VGPRs of 512), several
 // fit an otherwise empty CU.
 #include <algorithm>
 #include <stdlib.h>
@@ -58,20 +59,27 @@ struct AggS {
     const int32_t* hsu; const float* hsw;                                    // the tables holding the hub rows' edges (the full launch's own; a list launch borrows the batch's)
     const int32_t* heavy; const int32_t* hcum; int n_heavy; int e_norm;      // hub rows, prefix of their edge counts; their edges start at hsu / hsw[e_norm + hcum[h]]
     const int32_t* hub; float* hub_scratch; int hub_part, hub_ld, n_parts;   // gm_agg_schedule's part table (NULL: one part per hub row), partial rows
+    const int32_t* xord;                // with hub: [GM_NXCD + 1 offsets | n_parts part ids] -- the parts of a hub row all run on ONE XCD (see the hub section of the kernel)
     int prio;                           // s_setprio of the waves (GM_AGG_STREAM_PRIO): beside a GEMM workgroup whose feeder waves run at 2 / 3
     unsigned long long* dbg;            // timeline probe (tools/coreside_probe.py): [2 * blocks] start / end of every workgroup on the device's constant clock
 };
 
 // One gather: LDS[slot .. slot + LPR * 16) <- x[voff .. ), 16 bytes per lane of the lower LPR lanes (M0 = the slot's LDS byte address; EXEC is
 // all ones around this statement: the kernel's control flow is wave-uniform).  M0 is the compiler's: saved and restored.
+// The statement starts with lgkmcnt(0): the slot was READ (ds_read_b128) by the step that issues this gather, and nothing orders a DMA's LDS write behind
+// a read that has been issued but not yet executed.  The first version had no such wait: with the other stream's GEMM saturating the CU's LDS the read
+// could sit in its queue longer than a cache-resident source row takes to arrive, and the sum picked up 64-byte pieces of the row gathered for edge e + R
+// -- in hub rows (whose sources are the hottest), ~1 launch in 500, only beside the GEMM (tools/agg_stream_race.py; profiles/r05_experiments_not_shipped.txt
+// E).  Cost: the read's latency on every step's issue, ~3 % of a launch (1.14 M rows: 460 -> 476 us).  A ring of R + 1 slots (refill the slot read a step
+// earlier: the wait is then free) was measured too: 56 KiB per workgroup are two workgroups per CU instead of three, 516 us.
 template <int LPR>
 __device__ __forceinline__ void as_issue(unsigned lds_slot, const float* xbase, unsigned voff) {
     unsigned keep;
     if constexpr (LPR == 64)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot) : "memory");
     else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
                      "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot), "s"(LPR == 32 ? 0xffffffffu : 0xffffu) : "memory");
 }
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
             const float4 v = *reinterpret_cast<const float4*>(ring + slot + lane16);
             acc.x = __fmaf_rn(v.x, w, acc.x); acc.y = __fmaf_rn(v.y, w, acc.y); acc.z = __fmaf_rn(v.z, w, acc.z); acc.w = __fmaf_rn(v.w, w, acc.w);
         };
-        auto issue = [&](int u) { as_issue<LPR>(ring_lds + (unsigned)slot, a.x, (unsigned)u * a.row_bytes + lane16); };
+        auto issue = [&](int u) { as_issue<LPR>(ring_lds + (unsigned)slot, a.x, (unsigned)u * a.row_bytes + lane16); };      // (waits for the slot's read: as_issue)
         auto next_slot = [&]() { slot = slot + SLOT == R * SLOT ? 0 : slot + SLOT; };
         // descriptor chunk c (64 edges) -> half (c & 1) of the wave's source / weight rings
         auto load_su = [&](int c) { as_issue_desc(ring_lds + (unsigned)(R * SLOT + (c & 1) * 256), tsu, (unsigned)c * 256u + lane4); };
@@ -208,9 +216,18 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         while (rc < r_end) row_done();                              // the last row with edges and the empty rows behind it
         return;
     }
-    // ================= hub parts: wave hw of the hub workgroups takes parts hw, hw + HW, ...
+    // ================= hub parts.  Unsplit hub rows: wave hw of the hub workgroups takes rows hw, hw + HW, ...  Split rows: ALL parts of a hub row run on waves
+    // of one XCD (hardware block b runs on XCD b % 8; the host dealt the hub rows to the XCDs by part count: a.xord), like the window kernel's schedule: the
+    // partial rows then travel through ONE L2 -- the ticket protocol below (write-through stores acknowledged by the writer's L2, a relaxed ticket, one
+    // agent-scope acquire) has only ever been exercised that way, and the last arriver's reads hit that L2.
     const int HW = a.hub_wgs * AS_WAVES, hw = b * AS_WAVES + wave;
-    for (int g = hw; g < a.n_parts; g += HW) {
+    int i0 = hw, i1 = a.n_parts, istep = HW;
+    if (a.xord) {
+        const int xcd = b % GM_NXCD;
+        i0 = as_sload(a.xord + xcd) + (b / GM_NXCD) * AS_WAVES + wave; i1 = as_sload(a.xord + xcd + 1); istep = (a.hub_wgs / GM_NXCD) * AS_WAVES;
+    }
+    for (int i = i0; i < i1; i += istep) {
+        const int g = a.xord ? as_sload(a.xord + GM_NXCD + 1 + i) : i;
         int h = g, p = 0, P = 1;
         if (a.hub) { h = as_sload(a.hub + a.n_heavy + 1 + g); const int o0 = as_sload(a.hub + h); p = g - o0; P = as_sload(a.hub + h + 1) - o0; }
         const int row = as_sload(a.heavy + h);
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(AS_WAVES * 64) void k_agg_stream(AggS a) {
         run(a.hsu, a.hsw, eb, ee, std::false_type{});
         if (P == 1) { store_row((int64_t)row); continue; }
         // partial row -> scratch with write-through (sc1) stores, drained; one relaxed agent-scope ticket; the last arriver does ONE agent-scope acquire
-        // and sums the P partial rows in part order
+        // and sums the P partial rows in part order (writers and reader share an L2: see above)
         typedef float f4v __attribute__((ext_vector_type(4)));
         if (act) {
             float* dst = a.hub_scratch + (int64_t)g * a.hub_ld + lane * 4;
@@ -306,7 +323,8 @@ int gm_stream_wgs(int64_t cost) {
 // Stream tables of one orientation (o = 0: by destination; 1: by source).  hubs_host / deg_host: the orientation's ascending hub rows and
 // their degrees (host copies from the finalisation's round trip); n_parts: hub parts of the orientation's part table (the hub count when the
 // rows are not split).  Needs the batch's per-edge tables (d_enorm, d_efeat).
-int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg) {
+int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, const std::vector<int32_t>* part_tab, hipStream_t s,
+                     gm_stager* sg) {
     if (b->rows <= 0 || b->edges <= 0 || !b->d_enorm[o]) return GM_OK;
     // Where the stream kernel pays (measured): sparse induced subgraphs (the arxiv shape: ~2 in-edges per row -- a gather per ~0.5 KiB of
     // output) in batches large enough to fill its pipelines.  Dense batches (Tissue shape, ~24 in-edges per row: 5.6 vs 3.2 ms per meta-step) and small ones
@@ -342,6 +360,28 @@ int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t
         hub_wgs = std::min(hub_wgs, std::min(nwg / 2 / GM_NXCD * GM_NXCD, (n_parts + AS_WAVES * GM_NXCD - 1) / (AS_WAVES * GM_NXCD) * GM_NXCD));
     }
     b->stream_hubwg[o] = hub_wgs; b->stream_nwg[o] = nwg; b->stream_nparts[o] = n_parts;
+    if (part_tab && n_parts > 0) {
+        // split hub rows: deal the rows to the XCDs (each to the one with the fewest parts so far), list every XCD's parts -- interleaved over its rows, so that
+        // the waves of an XCD start on different rows -- behind the GM_NXCD + 1 list offsets
+        const std::vector<int32_t>& tab = *part_tab;                  // [part_off: n_hubs + 1][...]
+        std::vector<std::vector<int>> rows_of(GM_NXCD);
+        std::vector<int> load(GM_NXCD, 0);
+        for (int h = 0; h < n_hubs; ++h) {
+            const int x = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            rows_of[x].push_back(h); load[x] += tab[h + 1] - tab[h];
+        }
+        std::vector<int32_t> xord(GM_NXCD + 1, 0);
+        for (int x = 0; x < GM_NXCD; ++x) {
+            xord[x] = (int32_t)xord.size() - (GM_NXCD + 1);
+            for (int k = 0, more = 1; more; ++k) {
+                more = 0;
+                for (int h : rows_of[x]) if (tab[h] + k < tab[h + 1]) { xord.push_back(tab[h] + k); more = 1; }
+            }
+        }
+        xord[GM_NXCD] = (int32_t)xord.size() - (GM_NXCD + 1);
+        GM_REQUIRE(xord[GM_NXCD] == n_parts, GM_EINVAL, "stream tables: %d hub parts listed, %d expected", xord[GM_NXCD], n_parts);
+        GM_TRY(gm_balloc(b, &b->d_sxord[o], xord.size(), s)); GM_TRY(sg->upload(b->d_sxord[o], xord));
+    }
     b->stream_nseg[o] = (nwg - hub_wgs) * AS_WAVES;
     GM_TRY(gm_balloc(b, &b->d_sseg[o], (size_t)b->stream_nseg[o], s));
     hipLaunchKernelGGL(k_stream_segs, dim3((b->stream_nseg[o] + 255) / 256), dim3(256), 0, s, b->d_sptr[o], (int64_t)b->rows, b->stream_nseg[o], b->d_sseg[o]);
@@ -379,7 +419,8 @@ int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s) {
     const int32_t* su = g.stream_feat ? b->d_su_feat : b->d_su[o];
     AggS a{b->d_sptr[o], su, b->d_sw[o], g.x, (unsigned)(g.ldx * 4), g.out, g.width, nt, nullptr, b->d_sseg[o], b->stream_nseg[o],
            b->stream_hubwg[o], su, b->d_sw[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
-           split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], 0, nullptr};
+           split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], split ? b->d_sxord[o] : nullptr, 0, nullptr};
+    GM_REQUIRE(!split || a.xord, GM_EINVAL, "stream aggregate: split hub rows without their XCD lists");
     { static const int pr = getenv("GM_AGG_STREAM_PRIO") ? atoi(getenv("GM_AGG_STREAM_PRIO")) : 0; a.prio = pr; }
     if (g_stream_dbg && 2 * b->stream_nwg[o] <= g_stream_dbg_n) a.dbg = g_stream_dbg;
     const int depth = gm_knob().agg_stream_depth, nwg = b->stream_nwg[o];

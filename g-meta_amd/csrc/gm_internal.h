@@ -144,7 +144,7 @@ struct gm_batch {
     // hub row's end bound flags it), the per-edge source / weight tables in row order with the hub rows' edges behind (d_su_feat: sources = feature rows
     // of the store, layer 1), the prefix of the hub rows' edge counts, the cost-balanced row segments of the launch's waves and its grid split
     int32_t* d_sptr[2] = {nullptr, nullptr}; int32_t* d_su[2] = {nullptr, nullptr}; int32_t* d_su_feat = nullptr; float* d_sw[2] = {nullptr, nullptr};
-    int32_t* d_scum[2] = {nullptr, nullptr}; int2* d_sseg[2] = {nullptr, nullptr};
+    int32_t* d_scum[2] = {nullptr, nullptr}; int2* d_sseg[2] = {nullptr, nullptr}; int32_t* d_sxord[2] = {nullptr, nullptr};
     int32_t stream_nseg[2] = {0, 0}, stream_nwg[2] = {0, 0}, stream_hubwg[2] = {0, 0}, stream_nparts[2] = {0, 0}, stream_enorm[2] = {0, 0};
     int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
@@ -303,7 +303,8 @@ struct gm_agg_args {
 void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather);
 bool gm_stream_ok(const gm_agg_args& g);
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s);
-int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, hipStream_t s, gm_stager* sg);
+int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, const std::vector<int32_t>* part_tab, hipStream_t s,
+                     gm_stager* sg);
 #define GM_FUSE_SELF 0x40000000   // gm_batch::d_fuse2 entry: the source is the row's own, already aggregated, row
 #define GM_FUSE_ZERO 0x20000000   // ... the row has no source: an all-zero row
 const float* gm_zero_row(hipStream_t s);   // 4096 zero floats on the current device (allocated once)

@@ -37,73 +37,165 @@ __device__ __forceinline__ const float* centre_feat(const HeadK& k, int s, int w
 // Optional fused inner-loop SGD (meta.py:126,151): next_t[j] = cur_t[j] - lr * grad_t[j], written with the gradient.
 struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; };
 
-// logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph.
-__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, float* logits, const float* hs = nullptr, int s0 = 0,
-                                             const float* wl_s = nullptr, int lbase = 0) {   // wl_s: LDS copy of [Wl | bl]; logits holds subgraphs [lbase, ..)
-    const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
-    const float* h0 = centre_feat(k, s, 0, hs, s0);
-    const float* h1 = k.nc == 2 ? centre_feat(k, s, 1, hs, s0) : nullptr;
-    for (int c = 0; c < k.C; ++c) {
-        const float* w = wl_s ? wl_s + c * k.hc : P + k.wl_off + (int64_t)c * k.hc;
-        float acc = 0.f;
-        for (int h = lane; h < k.hc; h += 64) acc += (h < k.Hd ? h0[h] : h1[h - k.Hd]) * w[h];
-        acc = wave_sumf(acc);
-        if (lane == 0) logits[(int64_t)(s - lbase) * k.C + c] = acc + (wl_s ? wl_s[k.C * k.hc + c] : P[k.bl_off + c]);
+// ---- address-space policies of the head kernels.  The fused kernel (k_head_loss) keeps a set's centre rows, head weights, logits and dlogits in LDS; the
+// unfused kernels (k_head_fwd / k_proto / k_head_bwd: the public per-phase entry points) work on the global arrays.  Written with plain `float*` and a
+// run-time `staged ? lds : global` choice, every access became a FLAT instruction (159 flat_load in the fused kernel: LDS data through the vector-memory
+// path, several times an ds_read's latency, and both wait counters to drain) -- in a kernel that is one workgroup per task and nothing but latency.  The LDS
+// pointers therefore carry their address space in the type, and the two variants are separate instantiations.
+typedef __attribute__((address_space(3))) float lds_float;
+typedef __attribute__((address_space(3))) int lds_int;
+struct MemG { typedef float* F; typedef const float* CF; typedef const int32_t* CI; static constexpr bool lds = false; };
+struct MemL { typedef lds_float* F; typedef const lds_float* CF; typedef const lds_int* CI; static constexpr bool lds = true; };
+
+// logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph, a 16-lane group per output class: four classes
+// are reduced at once with four shuffle steps (a wave-wide reduction per class was 6 dependent ds_bpermute round trips per logit).
+// The association is the wave-wide version's, bit for bit: lane l of a group carries the partial sums of the former lanes l, l + 16, l + 32, l + 48
+// (columns h = lane mod 64, ascending) and joins them the way the 32- and 16-lane butterfly steps did.  (Not pedantry: fixture g1_sampled_h2 holds rows
+// whose layer-2 pre-activation is the bias alone, so the SIGN of a 1e-9-sized bias decides their relu' -- another rounding of the logits moved one
+// meta-gradient entry of the flagged schedules by 150 % against the reference's golden value.)
+// MemL: hs = the set's centre rows (subgraphs from s0, centre order: cat(h[c0], h[c1]) of a subgraph is contiguous), wl_s = [Wl | bl]; logits holds
+// subgraphs [lbase, ..).  MemG: rows of k.H, the set's parameters.
+template <typename M>
+__device__ __forceinline__ void head_fwd_sub(const HeadK& k, int s, int lane, typename M::F logits, typename M::CF hs, int s0, typename M::CF wl_s, int lbase) {
+    const int grp = lane >> 4, l = lane & 15;
+    if constexpr (M::lds) {
+        typename M::CF x = hs + (s - s0) * k.nc * k.Hd;
+        for (int c0 = 0; c0 < k.C; c0 += 4) {
+            const int c = c0 + grp, cc = min(c, k.C - 1);
+            typename M::CF w = wl_s + cc * k.hc;
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            if ((k.hc & 63) == 0) {                    // the reads of four 64-column steps (all of hc = 256) in flight together
+#pragma unroll 4
+                for (int hb = l; hb < k.hc; hb += 64) {
+                    p[0] += x[hb] * w[hb]; p[1] += x[hb + 16] * w[hb + 16]; p[2] += x[hb + 32] * w[hb + 32]; p[3] += x[hb + 48] * w[hb + 48];
+                }
+            } else {
+                for (int hb = l; hb < k.hc; hb += 64) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) { const int h = hb + 16 * m; if (h < k.hc) p[m] += x[h] * w[h]; }
+                }
+            }
+            float acc = (p[0] + p[2]) + (p[1] + p[3]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (l == 0 && c < k.C) logits[(s - lbase) * k.C + c] = acc + wl_s[k.C * k.hc + c];
+        }
+    } else {
+        const float* P = k.params + (int64_t)k.sub_set[s] * k.pstride;
+        const float* h0 = k.H + centre_row(k, s, 0) * k.ldh;
+        const float* h1 = k.nc == 2 ? k.H + centre_row(k, s, 1) * k.ldh : h0;
+        for (int c0 = 0; c0 < k.C; c0 += 4) {
+            const int c = c0 + grp, cc = min(c, k.C - 1);
+            const float* w = P + k.wl_off + (int64_t)cc * k.hc;
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int hb = l; hb < k.hc; hb += 64) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) { const int h = hb + 16 * m; if (h < k.hc) p[m] += (h < k.Hd ? h0[h] : h1[h - k.Hd]) * w[h]; }
+            }
+            float acc = (p[0] + p[2]) + (p[1] + p[3]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (l == 0 && c < k.C) logits[(int64_t)(s - lbase) * k.C + c] = acc + P[k.bl_off + c];
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_head_fwd(HeadK k, float* logits) {
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (s < k.subs) head_fwd_sub(k, s, threadIdx.x & 63, logits);
+    if (s < k.subs) head_fwd_sub<MemG>(k, s, threadIdx.x & 63, logits, nullptr, 0, nullptr, 0);
 }
 
 // Backward of the head for one set per block: dWl, dbl into dparams; dQ_L (pre-zeroed) at the centre rows,
 // already multiplied by relu'(H_L).  With Gc != NULL the rows go to a compact [subs*centres, Hd] matrix instead.
-template <int NT>
-__device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, const float* dlogits, float* dparams, int64_t dstride, float* dQ,
-                                             float* Gc, const SgdK& u, const float* hs = nullptr, const float* wl_s = nullptr, int dbase = 0,
-                                             const int* crow_s = nullptr) {     // dlogits holds subgraphs [dbase, ..); crow_s: LDS table of the set's centre rows
-    const int s0 = k.set_sub_off[set], s1 = k.set_sub_off[set + 1];
+// dlogits holds subgraphs [dbase, ..).  MemL: hs / wl_s as above, crow_s = the rows of the set's centres; pre: u.cur of this thread's first Wl / bl entry was
+// loaded by the caller.  s0 / s1: the set's subgraph range.  dbg: phase stamp 5 of block 0 (gm_head_loss_debug).
+template <int NT, typename M>
+__device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, typename M::CF dlogits, float* dparams, int64_t dstride, float* dQ,
+                                             float* Gc, const SgdK& u, typename M::CF hs, typename M::CF wl_s, int dbase, typename M::CI crow_s,
+                                             bool pre, float pre_w, float pre_b, int s0, int s1, unsigned long long* dbg) {
     const float* P = k.params + (int64_t)set * k.pstride;
-    const float* WL = wl_s ? wl_s : P + k.wl_off;                     // [C, hc]
+    auto wl = [&](int i) -> float { if constexpr (M::lds) return wl_s[i]; else return P[k.wl_off + i]; };                   // Wl[C, hc]
+    auto feat = [&](int s, int which, int col) -> float {                                                                  // H_L at centre `which` of subgraph s
+        if constexpr (M::lds) return hs[((s - s0) * k.nc + which) * k.Hd + col]; else return k.H[centre_row(k, s, which) * k.ldh + col];
+    };
+    auto crow = [&](int s, int which) -> int64_t { if constexpr (M::lds) return crow_s[(s - s0) * k.nc + which]; else return centre_row(k, s, which); };
     float* D = dparams + (int64_t)set * dstride;
+    const int S = s1 - s0;
     for (int id = tid; id < k.C * k.hc; id += NT) {
         const int c = id / k.hc, h = id - c * k.hc;
         float acc = 0.f;
-        for (int s = s0; s < s1; ++s) {
-            const float hv = h < k.Hd ? centre_feat(k, s, 0, hs, s0)[h] : centre_feat(k, s, 1, hs, s0)[h - k.Hd];
-            acc += dlogits[(int64_t)(s - dbase) * k.C + c] * hv;
+        if constexpr (M::lds) {     // column h of cat(h[c0], h[c1]) of subgraph s0 + j is hs[j * hc + h]: 32-bit index arithmetic, reads issued ahead
+            typename M::CF hcol = hs + h;
+            typename M::CF dcol = dlogits + (s0 - dbase) * k.C + c;
+#pragma unroll 8
+            for (int j = 0; j < S; ++j) acc += dcol[j * k.C] * hcol[j * k.hc];
+        } else {
+            for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)(s - dbase) * k.C + c] * (h < k.Hd ? feat(s, 0, h) : feat(s, 1, h - k.Hd));
         }
         D[k.wl_off + id] = acc;
-        if (u.next) u.next[(int64_t)set * u.next_stride + k.wl_off + id] = u.cur[(int64_t)set * u.cur_stride + k.wl_off + id] - u.lr * acc;
+        if (u.next) u.next[(int64_t)set * u.next_stride + k.wl_off + id] = ((pre && id == tid) ? pre_w : u.cur[(int64_t)set * u.cur_stride + k.wl_off + id]) - u.lr * acc;
     }
     for (int c = tid; c < k.C; c += NT) {
         float acc = 0.f;
-        for (int s = s0; s < s1; ++s) acc += dlogits[(int64_t)(s - dbase) * k.C + c];
+#pragma unroll 8
+        for (int s = s0; s < s1; ++s) acc += dlogits[(s - dbase) * k.C + c];
         D[k.bl_off + c] = acc;
-        if (u.next) u.next[(int64_t)set * u.next_stride + k.bl_off + c] = u.cur[(int64_t)set * u.cur_stride + k.bl_off + c] - u.lr * acc;
+        if (u.next) u.next[(int64_t)set * u.next_stride + k.bl_off + c] = ((pre && c == tid) ? pre_b : u.cur[(int64_t)set * u.cur_stride + k.bl_off + c]) - u.lr * acc;
     }
-    // one thread per (subgraph, column); both centres of a pair stay in one thread (they may share a row)
+    if (dbg && set == 0 && tid == 0) dbg[5] = wall_clock64();
+    // one thread per (subgraph, column); both centres of a pair stay in one thread (they may share a row).  dQ is all zeros when this runs and a row is the
+    // centre of ONE subgraph, so the "+=" of learner.py's index_select backward is a plain store (no dependent read of dQ); the two centres of a pair may be
+    // the same row: (0 + v0) + v1
     float dq_max = 0.f;
-    for (int id = tid; id < (s1 - s0) * k.Hd; id += NT) {
-        const int s = s0 + id / k.Hd, col = id % k.Hd;
-        float vv[2] = {0.f, 0.f};
-        for (int which = 0; which < k.nc; ++which) {
-            float v = 0.f;
-            for (int c = 0; c < k.C; ++c) v += dlogits[(int64_t)(s - dbase) * k.C + c] * WL[(int64_t)c * k.hc + which * k.Hd + col];
-            const float hval = centre_feat(k, s, which, hs, s0)[col];
-            if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
-            else vv[which] = hval > 0.f ? v : 0.f;
-        }
-        if (!Gc) {
-            // dQ is all zeros when this runs and a row is the centre of ONE subgraph, so the "+=" of learner.py's index_select backward is a
-            // plain store (no dependent read of dQ); the two centres of a pair may be the same row: (0 + v0) + v1
-            const int64_t r0 = crow_s ? crow_s[(s - s0) * k.nc] : centre_row(k, s, 0);
+    constexpr int CMAX = 8;
+    if (M::lds && !Gc && NT % k.Hd == 0 && k.C <= CMAX) {
+        // dense dQ from the staged rows: a thread keeps ONE column (NT is a multiple of Hd) and walks the subgraphs NT / Hd apart -- no division in the loop,
+        // the column's head weights in registers; per element the same operations in the same order as the general loop below
+        const int col = tid % k.Hd, sstep = NT / k.Hd;
+        float wv[2][CMAX];
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c) wv[which][c] = (which < k.nc && c < k.C) ? wl(c * k.hc + which * k.Hd + col) : 0.f;
+        for (int j = tid / k.Hd; j < S; j += sstep) {
+            typename M::CF dl_j = dlogits + (s0 - dbase + j) * k.C;
+            float vv[2] = {0.f, 0.f};
+#pragma unroll
+            for (int which = 0; which < 2; ++which) {
+                if (which < k.nc) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int c = 0; c < CMAX; ++c) if (c < k.C) v += dl_j[c] * wv[which][c];
+                    vv[which] = feat(s0 + j, which, col) > 0.f ? v : 0.f;
+                }
+            }
+            const int64_t r0 = crow(s0 + j, 0);
             if (k.nc == 2) {
-                const int64_t r1 = crow_s ? crow_s[(s - s0) * k.nc + 1] : centre_row(k, s, 1);
+                const int64_t r1 = crow(s0 + j, 1);
                 if (r1 == r0) vv[0] = vv[0] + vv[1]; else { dQ[r1 * k.ldh + col] = vv[1]; dq_max = fmaxf(dq_max, fabsf(vv[1])); }
             }
             dQ[r0 * k.ldh + col] = vv[0];
             dq_max = fmaxf(dq_max, fabsf(vv[0]));
+        }
+    } else {
+        for (int id = tid; id < S * k.Hd; id += NT) {
+            const int s = s0 + id / k.Hd, col = id % k.Hd;
+            float vv[2] = {0.f, 0.f};
+            for (int which = 0; which < k.nc; ++which) {
+                float v = 0.f;
+                for (int c = 0; c < k.C; ++c) v += dlogits[(s - dbase) * k.C + c] * wl(c * k.hc + which * k.Hd + col);
+                const float hval = feat(s, which, col);
+                if (Gc) Gc[((int64_t)s * k.nc + which) * k.Hd + col] = hval > 0.f ? v : 0.f;     // compact rows (sparse backward / cone)
+                else vv[which] = hval > 0.f ? v : 0.f;
+            }
+            if (!Gc) {
+                const int64_t r0 = crow(s, 0);
+                if (k.nc == 2) {
+                    const int64_t r1 = crow(s, 1);
+                    if (r1 == r0) vv[0] = vv[0] + vv[1]; else { dQ[r1 * k.ldh + col] = vv[1]; dq_max = fmaxf(dq_max, fabsf(vv[1])); }
+                }
+                dQ[r0 * k.ldh + col] = vv[0];
+                dq_max = fmaxf(dq_max, fabsf(vv[0]));
+            }
         }
     }
     if (k.dq_amax && !Gc) {
@@ -113,7 +205,9 @@ __device__ __forceinline__ void head_bwd_set(const HeadK& k, int set, int tid, c
     }
 }
 __global__ __launch_bounds__(256) void k_head_bwd(HeadK k, const float* dlogits, float* dparams, int64_t dstride, float* dQ, float* Gc) {
-    head_bwd_set<256>(k, blockIdx.x, threadIdx.x, dlogits, dparams, dstride, dQ, Gc, SgdK{nullptr, 0, nullptr, 0, 0.f});
+    const int set = blockIdx.x;
+    head_bwd_set<256, MemG>(k, set, threadIdx.x, dlogits, dparams, dstride, dQ, Gc, SgdK{nullptr, 0, nullptr, 0, 0.f}, nullptr, nullptr, 0, nullptr, false, 0.f, 0.f,
+                            k.set_sub_off[set], k.set_sub_off[set + 1], nullptr);
 }
 
 // Prototypical loss for one set per block (meta.py:28-79).  rows: [sets, Ct, n] global subgraph ids grouped by
@@ -125,28 +219,39 @@ struct ProtoK {
     int row_base;                         // logits / dlogits hold subgraphs [row_base, ...): 0 for the global arrays, the set's first
                                           // subgraph when the fused kernel keeps them in LDS
     const int32_t* tab;                   // [sets*3] per set: offset into rows, classes, rows per class (every task keeps its own class
-};                                        // layout, like the per-task proto_loss calls of meta.py:118-157); prototypes are strided by Ct
+                                          // layout, like the per-task proto_loss calls of meta.py:118-157); prototypes are strided by Ct
+    int uniform;                          // every set has Ct classes of n rows at offset set * Ct * n (the usual case): the kernels take the layout from the arguments
+};                                        // instead of a dependent load of `tab` ahead of the class rows
 
-__device__ __forceinline__ float sqdist(const float* x, const float* p, int D) {
+template <typename XP>
+__device__ __forceinline__ float sqdist(XP x, const lds_float* p, int D) {
     float d = 0.f;
     for (int k = 0; k < D; ++k) { const float t = x[k] - p[k]; d += t * t; }
     return d;
 }
 
-template <int NT>
-__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, float* sm, const int32_t* rows_l = nullptr) {
-    const int Ct = k.tab[set * 3 + 1], n = k.tab[set * 3 + 2];
-    const int Q = Ct * n, D = k.D;
-    float* protos = sm;                 // [Ct*D]   (LDS sized for the largest set)
-    float* lse = sm + k.Ct * D;         // [Q]
-    float* red = lse + k.Ct * k.n;      // [2 * NT]
-    const int32_t* rows = rows_l ? rows_l : k.rows + k.tab[set * 3];      // rows_l: the set's class rows already in LDS (k_head_loss)
+// LDS of a set: prototypes [Ct*D] | lse [Ct*n] | block-sum scratch [2*NT] | A [Ct*n*Ct] (only when it is at most PROTO_A_MAX floats).
+// A holds -dist(q, c) and then G[q,c] = (softmax(-d)[q,c] - [c == class(q)]) / Q: every later phase reads it instead of redoing the distance and the
+// exponential, and the loops that must stay serial (a class sum over its rows, a prototype's gradient over the queries: their order is part of the
+// result) carry nothing but LDS reads that can be issued ahead.  The kernel is one workgroup per task and pure latency.
+// logits / dlogits / rows: the arrays the set is scored on -- k's global ones (MemG; rows already offset to the set) or the fused kernel's LDS copies (MemL).
+#define PROTO_A_MAX 8192
+template <int NT, typename M>
+__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds_float* sm, typename M::CF logits, typename M::F dlogits, typename M::CI rows) {
+    const int Ct = k.uniform ? k.Ct : k.tab[set * 3 + 1], n = k.uniform ? k.n : k.tab[set * 3 + 2];
+    const int Q = Ct * n, D = k.D, rb = k.row_base;
+    lds_float* protos = sm;             // [Ct*D]   (LDS sized for the largest set)
+    lds_float* lse = sm + k.Ct * D;     // [Q]
+    lds_float* red = lse + k.Ct * k.n;  // [2 * NT]
+    lds_float* A = red + 2 * NT;        // [Q * Ct]
+    const bool useA = (int64_t)k.Ct * k.n * k.Ct <= PROTO_A_MAX;
     for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         float p;
         if (k.mode == 0) {
             p = 0.f;
-            for (int r = 0; r < n; ++r) p += k.logits[(int64_t)(rows[c * n + r] - k.row_base) * D + d];
+#pragma unroll 4
+            for (int r = 0; r < n; ++r) p += logits[(rows[c * n + r] - rb) * D + d];
             p /= (float)n;                                                          // .mean(0) (meta.py:41)
             if (k.protos_out) k.protos_out[(int64_t)set * k.Ct * D + id] = p;
         } else {
@@ -155,18 +260,25 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
         protos[id] = p;
     }
     __syncthreads();
+    if (useA) {
+        for (int id = tid; id < Q * Ct; id += NT) {
+            const int q = id / Ct, c = id - q * Ct;
+            A[id] = -sqdist(logits + (rows[q] - rb) * D, protos + c * D, D);      // -dists (meta.py:44-45)
+        }
+        __syncthreads();
+    }
     float lpart = 0.f, apart = 0.f;
     for (int q = tid; q < Q; q += NT) {
-        const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
+        typename M::CF x = logits + (rows[q] - rb) * D;
         const int tgt = q / n;
         float m = -INFINITY, at = 0.f;
         for (int c = 0; c < Ct; ++c) {
-            const float a = -sqdist(x, protos + c * D, D);                           // -dists (meta.py:44-45)
+            const float a = useA ? A[q * Ct + c] : -sqdist(x, protos + c * D, D);
             m = fmaxf(m, a);
             if (c == tgt) at = a;
         }
         float se = 0.f;
-        for (int c = 0; c < Ct; ++c) se += expf(-sqdist(x, protos + c * D, D) - m);
+        for (int c = 0; c < Ct; ++c) se += expf((useA ? A[q * Ct + c] : -sqdist(x, protos + c * D, D)) - m);
         const float lg = logf(se);
         lse[q] = m + lg;
         lpart += -((at - m) - lg);                                                   // -log_p[q, class(q)], log_softmax = (x - max) - log(sum exp(x - max))
@@ -175,7 +287,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
         // predicts class 0; reproduced (fixture g8_wide_scales)
         float bl = -INFINITY; int best = 0;
         for (int c = 0; c < Ct; ++c) {
-            const float lp = (-sqdist(x, protos + c * D, D) - m) - lg;
+            const float lp = ((useA ? A[q * Ct + c] : -sqdist(x, protos + c * D, D)) - m) - lg;
             if (lp > bl) { bl = lp; best = c; }
         }
         apart += (best == tgt) ? 1.f : 0.f;
@@ -192,31 +304,45 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
             k.acc[(int64_t)set * k.ld_out + k.col_out] = a2 / (float)Q;
         }
     }
-    if (!k.dlogits) return;
+    if (!dlogits) return;
     // G[q,c] = (softmax(-d)[q,c] - [c == tgt(q)]) / Q ;  d(-d_qc)/dx_q = -2 (x_q - p_c) ; d(-d_qc)/dp_c = +2 (x_q - p_c)
     const float invQ = 1.f / (float)Q;
+    if (useA) {
+        for (int id = tid; id < Q * Ct; id += NT) {
+            const int q = id / Ct, c = id - q * Ct;
+            A[id] = (expf(A[id] - lse[q]) - (c == q / n ? 1.f : 0.f)) * invQ;
+        }
+        __syncthreads();
+    }
     for (int id = tid; id < Q * D; id += NT) {
         const int q = id / D, d = id - q * D;
-        const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
+        typename M::CF x = logits + (rows[q] - rb) * D;
         const int tgt = q / n;
         float s = 0.f;
         for (int c = 0; c < Ct; ++c) {
-            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == tgt ? 1.f : 0.f)) * invQ;
+            const float g = useA ? A[q * Ct + c] : (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == tgt ? 1.f : 0.f)) * invQ;
             s += g * -2.f * (x[d] - protos[c * D + d]);
         }
-        k.dlogits[(int64_t)(rows[q] - k.row_base) * D + d] = s;
+        dlogits[(rows[q] - rb) * D + d] = s;
     }
     __syncthreads();
     for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
+        const float pd = protos[id];
         float s = 0.f;
-        for (int q = 0; q < Q; ++q) {
-            const float* x = k.logits + (int64_t)(rows[q] - k.row_base) * D;
-            const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / n ? 1.f : 0.f)) * invQ;
-            s += g * 2.f * (x[d] - protos[id]);
+        if (useA) {
+#pragma unroll 8
+            for (int q = 0; q < Q; ++q) s += A[q * Ct + c] * 2.f * (logits[(rows[q] - rb) * D + d] - pd);
+        } else {
+            for (int q = 0; q < Q; ++q) {
+                typename M::CF x = logits + (rows[q] - rb) * D;
+                const float g = (expf(-sqdist(x, protos + c * D, D) - lse[q]) - (c == q / n ? 1.f : 0.f)) * invQ;
+                s += g * 2.f * (x[d] - pd);
+            }
         }
         if (k.mode == 0) {
-            for (int r = 0; r < n; ++r) k.dlogits[(int64_t)(rows[c * n + r] - k.row_base) * D + d] += s / (float)n;
+#pragma unroll 4
+            for (int r = 0; r < n; ++r) dlogits[(rows[c * n + r] - rb) * D + d] += s / (float)n;
         } else if (k.dprotos) {
             k.dprotos[(int64_t)set * k.Ct * D + id] = s;
         }
@@ -225,7 +351,8 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, flo
 
 __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    proto_set<256>(k, blockIdx.x, threadIdx.x, sm);
+    const int set = blockIdx.x;
+    proto_set<256, MemG>(k, set, threadIdx.x, (lds_float*)sm, k.logits, k.dlogits, k.rows + (k.uniform ? set * k.Ct * k.n : k.tab[set * 3]));
 }
 
 // Head forward + prototypical loss (+ head backward and the SGD of the head's own parameters) of one set per block: the
@@ -233,84 +360,106 @@ __global__ __launch_bounds__(256) void k_proto(ProtoK k) {
 #define HL_THREADS 1024     // largest workgroup of k_head_loss (LDS sizing)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, ProtoK pk, int do_bwd, float* dparams, int64_t dstride, float* dQ,
-                                                          float* Gc, SgdK u, int stage, int proto_floats) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+                                                          float* Gc, SgdK u, int stage, int proto_floats, int copy_out, unsigned long long* dbg) {
+    extern __shared__ __attribute__((aligned(16))) float sm_generic[];
+    lds_float* sm = (lds_float*)sm_generic;
     const int set = blockIdx.x, tid = threadIdx.x;
+#define HL_STAMP(K) do { if (dbg && set == 0 && tid == 0) dbg[K] = wall_clock64(); } while (0)      // phase timeline of block 0 (tools/head_loss_probe.py)
+    HL_STAMP(0);
     const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1], S = s1 - s0, D = pk.D;
-    // stage != 0: everything the three phases share stays in LDS -- the set's centre rows of H_L, its head weights, its
-    // logits and dlogits -- so that a phase costs LDS latency instead of an L2 round trip (the kernel is pure latency)
-    float *hs = nullptr, *wl_s = nullptr;
-    int* crow = nullptr; int* rows_l = nullptr;
-    float* lg = logits; float* dl = pk.dlogits;
-    if (stage) {
-        hs = sm + proto_floats;
-        wl_s = hs + (int64_t)S * hk.nc * hk.Hd;
-        float* lg_s = wl_s + hk.C * hk.hc + hk.C;
-        float* dl_s = lg_s + S * D;
-        const float* P = hk.params + (int64_t)set * hk.pstride;
-        // centre rows of H_L -> LDS.  The row ids (two dependent loads each) are resolved first, then the row reads are
-        // issued eight deep: the kernel is one workgroup per task and pure latency, so a serial chain of 18 dependent
-        // global loads per thread (the first version) was most of its time.
-        crow = reinterpret_cast<int*>(dl_s + S * D);                    // [S * nc] row of every centre (scratch past the dlogits copy)
-        rows_l = crow + S * hk.nc;                                      // [Ct * n] the set's class rows (subgraph ids)
-        const int nq = S * hk.nc;
-        // first round trip, everything that needs no other load: centre rows (two loads each), class rows, head weights
-        for (int q = tid; q < nq; q += NT) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
-        {
-            const int off = pk.tab[set * 3], Qs = pk.tab[set * 3 + 1] * pk.tab[set * 3 + 2];
-            for (int q = tid; q < Qs; q += NT) rows_l[q] = pk.rows[off + q];
-        }
-        for (int id = tid; id < hk.C * hk.hc; id += NT) wl_s[id] = P[hk.wl_off + id];
-        for (int id = tid; id < hk.C; id += NT) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
-        __syncthreads();
-        // second round trip: the centre rows of H_L, all loads of a thread in flight together (16-byte loads when the rows allow it)
-        if ((hk.Hd & 3) == 0 && (hk.ldh & 3) == 0 && ((uintptr_t)hk.H & 15) == 0) {
-            const int hd4 = hk.Hd >> 2, total4 = nq * hd4;
-            for (int id0 = tid; id0 < total4; id0 += 8 * NT) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int id = min(id0 + u * NT, total4 - 1), q = id / hd4, c4 = id - q * hd4;
-                    v[u] = *reinterpret_cast<const float4*>(hk.H + (int64_t)crow[q] * hk.ldh + c4 * 4);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int id = id0 + u * NT; if (id < total4) *reinterpret_cast<float4*>(hs + (int64_t)id * 4) = v[u]; }
-            }
-        } else {
-            const int total = nq * hk.Hd;
-            for (int id0 = tid; id0 < total; id0 += 8 * NT) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int id = min(id0 + u * NT, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
-                    v[u] = hk.H[(int64_t)crow[q] * hk.ldh + col];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { const int id = id0 + u * NT; if (id < total) hs[id] = v[u]; }
-            }
-        }
-        lg = lg_s;                              // LDS copies hold the set's subgraphs only: indexed relative to s0 (base below)
-        if (pk.dlogits) { dl = dl_s; for (int id = tid; id < S * D; id += NT) dl_s[id] = 0.f; }
-        __syncthreads();
-    } else if (pk.dlogits) {
-        for (int id = tid; id < S * D; id += NT) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
+    // the head's own SGD inputs (w - lr * g, meta.py:126,151) go out with the first round trip instead of behind the loss
+    const bool pre = do_bwd && u.next != nullptr;
+    float pre_w = 0.f, pre_b = 0.f;
+    if (pre) {
+        if (tid < hk.C * hk.hc) pre_w = u.cur[(int64_t)set * u.cur_stride + hk.wl_off + tid];
+        if (tid < hk.C) pre_b = u.cur[(int64_t)set * u.cur_stride + hk.bl_off + tid];
     }
-    const int base = stage ? s0 : 0;
-    for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub(hk, s, tid & 63, lg, hs, s0, wl_s, base);
-    __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
+    if (!stage) {
+        // everything in the global arrays (sets too large for LDS): the three phases with L2 round trips in between
+        if (pk.dlogits) for (int id = tid; id < S * D; id += NT) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
+        for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub<MemG>(hk, s, tid & 63, logits, nullptr, 0, nullptr, 0);
+        __syncthreads();          // workgroup-scope fence: the logits / zeros written above are visible to the whole block
+        HL_STAMP(3);
+        proto_set<NT, MemG>(pk, set, tid, sm, logits, pk.dlogits, pk.rows + (pk.uniform ? set * pk.Ct * pk.n : pk.tab[set * 3]));
+        HL_STAMP(4);
+        if (!do_bwd) return;
+        __syncthreads();
+        head_bwd_set<NT, MemG>(hk, set, tid, pk.dlogits, dparams, dstride, dQ, Gc, u, nullptr, nullptr, 0, nullptr, pre, pre_w, pre_b, s0, s1, dbg);
+        HL_STAMP(6);
+        return;
+    }
+    // staged: everything the three phases share stays in LDS -- the set's centre rows of H_L, its head weights, its
+    // logits and dlogits -- so that a phase costs LDS latency instead of an L2 round trip (the kernel is pure latency)
+    lds_float* hs = sm + proto_floats;                                      // [S * nc, Hd] centre rows of H_L, centre order
+    lds_float* wl_s = hs + S * hk.nc * hk.Hd;                               // [C * hc | C]  Wl | bl
+    lds_float* lg_s = wl_s + hk.C * hk.hc + hk.C;                           // [S, D] logits
+    lds_float* dl_s = lg_s + S * D;                                         // [S, D] dlogits
+    lds_int* crow = (lds_int*)(dl_s + S * D);                               // [S * nc] row of every centre
+    lds_int* rows_l = crow + S * hk.nc;                                     // [Ct * n] the set's class rows (subgraph ids)
+    const float* P = hk.params + (int64_t)set * hk.pstride;
+    const int nq = S * hk.nc;
+    // first round trip, everything that needs no other load: centre rows (two dependent loads each), class rows, head weights
+    for (int q = tid; q < nq; q += NT) crow[q] = (int)centre_row(hk, s0 + q / hk.nc, q % hk.nc);
+    {
+        const int off = pk.uniform ? set * pk.Ct * pk.n : pk.tab[set * 3], Qs = pk.uniform ? pk.Ct * pk.n : pk.tab[set * 3 + 1] * pk.tab[set * 3 + 2];
+        for (int q = tid; q < Qs; q += NT) rows_l[q] = pk.rows[off + q];
+    }
+    for (int id = tid; id < hk.C * hk.hc; id += NT) wl_s[id] = P[hk.wl_off + id];
+    for (int id = tid; id < hk.C; id += NT) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
+    __syncthreads();
+    HL_STAMP(1);
+    // second round trip: the centre rows of H_L, all loads of a thread in flight together (16-byte loads when the rows allow it).  (The first version was a
+    // serial chain of 18 dependent global loads per thread.)
+    if ((hk.Hd & 3) == 0 && (hk.ldh & 3) == 0 && ((uintptr_t)hk.H & 15) == 0) {
+        const int hd4 = hk.Hd >> 2, total4 = nq * hd4;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) f4v lds_f4v;
+        for (int id0 = tid; id0 < total4; id0 += 8 * NT) {
+            float4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int id = min(id0 + j * NT, total4 - 1), q = id / hd4, c4 = id - q * hd4;
+                v[j] = *reinterpret_cast<const float4*>(hk.H + (int64_t)crow[q] * hk.ldh + c4 * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int id = id0 + j * NT; if (id < total4) { const f4v t = {v[j].x, v[j].y, v[j].z, v[j].w}; *(lds_f4v*)(hs + id * 4) = t; } }
+        }
+    } else {
+        const int total = nq * hk.Hd;
+        for (int id0 = tid; id0 < total; id0 += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int id = min(id0 + j * NT, total - 1), q = id / hk.Hd, col = id - q * hk.Hd;
+                v[j] = hk.H[(int64_t)crow[q] * hk.ldh + col];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int id = id0 + j * NT; if (id < total) hs[id] = v[j]; }
+        }
+    }
+    lds_float* dl = pk.dlogits ? dl_s : nullptr;        // (pk.dlogits only says WHETHER the gradient is wanted; the global array is written with copy_out)
+    if (dl) for (int id = tid; id < S * D; id += NT) dl_s[id] = 0.f;
+    __syncthreads();
+    HL_STAMP(2);
+    for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub<MemL>(hk, s, tid & 63, lg_s, hs, s0, wl_s, s0);
+    __syncthreads();
+    HL_STAMP(3);
     ProtoK pl = pk;
-    pl.logits = lg; pl.dlogits = dl; pl.row_base = base;
-    proto_set<NT>(pl, set, tid, sm, rows_l);
-    if (stage) {              // the global copies (API / debugging): logits always, dlogits when requested
+    pl.row_base = s0;                                   // the LDS copies hold the set's subgraphs only
+    proto_set<NT, MemL>(pl, set, tid, sm, lg_s, dl, rows_l);
+    HL_STAMP(4);
+    if (copy_out) {  // the global copies (the public gm_proto_loss_* shape; nobody inside gm_meta_step reads them): logits always, dlogits when requested
         __syncthreads();
         for (int id = tid; id < S * D; id += NT) {
-            logits[(int64_t)s0 * D + id] = lg[id];
-            if (pk.dlogits) pk.dlogits[(int64_t)s0 * D + id] = dl[id];
+            logits[(int64_t)s0 * D + id] = lg_s[id];
+            if (dl) pk.dlogits[(int64_t)s0 * D + id] = dl_s[id];
         }
     }
     if (!do_bwd) return;
     __syncthreads();
-    head_bwd_set<NT>(hk, set, tid, dl, dparams, dstride, dQ, Gc, u, hs, wl_s, base, crow);
+    head_bwd_set<NT, MemL>(hk, set, tid, dl_s, dparams, dstride, dQ, Gc, u, hs, wl_s, s0, crow, pre, pre_w, pre_b, s0, s1, dbg);
+    HL_STAMP(6);
+#undef HL_STAMP
 }
 
 // Prototype path back into the support logits (prototype_c = mean of the class's first n rows).
@@ -983,6 +1132,7 @@ struct ClassTables {
     std::vector<int32_t> rows;          // concatenated per set: [Ct_t][n_t] subgraph ids
     std::vector<int32_t> tab;           // [sets*3]: offset into rows, Ct_t, n_t
     int Ct = 0, n = 0;                  // maxima over the sets (LDS sizing, prototype stride)
+    bool uniform = false;               // every set: Ct classes x n rows, stored at set * Ct * n
 };
 static int class_tables(const gm_batch* b, const int32_t* y, int limit, ClassTables& ct) {
     ct.rows.clear(); ct.tab.assign((size_t)b->sets * 3, 0); ct.Ct = 0; ct.n = 0;
@@ -1005,12 +1155,18 @@ static int class_tables(const gm_batch* b, const int32_t* y, int limit, ClassTab
         for (auto& kv : by) ct.rows.insert(ct.rows.end(), kv.second.begin(), kv.second.begin() + cnt);
     }
     GM_REQUIRE((int64_t)ct.Ct * ct.n <= 8192 && ct.Ct <= 256, GM_ERANGE, "proto loss: %d classes x %d rows per set is outside the kernel's range", ct.Ct, ct.n);
+    ct.uniform = true;
+    for (int t = 0; t < b->sets; ++t) ct.uniform = ct.uniform && ct.tab[t * 3] == t * ct.Ct * ct.n && ct.tab[t * 3 + 1] == ct.Ct && ct.tab[t * 3 + 2] == ct.n;
     return GM_OK;
 }
 
-static size_t proto_lds(int Ct, int n, int D, int nt = 256) { return sizeof(float) * ((size_t)Ct * D + (size_t)Ct * n + 2 * (size_t)nt); }
+static size_t proto_lds(int Ct, int n, int D, int nt = 256) {
+    const size_t a = (size_t)Ct * n * Ct;
+    return sizeof(float) * ((size_t)Ct * D + (size_t)Ct * n + 2 * (size_t)nt + (a <= PROTO_A_MAX ? a : 0));
+}
 
 static int launch_proto(const gm_batch* b, ProtoK k, hipStream_t st) {
+    GM_TRY(gm_func_full_lds((const void*)k_proto));
     hipLaunchKernelGGL(k_proto, dim3(b->sets), dim3(256), proto_lds(k.Ct, k.n, k.D), st, k);
     GM_HIP(hipGetLastError());
     return GM_OK;
@@ -1072,6 +1228,15 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
     return rc;
 }
 
+static unsigned long long* g_head_dbg = nullptr;
+// Phase timeline of k_head_loss (block 0, device constant clock): enable allocates 8 stamps that every later launch overwrites; out != NULL copies them
+extern "C" int gm_head_loss_debug(int32_t enable, unsigned long long* out) {
+    if (enable && !g_head_dbg) { GM_HIP(hipMalloc((void**)&g_head_dbg, 64)); GM_HIP(hipMemset(g_head_dbg, 0, 64)); }
+    if (out && g_head_dbg) GM_HIP(hipMemcpy(out, g_head_dbg, 64, hipMemcpyDeviceToHost));
+    if (!enable && g_head_dbg) { (void)hipFree(g_head_dbg); g_head_dbg = nullptr; }
+    return GM_OK;
+}
+
 // Head forward + loss (+ head backward) in one launch (k_head_loss) after a gcn_forward(..., skip_head = 1).  With
 // bwd != 0 the matching gcn_backward(..., skip_head = 1) continues from dQ_L / the compact G2 written here; c.sgd (if
 // set) makes the head's own parameters take their SGD step in the same launch.
@@ -1104,9 +1269,9 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     if (nt != 256 && nt != 512) nt = 1024;
     const SgdK sg = bwd ? c.sgd : SgdK{nullptr, 0, nullptr, 0, 0.f};
     gm_prof_begin(GM_PROF_HEAD, st, b->subs);
-    if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
-    else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
-    else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float))); }
+    if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
+    else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
+    else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
     GM_HIP(hipGetLastError());
     gm_prof_end(GM_PROF_HEAD, st);
     if (bwd && dQ && hk.dq_amax) c.dqv = true;
@@ -1222,6 +1387,7 @@ struct MetaPlan {
     unsigned *featb_s, *featb_q;                  // [T] each: per-task bound of the layer-1 operand (fp32 bit patterns; rides in the class-table copy)
     unsigned* viol;                               // the step's violation word (gm_bound.h), zeroed with the bound slots; NULL without two-piece kernels
     int Ct, ns, nq;
+    int uni_s = 0, uni_q = 0;                     // class layouts uniform over the tasks (ProtoK::uniform)
     unsigned* bound_ws; int64_t bound_words;      // gm_bound.h slots of this step ([S passes | Q passes | weights]), zeroed by ONE memset; NULL: three-piece kernels
 };
 
@@ -1345,6 +1511,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     GM_TRY(gm_make_layout(m, &Lu));
     GM_TRY(meta_plan(p, spt, qry, &mp, hp, ws, ws_bytes, Ct, ns, nq, nullptr));
     const gm_layout& L = p.L; const int T = p.T, C = L.n_out, K1 = K + 1; const int64_t Pp = p.Pp;
+    p.uni_s = cs.uniform ? 1 : 0; p.uni_q = cq.uniform ? 1 : 0;
     p.S.pd = p.Q.pd = p.Q2.pd = p.pd.base ? &p.pd : nullptr;
     if (shift) {
         hipLaunchKernelGGL(k_pad_params, dim3((int)std::min<int64_t>(512, (L.P + 255) / 256)), dim3(256), 0, st, theta, Lu.P, cut, shift, p.theta_p);
@@ -1433,7 +1600,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
     auto spt_step = [&](int k, const float* w, int64_t wstride, float* w_next) -> int {
         GM_TRY(gcn_forward(p.S, w, wstride, p.logit_s, st, hoist, 1, (sparse && sparse_bwd_ok(p.L)) ? 0 : 2));
         p.S.sgd = SgdK{w, wstride, w_next, Pp, hp->update_lr};
-        ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr, 0, p.tab_s};
+        ProtoK pk{p.logit_s, C, p.rows_s, Ct, ns, 0, nullptr, protos(k), p.ls, p.as_, K1, k, p.dlog_s, nullptr, 0, p.tab_s, p.uni_s};
         GM_TRY(head_loss(p.S, w, wstride, p.logit_s, pk, 1, p.g, Pp, sparse, st));
         return GM_OK;
     };
@@ -1454,7 +1621,7 @@ extern "C" int gm_meta_step(const gm_batch_t* spt, const gm_batch_t* qry, const 
         return gcn_forward(c, w, wstride, q_log(j), q_str(j), hoist, 1, fwd_only);
     };
     auto qry_loss = [&](int j, const float* w, int64_t wstride, int col, int kproto, bool grad) -> int {
-        ProtoK pk{q_log(j), C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q};
+        ProtoK pk{q_log(j), C, p.rows_q, Ct, nq, 1, protos(kproto), nullptr, p.lq, p.aq, K1, col, grad ? p.dlog_q : nullptr, grad ? p.dprotos : nullptr, 0, p.tab_q, p.uni_q};
         return head_loss(q_ctx(j), w, wstride, q_log(j), pk, grad ? 1 : 0, p.gq, Pp, sparse, q_str(j));
     };
     // ---- support step 0 (meta.py:122-126) on st ; query evaluations 0 and 1 (meta.py:129-141) on sq.  Host enqueue order matters at the

@@ -271,12 +271,15 @@ def test_fused_aggregate_gemm_is_bitwise_the_unfused_pass(world):
     """Forward passes nobody differentiates (the inner steps' query evaluations, finetunning's query passes) form the aggregate of rows
     with one or two sources inside the GEMM's operand feeders (k_gemm_split_p<true>) instead of writing Z through HBM: same fma order,
     so the whole meta-step -- accuracies, every loss, the meta-gradient -- and the finetunning accuracies are BITWISE those of the
-    unfused pass (learner.py:41-47 either way)."""
+    unfused pass (learner.py:41-47 either way) when that pass aggregates with the window kernel.  (The stream kernel, which takes the unfused full
+    launches of batches this size by default, sums a hub row's parts with another association: there the two agree to rounding -- last assertion.)"""
     from gmeta_amd import _lib
     lib = _lib.lib()
     b = world['batch']
     try:
         lib.gm_set_fuse_agg(0)
+        ms = _meta(world); as_, gs = _step(ms, b); ls = np.asarray(ms.last_stats['losses_q']).copy()      # unfused, stream kernel (the default)
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 0), 'set_tuning')
         m0 = _meta(world); a0, g0 = _step(m0, b); l0 = np.asarray(m0.last_stats['losses_q']).copy()
         f0 = np.asarray(m0.finetunning_batch(b[0], b[1], b[2], b[3]))
         lib.gm_set_fuse_agg(1)
@@ -285,8 +288,12 @@ def test_fused_aggregate_gemm_is_bitwise_the_unfused_pass(world):
         f1 = np.asarray(m1.finetunning_batch(b[0], b[1], b[2], b[3]))
     finally:
         lib.gm_set_fuse_agg(-1)
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 1), 'set_tuning')
     assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and torch.equal(g0, g1)
     assert np.array_equal(f0, f1)
+    np.testing.assert_allclose(as_, a1, atol=1e-6)
+    np.testing.assert_allclose(ls, l1, atol=2e-6, rtol=0)
+    assert float((gs - g1).abs().max()) <= 1e-5
 
 
 @pytest.mark.parametrize('tasks', [1, 3])
@@ -298,6 +305,7 @@ def test_fused_aggregate_gemm_bitwise_on_small_task_counts(world, tasks):
     b = world['db'].get_batch(list(range(tasks)))
     out = []
     try:
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 0), 'set_tuning')       # (bitwise against the window kernel's unfused pass: see the test above)
         for fuse in (0, 1):
             lib.gm_set_fuse_agg(fuse)
             m = _meta(world, serialize=1 if tasks == 1 else 0)
@@ -305,5 +313,6 @@ def test_fused_aggregate_gemm_bitwise_on_small_task_counts(world, tasks):
             out.append((a, g, np.asarray(m.last_stats['losses_q']).copy(), np.asarray(m.finetunning_batch(b[0], b[1], b[2], b[3]))))
     finally:
         lib.gm_set_fuse_agg(-1)
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 1), 'set_tuning')
     (a0, g0, l0, f0), (a1, g1, l1, f1) = out
     assert np.array_equal(a0, a1) and np.array_equal(l0, l1) and torch.equal(g0, g1) and np.array_equal(f0, f1)

@@ -251,3 +251,69 @@ def test_meta_step_with_and_without_the_stream_aggregate(arxiv4):
     np.testing.assert_allclose(res[1][0], res[0][0], atol=1e-6)
     np.testing.assert_allclose(res[1][1], res[0][1], atol=1e-5, rtol=0)
     np.testing.assert_allclose(res[1][2], res[0][2], atol=1e-5, rtol=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------- beside the other stream's GEMM
+@pytest.fixture(scope='module')
+def arxiv8():
+    import random
+    import gmeta_amd
+    from gmeta_amd import synth
+    np.random.seed(222); random.seed(222); torch.manual_seed(222)
+    args, cfg = synth.make_args('arxiv', task_num=8)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=8, args=args, adjs=store, h=cfg['h'],
+                             tables=data['tables'], verbose=False)
+    batch = db.get_batch(list(range(8)))
+    config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
+    return dict(args=args, cfg=cfg, data=data, store=store, batch=batch, config=config)
+
+
+def test_stream_aggregate_beside_the_split_gemm_is_bitwise_the_solo_launch(arxiv8):
+    """The stream kernel refills a ring slot right after reading it; the gather's LDS write must not pass that read.  Regression: with the persistent split GEMM
+    of the other stream saturating the CUs' LDS, ~1 launch in 500 over the 8-task support batch returned a hub row with 64-byte pieces of a later edge's source
+    row (no lgkmcnt wait between the read and the refill).  2,000 launches beside the GEMM, each bitwise the solo launch."""
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    S, Q = arxiv8['batch'][0][0].view_of, arxiv8['batch'][2][0].view_of
+    assert S.rows >= 32768                                  # the support batch has stream tables
+    W = (torch.randn(256, 256, device='cuda') * 0.05).contiguous()
+    xq = torch.randn(Q.rows, 256, device='cuda'); og = torch.empty(Q.rows, 256, device='cuda')
+    xs = torch.randn(S.rows, 256, device='cuda')
+    pn = C.c_void_p(); lib.gm_batch_device_ptr(S.handle, _lib.F_NORM, C.byref(pn))
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
+
+    def agg(out):
+        _lib.check(lib.gm_aggregate(S.handle, 0, 0, _lib.ptr(xs), 256, pn, None, _lib.ptr(out), C.c_void_p(sb.cuda_stream)), 'aggregate')
+
+    def gemm():
+        _lib.check(lib.gm_dense_update(Q.handle, _lib.ptr(xq), 256, _lib.ptr(W), 0, 256, _lib.ptr(og), 1, C.c_void_p(sa.cuda_stream)), 'dense_update')
+
+    _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM', 1), 'set_tuning')
+    ref = torch.empty(S.rows, 256, device='cuda'); agg(ref); torch.cuda.synchronize()
+    outs = [torch.empty(S.rows, 256, device='cuda') for _ in range(4)]
+    bad = 0
+    for rep in range(500):
+        for o in outs:
+            gemm(); agg(o)
+        gemm()
+        torch.cuda.synchronize()
+        bad += sum(0 if torch.equal(o, ref) else 1 for o in outs)
+    assert bad == 0, '%d of 2000 launches beside the GEMM differ from the solo launch' % bad
+
+
+def test_meta_step_with_both_batches_on_the_stream_kernel_is_reproducible(arxiv8):
+    """8-task arxiv shard, 3 inner steps (support AND query batch qualify for the stream kernel, the two streams of the step keep each other busy): 40 steps from
+    identical state give bitwise identical accuracies, losses and meta-gradient (the configuration that exposed the race above: 6 of 100 runs differed)."""
+    import argparse
+    import gmeta_amd
+    a = argparse.Namespace(**vars(arxiv8['args'])); a.update_step = 3
+    res = []
+    for _ in range(40):
+        torch.manual_seed(7)
+        m = gmeta_amd.Meta(a, arxiv8['config']).to('cuda')
+        accs = m(*arxiv8['batch'], None)
+        res.append((np.asarray(accs), np.asarray(m.last_stats['losses_q']), torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).clone()))
+    for acc, lq, g in res[1:]:
+        assert np.array_equal(acc, res[0][0]) and np.array_equal(lq, res[0][1]) and torch.equal(g, res[0][2])
