@@ -22,6 +22,7 @@ struct HeadK {
     const float* params; int64_t pstride; int64_t wl_off, bl_off; int hc, C; int subs;
     int compact;                                    // 1: H holds only the centre rows, [subs*nc, Hd] in centre order (cone schedule)
     unsigned* dq_amax;                              // optional [sets * GM_BOUND_PAD] (zeroed): receives max |dQ| written for the set (gm_bound.h)
+    int subs_per_set;                               // > 0: every set holds this many subgraphs (set t starts at t * subs_per_set: no load of set_sub_off ahead of everything else)
 };
 
 __device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) {
@@ -46,6 +47,12 @@ typedef __attribute__((address_space(3))) float lds_float;
 typedef __attribute__((address_space(3))) int lds_int;
 struct MemG { typedef float* F; typedef const float* CF; typedef const int32_t* CI; static constexpr bool lds = false; };
 struct MemL { typedef lds_float* F; typedef const lds_float* CF; typedef const lds_int* CI; static constexpr bool lds = true; };
+// Barrier between phases that exchange data through LDS only (MemL): lgkmcnt(0) + s_barrier.  __syncthreads() also drains the vector-memory counter, i.e.
+// it waits for the acknowledgement of every global STORE issued before it (the prototypes, the loss / accuracy, the phase stamps: ~1 us each) -- results nobody in
+// the block reads.  MemG exchanges the logits / dlogits through global memory and keeps the full barrier.
+template <typename M> __device__ __forceinline__ void block_sync() {
+    if constexpr (M::lds) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
+}
 
 // logits[s,:] = F.linear(cat(h[c0], h[c1]), Wl, bl)  (learner.py:165-175); one wave per subgraph, a 16-lane group per output class: four classes
 // are reduced at once with four shuffle steps (a wave-wide reduction per class was 6 dependent ds_bpermute round trips per logit).
@@ -237,7 +244,8 @@ __device__ __forceinline__ float sqdist(XP x, const lds_float* p, int D) {
 // logits / dlogits / rows: the arrays the set is scored on -- k's global ones (MemG; rows already offset to the set) or the fused kernel's LDS copies (MemL).
 #define PROTO_A_MAX 8192
 template <int NT, typename M>
-__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds_float* sm, typename M::CF logits, typename M::F dlogits, typename M::CI rows) {
+__device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds_float* sm, typename M::CF logits, typename M::F dlogits, typename M::CI rows,
+                                          bool have_proto = false, float proto_pre = 0.f) {      // have_proto: protos_in[set][tid] was loaded by the caller (tid < Ct * D)
     const int Ct = k.uniform ? k.Ct : k.tab[set * 3 + 1], n = k.uniform ? k.n : k.tab[set * 3 + 2];
     const int Q = Ct * n, D = k.D, rb = k.row_base;
     lds_float* protos = sm;             // [Ct*D]   (LDS sized for the largest set)
@@ -255,17 +263,17 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds
             p /= (float)n;                                                          // .mean(0) (meta.py:41)
             if (k.protos_out) k.protos_out[(int64_t)set * k.Ct * D + id] = p;
         } else {
-            p = k.protos_in[(int64_t)set * k.Ct * D + id];
+            p = (have_proto && id == tid) ? proto_pre : k.protos_in[(int64_t)set * k.Ct * D + id];
         }
         protos[id] = p;
     }
-    __syncthreads();
+    block_sync<M>();
     if (useA) {
         for (int id = tid; id < Q * Ct; id += NT) {
             const int q = id / Ct, c = id - q * Ct;
             A[id] = -sqdist(logits + (rows[q] - rb) * D, protos + c * D, D);      // -dists (meta.py:44-45)
         }
-        __syncthreads();
+        block_sync<M>();
     }
     float lpart = 0.f, apart = 0.f;
     for (int q = tid; q < Q; q += NT) {
@@ -295,7 +303,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds
     // block sum of (loss, correct): wave shuffles, then the first wave adds the NT / 64 wave partials (two barriers instead of log2 NT)
     lpart = wave_sumf(lpart); apart = wave_sumf(apart);
     if ((tid & 63) == 0) { red[tid >> 6] = lpart; red[NT + (tid >> 6)] = apart; }
-    __syncthreads();
+    block_sync<M>();
     if (tid < 64) {
         float l2 = tid < NT / 64 ? red[tid] : 0.f, a2 = tid < NT / 64 ? red[NT + tid] : 0.f;
         l2 = wave_sumf(l2); a2 = wave_sumf(a2);
@@ -312,7 +320,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds
             const int q = id / Ct, c = id - q * Ct;
             A[id] = (expf(A[id] - lse[q]) - (c == q / n ? 1.f : 0.f)) * invQ;
         }
-        __syncthreads();
+        block_sync<M>();
     }
     for (int id = tid; id < Q * D; id += NT) {
         const int q = id / D, d = id - q * D;
@@ -325,7 +333,7 @@ __device__ __forceinline__ void proto_set(const ProtoK& k, int set, int tid, lds
         }
         dlogits[(rows[q] - rb) * D + d] = s;
     }
-    __syncthreads();
+    block_sync<M>();
     for (int id = tid; id < Ct * D; id += NT) {
         const int c = id / D, d = id - c * D;
         const float pd = protos[id];
@@ -366,7 +374,8 @@ __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, Proto
     const int set = blockIdx.x, tid = threadIdx.x;
 #define HL_STAMP(K) do { if (dbg && set == 0 && tid == 0) dbg[K] = wall_clock64(); } while (0)      // phase timeline of block 0 (tools/head_loss_probe.py)
     HL_STAMP(0);
-    const int s0 = hk.set_sub_off[set], s1 = hk.set_sub_off[set + 1], S = s1 - s0, D = pk.D;
+    const long long cyc0 = dbg ? clock64() : 0;      // shader-clock cycles next to the constant-clock stamps: stamp 7 = cycles spent (what clock the probe ran at)
+    const int s0 = hk.subs_per_set ? set * hk.subs_per_set : hk.set_sub_off[set], s1 = hk.subs_per_set ? s0 + hk.subs_per_set : hk.set_sub_off[set + 1], S = s1 - s0, D = pk.D;
     // the head's own SGD inputs (w - lr * g, meta.py:126,151) go out with the first round trip instead of behind the loss
     const bool pre = do_bwd && u.next != nullptr;
     float pre_w = 0.f, pre_b = 0.f;
@@ -374,6 +383,10 @@ __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, Proto
         if (tid < hk.C * hk.hc) pre_w = u.cur[(int64_t)set * u.cur_stride + hk.wl_off + tid];
         if (tid < hk.C) pre_b = u.cur[(int64_t)set * u.cur_stride + hk.bl_off + tid];
     }
+    // ... and so do the prototypes a query loss is scored against (mode 1; uniform class layout: the set's are at set * Ct * D)
+    const bool have_proto = stage && pk.mode == 1 && pk.uniform && pk.Ct * D <= NT;
+    float proto_pre = 0.f;
+    if (have_proto && tid < pk.Ct * D) proto_pre = pk.protos_in[(int64_t)set * pk.Ct * D + tid];
     if (!stage) {
         // everything in the global arrays (sets too large for LDS): the three phases with L2 round trips in between
         if (pk.dlogits) for (int id = tid; id < S * D; id += NT) pk.dlogits[(int64_t)s0 * D + id] = 0.f;   // rows outside the class tables
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, Proto
     }
     for (int id = tid; id < hk.C * hk.hc; id += NT) wl_s[id] = P[hk.wl_off + id];
     for (int id = tid; id < hk.C; id += NT) wl_s[hk.C * hk.hc + id] = P[hk.bl_off + id];
-    __syncthreads();
+    block_sync<MemL>();
     HL_STAMP(1);
     // second round trip: the centre rows of H_L, all loads of a thread in flight together (16-byte loads when the rows allow it).  (The first version was a
     // serial chain of 18 dependent global loads per thread.)
@@ -439,26 +452,27 @@ __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, Proto
     }
     lds_float* dl = pk.dlogits ? dl_s : nullptr;        // (pk.dlogits only says WHETHER the gradient is wanted; the global array is written with copy_out)
     if (dl) for (int id = tid; id < S * D; id += NT) dl_s[id] = 0.f;
-    __syncthreads();
+    block_sync<MemL>();
     HL_STAMP(2);
     for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub<MemL>(hk, s, tid & 63, lg_s, hs, s0, wl_s, s0);
-    __syncthreads();
+    block_sync<MemL>();
     HL_STAMP(3);
     ProtoK pl = pk;
     pl.row_base = s0;                                   // the LDS copies hold the set's subgraphs only
-    proto_set<NT, MemL>(pl, set, tid, sm, lg_s, dl, rows_l);
+    proto_set<NT, MemL>(pl, set, tid, sm, lg_s, dl, rows_l, have_proto, proto_pre);
     HL_STAMP(4);
     if (copy_out) {  // the global copies (the public gm_proto_loss_* shape; nobody inside gm_meta_step reads them): logits always, dlogits when requested
-        __syncthreads();
+        block_sync<MemL>();
         for (int id = tid; id < S * D; id += NT) {
             logits[(int64_t)s0 * D + id] = lg_s[id];
             if (dl) pk.dlogits[(int64_t)s0 * D + id] = dl_s[id];
         }
     }
     if (!do_bwd) return;
-    __syncthreads();
+    block_sync<MemL>();
     head_bwd_set<NT, MemL>(hk, set, tid, dl_s, dparams, dstride, dQ, Gc, u, hs, wl_s, s0, crow, pre, pre_w, pre_b, s0, s1, dbg);
     HL_STAMP(6);
+    if (dbg && set == 0 && tid == 0) dbg[7] = (unsigned long long)(clock64() - cyc0);
 #undef HL_STAMP
 }
 
@@ -708,6 +722,8 @@ static HeadK make_head(const GcnCtx& c, const float* params, int64_t pstride) {
     k.set_sub_off = b->d_set_sub_off; k.params = params; k.pstride = pstride; k.wl_off = L.wl_off; k.bl_off = L.bl_off;
     k.hc = L.hc; k.C = L.n_out; k.subs = b->subs; k.compact = c.cone ? 1 : 0;
     k.dq_amax = (c.np == 2 && c.am_pass >= 0) ? c.amdQ() : nullptr;
+    k.subs_per_set = b->sets > 0 ? b->subs / b->sets : 0;
+    for (int t = 0; t <= b->sets && k.subs_per_set; ++t) if (b->h_set_sub_off[t] != t * k.subs_per_set) k.subs_per_set = 0;
     return k;
 }
 
