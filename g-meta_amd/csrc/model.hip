@@ -454,7 +454,9 @@ __global__ __launch_bounds__(NT) void k_head_loss(HeadK hk, float* logits, Proto
     if (dl) for (int id = tid; id < S * D; id += NT) dl_s[id] = 0.f;
     block_sync<MemL>();
     HL_STAMP(2);
+    if (dbg && set == 0 && (tid & 63) == 0) dbg[8 + (tid >> 6)] = wall_clock64();
     for (int s = s0 + (tid >> 6); s < s1; s += NT / 64) head_fwd_sub<MemL>(hk, s, tid & 63, lg_s, hs, s0, wl_s, s0);
+    if (dbg && set == 0 && (tid & 63) == 0) dbg[24 + (tid >> 6)] = wall_clock64();      // per-wave start / end of the logits phase
     block_sync<MemL>();
     HL_STAMP(3);
     ProtoK pl = pk;
@@ -1247,8 +1249,8 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
 static unsigned long long* g_head_dbg = nullptr;
 // Phase timeline of k_head_loss (block 0, device constant clock): enable allocates 8 stamps that every later launch overwrites; out != NULL copies them
 extern "C" int gm_head_loss_debug(int32_t enable, unsigned long long* out) {
-    if (enable && !g_head_dbg) { GM_HIP(hipMalloc((void**)&g_head_dbg, 64)); GM_HIP(hipMemset(g_head_dbg, 0, 64)); }
-    if (out && g_head_dbg) GM_HIP(hipMemcpy(out, g_head_dbg, 64, hipMemcpyDeviceToHost));
+    if (enable && !g_head_dbg) { GM_HIP(hipMalloc((void**)&g_head_dbg, 512)); GM_HIP(hipMemset(g_head_dbg, 0, 512)); }
+    if (out && g_head_dbg) GM_HIP(hipMemcpy(out, g_head_dbg, 512, hipMemcpyDeviceToHost));
     if (!enable && g_head_dbg) { (void)hipFree(g_head_dbg); g_head_dbg = nullptr; }
     return GM_OK;
 }
@@ -1288,6 +1290,11 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
     else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
     else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
+    {   // probe only (tools/head_loss_probe.py): the same launch again -- it is idempotent -- to see what a warm instruction cache / warm L2 is worth
+        static const int twice = getenv("GM_HEAD_TWICE") ? atoi(getenv("GM_HEAD_TWICE")) : 0;
+        if (twice && nt != 256 && nt != 512)
+            hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg);
+    }
     GM_HIP(hipGetLastError());
     gm_prof_end(GM_PROF_HEAD, st);
     if (bwd && dQ && hk.dq_amax) c.dqv = true;

@@ -268,7 +268,7 @@ int gm_debug_stamp(void* out, void* stream);
 /* ... and of the stream aggregate kernel (agg_stream.hip): enable != 0 makes every later launch stamp the start / end clock of each of its workgroups
  * (2 x uint64 per workgroup) into a device buffer of n entries; out != NULL copies that buffer to the host; enable == 0 releases it. */
 int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t n);
-/* ... and of k_head_loss: eight phase stamps of block 0 of the LAST launch (start, first round trip, centre rows staged, logits, loss, backward). */
+/* ... and of k_head_loss: 64 stamps of block 0 of the LAST launch (phases 0-6, shader cycles in 7, per-wave start / end of the logits phase in 8-23 / 24-39). */
 int gm_head_loss_debug(int32_t enable, unsigned long long* out);
 
 #ifdef __cplusplus

@@ -32,8 +32,10 @@ lib.gm_head_loss_debug(1, None)
 m.serialize = 1
 for rep in range(3):
     m(*b, data['feats']); torch.cuda.synchronize()
-    st = np.zeros(8, np.uint64)
+    st = np.zeros(64, np.uint64)
     lib.gm_head_loss_debug(1, st.ctypes.data_as(C.c_void_p))
     s = st.astype(np.int64)
     print('%s last k_head_loss launch (the differentiated query loss), block 0, us since its first instruction: loads 1 %.2f | centre rows %.2f | logits %.2f | loss %.2f | head weight gradients %.2f | dQ rows %.2f   (%d shader cycles: %.0f MHz)'
           % (name, *((s[k] - s[0]) / 100.0 for k in (1, 2, 3, 4, 5, 6)), s[7], s[7] / max(1e-9, (s[6] - s[0]) / 100.0)))
+    if rep == 2:
+        print('    logits phase per wave, start / end (us): ' + ' '.join('%.2f/%.2f' % ((s[8 + w] - s[0]) / 100.0, (s[24 + w] - s[0]) / 100.0) for w in range(16)))
