@@ -513,6 +513,23 @@ def main():
     mm = ov_mm if a.serialize else {c: [0.0, 0, 0] for c in MM_CATS}    # [ms, launches, flops] of the GEMM / weight-gradient launches (serialised steps)
     ser_steps = a.steps if a.serialize else 0
     one_stream_ms = None
+    deferred_ms = None
+    if not a.serialize and not a.defer and a.roofline_steps > 0:
+        # the same steps with the accuracies of step k read after step k + 1 is queued (Meta.forward_deferred -- what train.py does between its report
+        # steps): the host prologue of a step then runs while the GPU still works on the previous one.  `value` keeps the reference's calling
+        # convention (Meta.forward returns the accuracies of every step).
+        nd = max(4, min(a.steps, 50))
+        pend = [maml.forward_deferred(*batches[0][:4])]
+        pend.pop(0).accs()
+        torch.cuda.synchronize(); te = time.perf_counter()
+        for k in range(nd):
+            pend.append(maml.forward_deferred(*batches[k % a.n_batches][:4]))
+            if len(pend) > 1:
+                pend.pop(0).accs()
+        while pend:
+            pend.pop(0).accs()
+        torch.cuda.synchronize()
+        deferred_ms = (time.perf_counter() - te) / nd * 1e3
     if not a.serialize and a.roofline_steps > 0:            # every rank takes part: Meta.forward all-reduces when N > 1
         # the same step on ONE stream (no events): what the two queues buy -- kernels of the support chain and of the query evaluations side by side,
         # the stream aggregate's workgroups inside the CUs a persistent GEMM workgroup of the other queue occupies
@@ -860,6 +877,10 @@ def main():
                                  'what': 'the same step with the query evaluations on the support chain\'s stream; the difference is what side-by-side execution buys. '
                                          'A persistent split-GEMM workgroup owns 480 of the 512 VGPRs of each SIMD lane and 101 KiB of LDS: only a kernel of <= 32 VGPRs '
                                          'and <= 59 KiB starts beside it (profiles/r05_coreside_micro.log) -- the stream aggregate (30 VGPRs, 52 KiB) is built to that budget'}
+        if deferred_ms:
+            out['deferred_readback'] = {'ms_per_step': round(deferred_ms, 3), 'meta_tasks_per_s': round(cfg['task_num'] / deferred_ms * 1e3, 1),
+                                        'what': 'Meta.forward_deferred: the accuracies of step k are read after step k + 1 is queued (train.py between report steps); every step does '
+                                                'all of its work, the host prologue of a step overlaps the previous step on the GPU.  Not `value`: the reference returns the accuracies every step'}
         if allreduce:
             out['allreduce'] = allreduce
         if rank_report:

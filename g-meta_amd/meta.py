@@ -50,7 +50,7 @@ class Meta(nn.Module):
         self._flat_theta_buf = None
         self._found_inf = None
 
-    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring', '_unchecked', '_adam_m', '_adam_v', '_adam_steps', '_adam_ticket')      # device caches / ctypes handles: never copied
+    _TRANSIENT = ('_keep', '_ws', '_flat_grad', '_flat_theta_buf', '_found_inf', '_sizes', '_hp', '_rb_ring', '_unchecked', '_adam_m', '_adam_v', '_adam_steps', '_adam_ticket', '_plist')      # device caches / ctypes handles: never copied
 
     def __deepcopy__(self, memo):
         """train.py:87,127 deep-copies the Meta object (best-model snapshot); parameters, buffers and the optimiser
@@ -80,11 +80,21 @@ class Meta(nn.Module):
             self.meta_optim = self._make_adam()
         return r
 
+    def _params(self):
+        """The Parameter objects of the learner as a plain list.  Iterating / indexing an nn.ParameterList goes through string keys (~2 us per access:
+        26 accesses per meta-step were 50 us of the host prologue, during which the GPU sits idle); the list is rebuilt when the ParameterList
+        object or its length changes (nothing else replaces the Parameter objects: .to() / load_state_dict swap their .data in place)."""
+        pl = self.net.parameters()
+        c = getattr(self, '_plist', None)
+        if c is None or c[0] is not pl or c[1] != len(pl):
+            c = self._plist = (pl, len(pl), list(pl))
+        return c[2]
+
     def _bind_flat(self, attr, dev, grads):
         """Every parameter (grads=False) or its .grad (grads=True) is a view into ONE flat fp32 buffer: the kernels read
         theta / write the meta-gradient without a gather or scatter launch.  Re-bound whenever something (deepcopy, .to(),
         zero_grad(set_to_none), load_state_dict on fresh tensors) broke the aliasing; values are preserved."""
-        params = list(self.net.parameters())
+        params = self._params()
         P = sum(p.numel() for p in params)
         buf = getattr(self, attr, None)
         ok = buf is not None and buf.numel() == P and buf.device == dev
@@ -116,7 +126,7 @@ class Meta(nn.Module):
         the flat parameter vector, so that gm_meta_finish_adam updates them in place and meta_optim (state_dict, deepcopy, a later plain
         meta_optim.step()) keeps seeing the true state.  Re-bound -- values preserved -- whenever something broke the aliasing (deepcopy,
         load_state_dict, .to())."""
-        params = list(self.net.parameters())
+        params = self._params()
         P = sum(p.numel() for p in params)
         st = self.meta_optim.state
         m_, v_, steps = getattr(self, '_adam_m', None), getattr(self, '_adam_v', None), getattr(self, '_adam_steps', None)
@@ -150,7 +160,7 @@ class Meta(nn.Module):
         return self._bind_flat('_flat_grad', dev, True)
 
     def _flat_theta(self):
-        p0 = self.net.parameters()[0]
+        p0 = self._params()[0]
         if not p0.is_cuda:
             return torch.cat([p.detach().reshape(-1) for p in self.net.parameters()]).contiguous()
         return self._bind_flat('_flat_theta_buf', p0.device, False)
