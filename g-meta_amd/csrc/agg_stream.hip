@@ -279,19 +279,28 @@ __global__ void k_stream_bounds(const int32_t* indptr, int64_t rows, const int32
     const bool prev_is_hub = r > 0 && lo > 0 && hubs[lo - 1] == r - 1;
     sptr[r] = (indptr[r] - cum[lo]) | (prev_is_hub ? (int)0x80000000 : 0);
 }
-// sources / weights of every edge at its stream position: one thread per row below the hub threshold, one 64-thread block per hub row (up to ~1000
-// edges each, copied behind the row-ordered part at e_norm + cum[hub])
-__global__ void k_stream_edges(const int32_t* indptr, const int32_t* sptr, int64_t rows, const int32_t* src, const int32_t* src2, const float* wgt,
-                               int32_t* su, int32_t* su2, float* sw) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows || sptr[r + 1] < 0) return;
-    const int p0 = indptr[r], n = indptr[r + 1] - p0, o = sptr[r] & 0x7fffffff;
-    for (int j = 0; j < n; ++j) { su[o + j] = src[p0 + j]; if (su2) su2[o + j] = src2[p0 + j]; sw[o + j] = wgt ? wgt[p0 + j] : 1.f; }
+// sources / weights of every edge at its stream position, one thread per EDGE: the stream order is the CSR order with the hub rows' edges taken out and
+// appended (hub by hub) behind the rest, so an edge's position follows from the hub rows that start at or before it -- a binary search over the hub rows'
+// edge ranges (hub_lo / hub_hi: a few thousand entries, cache-resident).  Coalesced reads and writes: 26-35 us for the 2.4 M edges of a query batch, where a
+// thread per ROW copying its edges one after the other (a dependent chain per thread) took 190-380 us -- twice the extraction kernels' own time per batch.
+__global__ void k_stream_hub_ranges(const int32_t* indptr, const int32_t* hubs, int n_hubs, int32_t* hub_lo, int32_t* hub_hi) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_hubs) return;
+    const int r = hubs[k];
+    hub_lo[k] = indptr[r]; hub_hi[k] = indptr[r + 1];
 }
-__global__ __launch_bounds__(64) void k_stream_hub_edges(const int32_t* indptr, const int32_t* hubs, const int32_t* cum, int e_norm, const int32_t* src, const int32_t* src2,
-                                                         const float* wgt, int32_t* su, int32_t* su2, float* sw) {
-    const int h = blockIdx.x, r = hubs[h], p0 = indptr[r], n = indptr[r + 1] - p0, o = e_norm + cum[h];
-    for (int j = threadIdx.x; j < n; j += 64) { su[o + j] = src[p0 + j]; if (su2) su2[o + j] = src2[p0 + j]; sw[o + j] = wgt ? wgt[p0 + j] : 1.f; }
+__global__ void k_stream_edges(int64_t edges, const int32_t* hub_lo, const int32_t* hub_hi, const int32_t* cum, int n_hubs, int e_norm, const int32_t* src,
+                               const int32_t* src2, const float* wgt, int32_t* su, int32_t* su2, float* sw) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= edges) return;
+    int lo = 0, hi = n_hubs;                                                  // hub rows whose first edge is at or before e
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (hub_lo[mid] <= e) lo = mid + 1; else hi = mid; }
+    int64_t pos;
+    if (lo > 0 && e < hub_hi[lo - 1]) pos = (int64_t)e_norm + cum[lo - 1] + (e - hub_lo[lo - 1]);      // an edge of hub lo - 1
+    else pos = e - cum[lo];                                                   // lo hub rows lie entirely before e
+    su[pos] = src[e];
+    if (su2) su2[pos] = src2[e];
+    sw[pos] = wgt ? wgt[e] : 1.f;
 }
 // Wave segments: segment k starts at the first row whose cost prefix (stream edges + rows before it) reaches k / n_seg of the total
 __global__ void k_stream_segs(const int32_t* sptr, int64_t rows, int n_seg, int2* seg) {
@@ -346,11 +355,11 @@ int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t
     GM_TRY(gm_balloc(b, &b->d_su[o], n_ed, s)); GM_TRY(gm_balloc(b, &b->d_sw[o], n_ed, s));
     const bool feat = o == 0 && b->d_efeat;                         // layer 1 gathers rows of the store's feature table
     if (feat) GM_TRY(gm_balloc(b, &b->d_su_feat, n_ed, s));
-    hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, indptr, b->d_sptr[o], (int64_t)b->rows,
+    int32_t* d_hlo = nullptr; int32_t* d_hhi = nullptr;
+    GM_TRY(gm_balloc(b, &d_hlo, (size_t)std::max(n_hubs, 1), s)); GM_TRY(gm_balloc(b, &d_hhi, (size_t)std::max(n_hubs, 1), s));
+    if (n_hubs > 0) hipLaunchKernelGGL(k_stream_hub_ranges, dim3((n_hubs + 255) / 256), dim3(256), 0, s, indptr, d_hubs, n_hubs, d_hlo, d_hhi);
+    hipLaunchKernelGGL(k_stream_edges, dim3((unsigned)((b->edges + 255) / 256)), dim3(256), 0, s, (int64_t)b->edges, d_hlo, d_hhi, b->d_scum[o], n_hubs, e_norm,
                        o ? b->d_indices_t : b->d_indices, feat ? b->d_efeat : nullptr, b->d_enorm[o], b->d_su[o], feat ? b->d_su_feat : nullptr, b->d_sw[o]);
-    if (n_hubs > 0)
-        hipLaunchKernelGGL(k_stream_hub_edges, dim3(n_hubs), dim3(64), 0, s, indptr, d_hubs, b->d_scum[o], e_norm, o ? b->d_indices_t : b->d_indices, feat ? b->d_efeat : nullptr,
-                           b->d_enorm[o], b->d_su[o], feat ? b->d_su_feat : nullptr, b->d_sw[o]);
     // workgroups: the hub parts' share of the launch by their share of its work (in whole XCD rounds), the rest for the row segments
     const int nwg = gm_stream_wgs(b->edges + b->rows);
     int hub_wgs = 0;
