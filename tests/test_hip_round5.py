@@ -317,3 +317,72 @@ def test_meta_step_with_both_batches_on_the_stream_kernel_is_reproducible(arxiv8
         res.append((np.asarray(accs), np.asarray(m.last_stats['losses_q']), torch.cat([p.grad.reshape(-1) for p in m.net.parameters()]).clone()))
     for acc, lq, g in res[1:]:
         assert np.array_equal(acc, res[0][0]) and np.array_equal(lq, res[0][1]) and torch.equal(g, res[0][2])
+
+
+# ---------------------------------------------------------------------------------------------------------------- k_head_loss: every variant of the kernel
+@pytest.mark.parametrize('case', ['g1_sampled_h2', 'g3_linkpred', 'g8_wide_scales'])
+def test_head_loss_kernel_variants_are_bitwise_the_default(case):
+    """k_head_loss has a staged (LDS, typed pointers) and an unstaged (global arrays) instantiation and three workgroup sizes; the unfused per-phase kernels
+    (k_head_fwd / k_proto / k_head_bwd) share the phase code.  All keep ONE association (model.hip: head_fwd_sub), so a golden fixture's meta-step -- accuracies,
+    losses, meta-gradient, updated weights -- is bitwise the same through every one of them, and equal to the reference's golden values (default schedule)."""
+    import hip_util as hu
+    from test_hip_parity import Fixture, TOL
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    fx = Fixture(case)
+    base = hu.hip_meta_step(fx, replay=True)
+    ref_g = np.concatenate([g.reshape(-1) for g in fx.grad])
+    np.testing.assert_allclose(base['grad'], ref_g, atol=TOL, rtol=0)
+    try:
+        for knob, val in ((b'GM_HEAD_STAGE', 0), (b'GM_HEAD_THREADS', 256), (b'GM_HEAD_THREADS', 512)):
+            _lib.check(lib.gm_set_tuning(knob, val), 'set_tuning')
+            r = hu.hip_meta_step(fx, replay=True)
+            _lib.check(lib.gm_set_tuning(knob, 1 if knob == b'GM_HEAD_STAGE' else 0), 'set_tuning')
+            assert np.array_equal(np.asarray(r['accs']), np.asarray(base['accs'])), (knob, val)
+            assert np.array_equal(np.asarray(r['stats']['losses_q']), np.asarray(base['stats']['losses_q'])), (knob, val)
+            assert np.array_equal(r['grad'], base['grad']), (knob, val)
+            for a, b in zip(r['vars1'], base['vars1']):
+                assert np.array_equal(a, b), (knob, val)
+    finally:
+        lib.gm_set_tuning(b'GM_HEAD_STAGE', 1); lib.gm_set_tuning(b'GM_HEAD_THREADS', 0)
+
+
+def test_proto_losses_with_many_classes_match_oracle():
+    """proto_loss_spt / proto_loss_qry (meta.py:28-79) with 24 classes per task: 16 query rows per class make the loss kernel's distance / softmax matrix
+    (Q x Ct = 9,216 floats) larger than its LDS budget, so the query loss recomputes the terms per use (the path small class counts never take), the support loss
+    (Ct x n x Ct = 1,152) keeps the matrix.  Both against the oracle, through the per-phase C entry points."""
+    import random
+    import gmeta_oracle as orc
+    import gmeta_amd
+    from gmeta_amd import _lib, synth
+    np.random.seed(5); random.seed(5)
+    Ct, ks, kq, T, D = 24, 2, 16, 2, 24
+    args, cfg = synth.make_args('syn0', n_way=Ct, k_spt=ks, k_qry=kq, task_num=T, classes=40, n=6000)
+    data = synth.make_dataset(cfg)
+    store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+    db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=Ct, k_shot=ks, k_query=kq, batchsz=T, args=args, adjs=store, h=cfg['h'], tables=data['tables'], verbose=False)
+    b = db.get_batch(list(range(T)))
+    S, Q = b[0][0].view_of, b[2][0].view_of
+    ys = np.concatenate([np.asarray(y).reshape(-1) for y in b[1]]).astype(np.int32); yq = np.concatenate([np.asarray(y).reshape(-1) for y in b[3]]).astype(np.int32)
+    assert S.subs == T * Ct * ks and Q.subs == T * Ct * kq and Ct * kq * Ct > 8192
+    rng = np.random.default_rng(1)
+    ls, lq = rng.standard_normal((S.subs, D)).astype(np.float32), rng.standard_normal((Q.subs, D)).astype(np.float32)
+    lib = _lib.lib()
+    dls, dlq = torch.from_numpy(ls).cuda(), torch.from_numpy(lq).cuda()
+    loss, acc = torch.empty(T, device='cuda'), torch.empty(T, device='cuda')
+    protos = torch.empty(T, Ct, D, device='cuda'); dl = torch.empty(S.subs, D, device='cuda')
+    _lib.check(lib.gm_proto_loss_spt(S.handle, _lib.ptr(dls), D, _lib.ptr(ys), ks, _lib.ptr(loss), _lib.ptr(acc), _lib.ptr(protos), _lib.ptr(dl), _lib.stream_ptr()))
+    lossq, accq = torch.empty(T, device='cuda'), torch.empty(T, device='cuda')
+    dq = torch.empty(Q.subs, D, device='cuda'); dp = torch.empty(T, Ct, D, device='cuda')
+    _lib.check(lib.gm_proto_loss_qry(Q.handle, _lib.ptr(dlq), D, _lib.ptr(yq), _lib.ptr(protos), Ct, _lib.ptr(lossq), _lib.ptr(accq), _lib.ptr(dq), _lib.ptr(dp), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    Ss, Sq = S.subs // T, Q.subs // T
+    for t in range(T):
+        l, ac, pr, g = orc.proto_loss_spt(ls[t * Ss:(t + 1) * Ss], ys[t * Ss:(t + 1) * Ss], ks)
+        np.testing.assert_allclose(loss[t].item(), l, atol=1e-5); np.testing.assert_allclose(acc[t].item(), ac, atol=1e-6)
+        np.testing.assert_allclose(protos[t].cpu().numpy(), pr, atol=1e-6)
+        np.testing.assert_allclose(dl[t * Ss:(t + 1) * Ss].cpu().numpy(), g, atol=1e-5)
+        l2, ac2, g2, p2 = orc.proto_loss_qry(lq[t * Sq:(t + 1) * Sq], yq[t * Sq:(t + 1) * Sq], pr, need_grad=True)
+        np.testing.assert_allclose(lossq[t].item(), l2, atol=1e-5); np.testing.assert_allclose(accq[t].item(), ac2, atol=1e-6)
+        np.testing.assert_allclose(dq[t * Sq:(t + 1) * Sq].cpu().numpy(), g2, atol=1e-5)
+        np.testing.assert_allclose(dp[t].cpu().numpy(), p2, atol=1e-5)
