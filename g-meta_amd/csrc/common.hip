@@ -279,7 +279,7 @@ const gm_knobs& gm_knob() {
         k.cu_mask_support = env("GM_CU_MASK_SUPPORT", 0);
         k.wgrad_split_min_chunks = env("GM_WGRAD_SPLIT_MIN_CHUNKS", -1);
         k.agg_stream = env("GM_AGG_STREAM", 1);
-        k.agg_stream_min_rows = env("GM_AGG_STREAM_MIN_ROWS", 32768);
+        k.agg_stream_min_rows = env("GM_AGG_STREAM_MIN_ROWS", 100000);
         k.agg_stream_wgs = env("GM_AGG_STREAM_WGS", 0);
         k.agg_stream_cost = env("GM_AGG_STREAM_COST", 96);
         k.agg_stream_gather = env("GM_AGG_STREAM_GATHER", 1);

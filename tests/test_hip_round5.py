@@ -192,7 +192,7 @@ def test_stream_aggregate_matches_oracle_and_window_kernel(arxiv4, width, transp
     from gmeta_amd import _lib
     lib = _lib.lib()
     Q = arxiv4['Q']
-    assert Q.rows >= 32768
+    assert Q.rows >= 100000
     ptr, idx = (np.asarray(a) for a in Q.csr()[:2])
     n = Q.rows
     deg_in = np.diff(ptr)
@@ -259,13 +259,22 @@ def arxiv8():
     import random
     import gmeta_amd
     from gmeta_amd import synth
+    from gmeta_amd import _lib
     np.random.seed(222); random.seed(222); torch.manual_seed(222)
     args, cfg = synth.make_args('arxiv', task_num=8)
     data = synth.make_dataset(cfg)
     store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
     db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=cfg['n_way'], k_shot=cfg['k_spt'], k_query=cfg['k_qry'], batchsz=8, args=args, adjs=store, h=cfg['h'],
                              tables=data['tables'], verbose=False)
-    batch = db.get_batch(list(range(8)))
+    # the 34 k-row support batch gets stream tables too (the default threshold is 100,000 rows: these tests want BOTH batches of a step on the stream kernel,
+    # with the small, hub-heavy launches that exposed the race)
+    lib = _lib.lib()
+    prev = lib.gm_get_tuning(b'GM_AGG_STREAM_MIN_ROWS')
+    _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM_MIN_ROWS', 32768), 'set_tuning')
+    try:
+        batch = db.get_batch(list(range(8)))
+    finally:
+        _lib.check(lib.gm_set_tuning(b'GM_AGG_STREAM_MIN_ROWS', prev), 'set_tuning')
     config = synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])
     return dict(args=args, cfg=cfg, data=data, store=store, batch=batch, config=config)
 
