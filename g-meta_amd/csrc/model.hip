@@ -29,12 +29,6 @@ __device__ __forceinline__ int64_t centre_row(const HeadK& k, int s, int which) 
     return k.compact ? (int64_t)s * k.nc + which : (int64_t)k.sub_off[s] + k.centre[s * k.nc + which];
 }
 
-// Row of the last GCN activation at centre `which` of subgraph s: from the LDS copy hs (rows of the set starting at
-// subgraph s0, centre order) when the fused kernel staged one, else from H.
-__device__ __forceinline__ const float* centre_feat(const HeadK& k, int s, int which, const float* hs, int s0) {
-    return hs ? hs + ((int64_t)(s - s0) * k.nc + which) * k.Hd : k.H + centre_row(k, s, which) * k.ldh;
-}
-
 // Optional fused inner-loop SGD (meta.py:126,151): next_t[j] = cur_t[j] - lr * grad_t[j], written with the gradient.
 struct SgdK { const float* cur; int64_t cur_stride; float* next; int64_t next_stride; float lr; };
 
