@@ -67,6 +67,9 @@ PROTOTYPES = {
     'gm_profile_aggregate': (C.c_int, [vp, vp, vp]),
     'gm_profile_read': (C.c_int, [i32, vp, vp, vp]),
     'gm_profile_read_launches': (C.c_int, [i32, vp, vp, i32]),
+}
+# include/gmeta_hip_probes.h: exported only by the probe build (build.py --probes -> libgmeta_hip_probes.so, loaded through GMETA_HIP_LIB by tools/)
+PROBE_PROTOTYPES = {
     'gm_debug_stamp': (C.c_int, [vp, vp]),
     'gm_stream_debug': (C.c_int, [i32, vp, i32]),
     'gm_head_loss_debug': (C.c_int, [i32, vp]),
@@ -86,6 +89,10 @@ def lib():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(l, name)           # AttributeError if a declared symbol is not exported
             fn.restype, fn.argtypes = res, args
+        for name, (res, args) in PROBE_PROTOTYPES.items():
+            if hasattr(l, name):            # the probe build only
+                fn = getattr(l, name)
+                fn.restype, fn.argtypes = res, args
         _lib = l
     return _lib
 

@@ -26,18 +26,21 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, probes=False):
+    """probes=True: the same sources with -DGM_PROBES -> libgmeta_hip_probes.so (include/gmeta_hip_probes.h; tools/ only, never the product path)."""
     hipcc = _hipcc()
-    objdir = os.path.join(CSRC, 'build')
+    objdir = os.path.join(CSRC, 'build', 'probes') if probes else os.path.join(CSRC, 'build')
+    out = os.path.join(HERE, 'libgmeta_hip_probes.so') if probes else OUT
+    flags = FLAGS + (['-DGM_PROBES'] if probes else [])
     os.makedirs(objdir, exist_ok=True)
     # every header a translation unit can include: editing any of them (gemm_split.h is only included by gemm.hip) rebuilds the objects
-    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', 'gmeta_hip.h')]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + [os.path.join(HERE, '..', 'include', f) for f in ('gmeta_hip.h', 'gmeta_hip_probes.h')]
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace('.hip', '.o'))
         if force or _newer(obj, [src] + headers):
-            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([hipcc] + flags + ['-c', src, '-o', obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -50,10 +53,10 @@ def build(force=False, verbose=True):
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s.replace('.hip', '.o')) for s in SOURCES]
-    if force or jobs or _newer(OUT, objs):
-        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
-    return OUT
+    if force or jobs or _newer(out, objs):
+        run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    print(build(force='--force' in sys.argv, probes='--probes' in sys.argv))

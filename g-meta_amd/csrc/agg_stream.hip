@@ -35,7 +35,7 @@ typedef int as_i4 __attribute__((ext_vector_type(4)));
 // Addresses are formed in full by scalar arithmetic (no register offset operand).
 __device__ __forceinline__ int as_sload(const void* p) {            // one dword, waited for
     int r;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r) : "s"(p) : "memory");
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");       // early clobber: the result never aliases the address pair
     return r;
 }
 __device__ __forceinline__ void as_sload16(const void* p, as_i4& a, as_i4& b, as_i4& c, as_i4& d) {      // 16 dwords at p (4-byte aligned), issued only
@@ -64,8 +64,11 @@ struct AggS {
     unsigned long long* dbg;            // timeline probe (tools/coreside_probe.py): [2 * blocks] start / end of every workgroup on the device's constant clock
 };
 
-// One gather: LDS[slot .. slot + LPR * 16) <- x[voff .. ), 16 bytes per lane of the lower LPR lanes (M0 = the slot's LDS byte address; EXEC is
-// all ones around this statement: the kernel's control flow is wave-uniform).  M0 is the compiler's: saved and restored.
+// One gather: LDS[slot .. slot + LPR * 16) <- x[voff .. ), 16 bytes per lane of the lower LPR lanes (M0 = the slot's LDS byte address).  M0 is the
+// compiler's: saved and restored.  So is EXEC: the narrow variants mask the upper lanes for the one DMA instruction and put back the mask they found
+// (saved in an SGPR pair), so the statement is correct inside a predicated region too -- the kernel's control flow is wave-uniform today (act is applied at
+// the stores, never around a gather), but nothing in this statement depends on that any more.  (The kernel is built xnack-: gfx950 default target, no
+// replay of a scalar load whose destination overlaps its address.)
 // The statement starts with lgkmcnt(0): the slot was READ (ds_read_b128) by the step that issues this gather, and nothing orders a DMA's LDS write behind
 // a read that has been issued but not yet executed.  The first version had no such wait: with the other stream's GEMM saturating the CU's LDS the read
 // could sit in its queue longer than a cache-resident source row takes to arrive, and the sum picked up 64-byte pieces of the row gathered for edge e + R
@@ -78,10 +81,12 @@ __device__ __forceinline__ void as_issue(unsigned lds_slot, const float* xbase, 
     if constexpr (LPR == 64)
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot) : "memory");
-    else
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
-                     "global_load_lds_dwordx4 %1, %2\n\ts_mov_b64 exec, -1\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(voff), "s"(xbase), "s"(lds_slot), "s"(LPR == 32 ? 0xffffffffu : 0xffffu) : "memory");
+    else {
+        unsigned long long ex;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_mov_b64 %1, exec\n\ts_and_b32 exec_lo, exec_lo, %5\n\ts_mov_b32 exec_hi, 0\n\ts_nop 1\n\t"
+                     "global_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep), "=&s"(ex) : "v"(voff), "s"(xbase), "s"(lds_slot), "s"(LPR == 32 ? 0xffffffffu : 0xffffu) : "memory", "scc");
+    }
 }
 
 // 64 descriptors (256 bytes): LDS[dst .. dst + 256) <- base[voff .. ), 4 bytes per lane, all 64 lanes
@@ -398,6 +403,9 @@ int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t
     return GM_OK;
 }
 
+#ifdef GM_PROBES
+// Probe build only (build.py --probes -> libgmeta_hip_probes.so; include/gmeta_hip_probes.h): workgroup timelines of the stream launches and the
+// s_setprio experiment.  The product library exports neither the symbol nor the process-global buffer.
 static unsigned long long* g_stream_dbg = nullptr; static int g_stream_dbg_n = 0;
 // enable != 0: every later stream launch stamps its workgroups' start / end clocks (2 x uint64 each) into a device buffer of n entries; out != NULL: copy
 // the buffer to the host (after the caller has synchronised)
@@ -407,6 +415,7 @@ extern "C" int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t 
     if (!enable && g_stream_dbg) { (void)hipFree(g_stream_dbg); g_stream_dbg = nullptr; g_stream_dbg_n = 0; }
     return GM_OK;
 }
+#endif
 
 template <int LPR, int R>
 static void launch_stream(const AggS& a, int nwg, hipStream_t s) {
@@ -418,6 +427,11 @@ bool gm_stream_ok(const gm_agg_args& g) {
     if (!g.stream || g.s_out || g.bias || g.mask_h || g.mask_b || g.relu || g.relu_bits) return false;
     if (g.stream_feat && !gm_knob().agg_stream_gather) return false;
     if (g.rowlist || g.skip_on) return false;                                  // partial launches stay on the window kernel (measured: profiles/r05_experiments_not_shipped.txt C.1)
+    // The stream kernel takes every per-edge quantity from the batch's stream tables: the launch described by `g` must BE that aggregate -- same
+    // orientation, rows, per-edge weights and (layer 1) per-edge feature rows -- or the window kernel, which reads g's own arrays, computes it
+    const gm_batch* b = g.stream; const int o = g.stream_o;
+    if (o < 0 || o > 1 || !b->d_sptr[o] || g.rows != b->rows || g.indptr != (o ? b->d_indptr_t : b->d_indptr) || g.e_w != b->d_enorm[o]) return false;
+    if (g.stream_feat ? (o != 0 || !b->d_su_feat || g.x_idx != b->d_efeat) : (g.x_idx != nullptr || g.x_row != nullptr)) return false;
     return
            (g.width == 64 || g.width == 128 || g.width == 256) && g.ldx % 4 == 0 && (((uintptr_t)g.x | (uintptr_t)g.out) & 15) == 0 &&
            (uint64_t)g.stream_xrows * (uint64_t)g.ldx * 4u < ((uint64_t)1 << 31) && g.stream_xrows < (1 << 24);
@@ -430,8 +444,10 @@ int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s) {
            b->stream_hubwg[o], su, b->d_sw[o], b->d_heavy[o], b->d_scum[o], b->n_heavy[o], b->stream_enorm[o], split ? g.hub : nullptr, split ? g.hub_scratch : nullptr,
            split ? b->hub_part[o] : 0, GM_AGG_HUB_LD, b->stream_nparts[o], split ? b->d_sxord[o] : nullptr, 0, nullptr};
     GM_REQUIRE(!split || a.xord, GM_EINVAL, "stream aggregate: split hub rows without their XCD lists");
+#ifdef GM_PROBES
     { static const int pr = getenv("GM_AGG_STREAM_PRIO") ? atoi(getenv("GM_AGG_STREAM_PRIO")) : 0; a.prio = pr; }
     if (g_stream_dbg && 2 * b->stream_nwg[o] <= g_stream_dbg_n) a.dbg = g_stream_dbg;
+#endif
     const int depth = gm_knob().agg_stream_depth, nwg = b->stream_nwg[o];
     // (ring depths: 8 / 12 KiB of gathers in flight per wave; beyond ~15 KiB per wave the workgroup's LDS would pass 64 KiB -- the reach of M0's 16-bit DMA base)
     if (g.width == 256) { if (depth == 8) launch_stream<64, 8>(a, nwg, s); else launch_stream<64, 12>(a, nwg, s); }

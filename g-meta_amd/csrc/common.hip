@@ -222,8 +222,9 @@ extern "C" int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t
     return gm_profile_read(GM_PROF_AGG, total_ms, launches, algorithmic_bytes);
 }
 
-// Timeline probe for tools/: one thread writes the 100 MHz constant clock to *out when the stream reaches this point (stamps of different streams
-// are comparable, HIP event times of different streams are not)
+#ifdef GM_PROBES
+// Timeline probe for tools/ (probe build only): one thread writes the 100 MHz constant clock to *out when the stream reaches this point (stamps of
+// different streams are comparable, HIP event times of different streams are not)
 __global__ void k_debug_stamp(unsigned long long* out) { *out = wall_clock64(); }
 extern "C" int gm_debug_stamp(void* out, void* stream) {
     GM_REQUIRE(out, GM_EINVAL, "debug_stamp: NULL argument");
@@ -231,6 +232,7 @@ extern "C" int gm_debug_stamp(void* out, void* stream) {
     GM_HIP(hipGetLastError());
     return GM_OK;
 }
+#endif
 
 static gm_knobs g_knobs;
 static std::once_flag g_knobs_once;

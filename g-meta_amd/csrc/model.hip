@@ -1240,14 +1240,19 @@ extern "C" int gm_proto_loss_qry(const gm_batch_t* b, const float* logits, int32
     return rc;
 }
 
+#ifdef GM_PROBES
+// Probe build only (build.py --probes; include/gmeta_hip_probes.h)
 static unsigned long long* g_head_dbg = nullptr;
-// Phase timeline of k_head_loss (block 0, device constant clock): enable allocates 8 stamps that every later launch overwrites; out != NULL copies them
+// Phase timeline of k_head_loss (block 0, device constant clock): enable allocates 64 stamps that every later launch overwrites; out != NULL copies them
 extern "C" int gm_head_loss_debug(int32_t enable, unsigned long long* out) {
     if (enable && !g_head_dbg) { GM_HIP(hipMalloc((void**)&g_head_dbg, 512)); GM_HIP(hipMemset(g_head_dbg, 0, 512)); }
     if (out && g_head_dbg) GM_HIP(hipMemcpy(out, g_head_dbg, 512, hipMemcpyDeviceToHost));
     if (!enable && g_head_dbg) { (void)hipFree(g_head_dbg); g_head_dbg = nullptr; }
     return GM_OK;
 }
+#else
+static unsigned long long* const g_head_dbg = nullptr;      // the product library carries no probe state
+#endif
 
 // Head forward + loss (+ head backward) in one launch (k_head_loss) after a gcn_forward(..., skip_head = 1).  With
 // bwd != 0 the matching gcn_backward(..., skip_head = 1) continues from dQ_L / the compact G2 written here; c.sgd (if
@@ -1284,11 +1289,13 @@ static int head_loss(GcnCtx& c, const float* params, int64_t pstride, float* log
     if (nt == 256) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<256>)); hipLaunchKernelGGL(k_head_loss<256>, dim3(b->sets), dim3(256), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
     else if (nt == 512) { GM_TRY(gm_func_full_lds((const void*)k_head_loss<512>)); hipLaunchKernelGGL(k_head_loss<512>, dim3(b->sets), dim3(512), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
     else { GM_TRY(gm_func_full_lds((const void*)k_head_loss<1024>)); hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg); }
-    {   // probe only (tools/head_loss_probe.py): the same launch again -- it is idempotent -- to see what a warm instruction cache / warm L2 is worth
+#ifdef GM_PROBES
+    {   // tools/head_loss_probe.py: the same launch again -- it is idempotent -- to see what a warm instruction cache / warm L2 is worth
         static const int twice = getenv("GM_HEAD_TWICE") ? atoi(getenv("GM_HEAD_TWICE")) : 0;
         if (twice && nt != 256 && nt != 512)
             hipLaunchKernelGGL(k_head_loss<1024>, dim3(b->sets), dim3(1024), lds, st, hk, logits, pk, bwd, dparams, dstride, dQ, Gc, sg, stage_h, (int)(proto_bytes / sizeof(float)), 0, g_head_dbg);
     }
+#endif
     GM_HIP(hipGetLastError());
     gm_prof_end(GM_PROF_HEAD, st);
     if (bwd && dQ && hk.dq_amax) c.dqv = true;

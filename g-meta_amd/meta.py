@@ -413,19 +413,24 @@ class _Deferred:
     def __del__(self):
         # an unread handle gives its pinned read-back slot back (Meta._readback): the copy into it was queued before any later step's copy
         # on the same stream, so a later reuse cannot be overtaken by it
+        # (only while this handle still OWNS the slot: accs() gives it back and drops the reference in one statement, so a handle whose accs() raised
+        # after that point can never mark a slot free that has meanwhile gone to a newer handle)
         buf = getattr(self, '_buf', None)
         if getattr(self, '_applied', False) and isinstance(buf, tuple):
+            self._buf = None
             buf[0][2] = False
 
     def accs(self):
         if self._accs is not None:
             return self._accs
         m, K1 = self._meta, self._K1
+        if self._buf is None:
+            raise RuntimeError('gmeta_amd: the read-back of this meta-step was already consumed by an accs() call that failed')
         if self._applied:                                     # device path: Adam already queued, buf = (pinned [losses_q | corrects | count | per-task | violation], event)
             slot, n = self._buf
             slot[1].synchronize()           # (polling the event instead measured no different: the wait's wake-up is not what the step start waits for)
             tail = slot[0][:n].numpy().astype(np.float64)
-            slot[2] = False                                   # (astype copied: the pinned slot may be reused)
+            self._buf, slot[2] = None, False                  # (astype copied: the pinned slot may be reused -- and is no longer this handle's to free)
         else:                                                 # host path (non-fused Adam / CPU tensors): guard + step here
             head, P = self._buf, self._P
             tail = head[P:].cpu().numpy().astype(np.float64)

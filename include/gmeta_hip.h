@@ -262,14 +262,8 @@ int gm_profile_aggregate(double* total_ms, int64_t* launches, int64_t* algorithm
 int gm_profile_read(int32_t category, double* total_ms, int64_t* launches, int64_t* work);
 /* The same per launch: ms[k] / work[k] of the k-th timed launch of the category since the last reset (at most cap); returns their number (< 0: error). */
 int gm_profile_read_launches(int32_t category, double* ms, int64_t* work, int32_t cap);
-/* Timeline probe (tools/): a one-thread kernel on `stream` writes the device's 100 MHz constant clock to *out (device uint64) -- stamps taken on
- * different streams are comparable, which HIP event times are not. */
-int gm_debug_stamp(void* out, void* stream);
-/* ... and of the stream aggregate kernel (agg_stream.hip): enable != 0 makes every later launch stamp the start / end clock of each of its workgroups
- * (2 x uint64 per workgroup) into a device buffer of n entries; out != NULL copies that buffer to the host; enable == 0 releases it. */
-int gm_stream_debug(int32_t enable, unsigned long long* out, int32_t n);
-/* ... and of k_head_loss: 64 stamps of block 0 of the LAST launch (phases 0-6, shader cycles in 7, per-wave start / end of the logits phase in 8-23 / 24-39). */
-int gm_head_loss_debug(int32_t enable, unsigned long long* out);
+/* Timeline / phase probes used by tools/ (gm_debug_stamp, gm_stream_debug, gm_head_loss_debug) are NOT part of this library: they exist only in
+ * the probe build, libgmeta_hip_probes.so (`python g-meta_amd/build.py --probes`), and are declared in include/gmeta_hip_probes.h. */
 
 #ifdef __cplusplus
 }

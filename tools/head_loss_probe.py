@@ -9,6 +9,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _probe_lib  # noqa: F401  (probe build of the library: gm_debug_stamp / gm_stream_debug / gm_head_loss_debug)
 import gmeta_amd
 from gmeta_amd import _lib, synth
 
