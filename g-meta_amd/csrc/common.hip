@@ -59,7 +59,7 @@ void gm_dev_free(void* p, hipStream_t s) {
 // ---------------------------------------------------------------- pinned staging pool (gm_stager)
 struct StageChunk { char* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false, held = false; };
 // ONE pool per device for the whole process, behind a mutex: Subgraphs.batches() starts a fresh prefetch thread per epoch, and a per-thread pool
-// orphaned its pinned chunks (>= 1 MiB each) and events whenever such a thread ended.  The pools are deliberately leaked at process exit (a static
+// orphaned its pinned chunks (>= 4 MiB each) and events whenever such a thread ended.  The pools are deliberately leaked at process exit (a static
 // destructor would run after the HIP runtime's own teardown); what they hold is bounded by the largest number of builds in flight at once.
 struct StagePool {
     std::vector<StageChunk> chunks;
@@ -73,7 +73,7 @@ struct StagePool {
         }
         if (best < 0) {
             StageChunk c;
-            c.cap = std::max<size_t>(bytes, (size_t)1 << 20);
+            c.cap = std::max<size_t>(bytes, (size_t)4 << 20);       // one chunk carries a whole batch build (1 MiB chunks: four acquisitions -- each a walk over the pool with an event query per pending chunk -- per 32-task query batch)
             if (hipHostMalloc((void**)&c.p, c.cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return -1; }
             if (hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(c.p); return -1; }
             chunks.push_back(c); best = (int)chunks.size() - 1;
@@ -269,6 +269,7 @@ const gm_knobs& gm_knob() {
         k.wgrad_split = env("GM_WGRAD_SPLIT", 1);
         k.dz_glds = env("GM_DZ_GLDS", 1);
         k.fuse_agg = env("GM_FUSE_AGG", 1);
+        k.fuse_diff = env("GM_FUSE_DIFF", 2);
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.head_threads = env("GM_HEAD_THREADS", 0);
         k.query_streams = env("GM_QUERY_STREAMS", 0);
@@ -304,6 +305,7 @@ static int gm_knobs::* gm_find_knob(const char* name) {
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
         {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list}, {"GM_AGG_MID_WIN", &gm_knobs::agg_mid_win}, {"GM_AGG_STREAM", &gm_knobs::agg_stream}, {"GM_AGG_STREAM_DEPTH", &gm_knobs::agg_stream_depth}, {"GM_AGG_STREAM_MIN_ROWS", &gm_knobs::agg_stream_min_rows},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
+        {"GM_FUSE_DIFF", &gm_knobs::fuse_diff},
     };
     for (const auto& e : tab)
         if (!strcmp(name, e.name)) return e.field;

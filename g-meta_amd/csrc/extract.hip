@@ -432,13 +432,6 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
     }
 }
 
-// rows whose degree exceeds gm_heavy_deg() (hubs inside their own neighbourhood): appended to a list, sorted on the host
-__global__ void k_find_heavy(const int32_t* indptr, int64_t rows, int32_t* list, int32_t* count, int cap, int thr) {
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        const int d = indptr[r + 1] - indptr[r];
-        if (d > thr) { const int k = atomicAdd(count, 1); if (k < cap) { list[k] = (int32_t)r; list[cap + k] = d; } }      // [rows: cap][degrees: cap]
-    }
-}
 // per-edge tables: source norm (both orientations) and source feature row (forward orientation)
 // Row gains of the aggregates (gm_batch::d_gain, zeroed): bit patterns of non-negative floats order as unsigned integers.
 __global__ void k_gains(const int32_t* indptr, const int32_t* indices, const int32_t* indptr_t, const float* norm, int64_t rows, unsigned* gain) {
@@ -463,12 +456,18 @@ __global__ void k_edge_tables(const int32_t* indices, const int32_t* indices_t, 
         enorm[e] = norm[u]; enorm_t[e] = norm[v]; efeat[e] = feat_row[u];
     }
 }
-// per-row source table of the fused aggregate + GEMM kernel (gm_batch::d_fuse2 / d_fuse2_feat)
-__global__ void k_fuse2(const int32_t* indptr, const int32_t* indices, int64_t rows, const float* norm, const int32_t* feat_row, int4* f2, int4* f2_feat,
-                        unsigned long long* counts) {
+// ONE pass over the rows for everything the finalisation derives from the row bounds (round 6; four launches before): hub-row lists of both orientations (atomic append; the host orders them), the fused launch's per-row source table with its
+// row / edge counts (gm_batch::d_fuse2 / d_fuse2_feat, unfused_rows / unfused_edges), and the keep-flag row scale gm_batch::d_norm_c with the sign bit set on
+// every row (k_centre_rows clears it on the centre rows afterwards).  Hub rows: in-degree (o = 0) / out-degree (o = 1) above `thr`.
+__global__ void k_row_tables(const int32_t* indptr, const int32_t* indices, const int32_t* indptr_t, int64_t rows, const float* norm, const int32_t* feat_row,
+                             int4* f2, int4* f2_feat, unsigned long long* counts, int32_t* heavy0, int32_t* heavy1, int32_t* hcnt, int cap, int thr, float* norm_c) {
     unsigned long long nr = 0, ne = 0;
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-        const int p = indptr[r], d = indptr[r + 1] - p;
+        const int p = indptr[r], d = indptr[r + 1] - p, dt = indptr_t[r + 1] - indptr_t[r];
+        if (d > thr) { const int k = atomicAdd(hcnt, 1); if (k < cap) { heavy0[k] = (int32_t)r; heavy0[cap + k] = d; } }         // [rows: cap][degrees: cap]
+        if (dt > thr) { const int k = atomicAdd(hcnt + 1, 1); if (k < cap) { heavy1[k] = (int32_t)r; heavy1[cap + k] = dt; } }
+        const float nrm = norm[r];
+        norm_c[r] = __uint_as_float(__float_as_uint(nrm) | 0x80000000u);
         const int self = (int)r | GM_FUSE_SELF;
         int4 t = make_int4(self, self, __float_as_int(1.f), 0), tf = t;
         if (d == 0) { t = make_int4(GM_FUSE_ZERO, GM_FUSE_ZERO, __float_as_int(1.f), 0); tf = t; }
@@ -564,22 +563,15 @@ __global__ __launch_bounds__(MID_BLOCK) void k_mid_scatter(const int32_t* indptr
     const int at = base + __popcll(m & ((1ull << lane) - 1ull));
     if (f && at < cap) list[at] = (int32_t)r;
 }
-// norm with the sign bit set (every row), then cleared again on the centre rows: gm_batch::d_norm_c
-__global__ void k_norm_neg(const float* norm, int64_t n, float* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = __uint_as_float(__float_as_uint(norm[i]) | 0x80000000u);
-}
-__global__ void k_norm_centres(const float* norm, const int32_t* crow, int n_c, float* out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n_c) { const int r = crow[k]; out[r] = __uint_as_float(__float_as_uint(norm[r]) & 0x7fffffffu); }
-}
 // centre rows, their norms and in-degrees (row-sparse backward tables)
+// (norm_c != NULL: also clears the keep-flag scale's sign bit on the centre rows -- after k_row_tables set it on every row)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
-                              int32_t* crow, float* cnorm, int32_t* cdeg) {
+                              int32_t* crow, float* cnorm, int32_t* cdeg, float* norm_c) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_c) return;
     const int row = sub_off[k / nc] + centre[k];
     crow[k] = row; cnorm[k] = norm[row]; cdeg[k] = indptr[row + 1] - indptr[row];
+    if (norm_c) norm_c[row] = __uint_as_float(__float_as_uint(norm[row]) & 0x7fffffffu);
 }
 __global__ void k_centre_edges(const int32_t* crow, const int32_t* eoff, int n_c, const int32_t* indptr, const int32_t* indices,
                                const float* norm, int32_t* e_row, int32_t* e_par, float* e_norm) {
@@ -705,6 +697,25 @@ int gm_batch_gains(const gm_batch* cb, hipStream_t s) {
 // row / edge counts, the centres' in-degrees) are launched back to back, their results come back in one batch of copies into pinned memory,
 // and everything the host derives from them goes up through pinned staging without waiting (gm_stager).
 #define GM_HEAVY_FIRST 8192     // hub rows per orientation fetched with the first round trip (more: one more round trip)
+// Hub rows come back in atomic-append order; the schedules want them ascending (and the build deterministic).  The rows are distinct ids below
+// `rows`: an LSD radix sort, 11 bits a pass (two passes up to 4 M rows), carries the degrees along -- std::sort on the pairs cost 0.2 ms per
+// orientation of the 1.14 M-row query batch, on the host, between the build's kernels.
+static void sort_rows_with_degrees(std::vector<int32_t>& row, std::vector<int32_t>& deg, int64_t rows) {
+    const size_t n = row.size();
+    if (n < 2) return;
+    std::vector<int32_t> row2(n), deg2(n);
+    int bits = 1;
+    while (bits < 31 && ((int64_t)1 << bits) < rows) ++bits;
+    int32_t* r0 = row.data(); int32_t* d0 = deg.data(); int32_t* r1 = row2.data(); int32_t* d1 = deg2.data();
+    for (int shift = 0; shift < bits; shift += 11) {
+        uint32_t cnt[2049] = {};
+        for (size_t k = 0; k < n; ++k) ++cnt[(((uint32_t)r0[k] >> shift) & 2047u) + 1];
+        for (int k = 0; k < 2048; ++k) cnt[k + 1] += cnt[k];
+        for (size_t k = 0; k < n; ++k) { const uint32_t at = cnt[((uint32_t)r0[k] >> shift) & 2047u]++; r1[at] = r0[k]; d1[at] = d0[k]; }
+        std::swap(r0, r1); std::swap(d0, d1);
+    }
+    if (r0 != row.data()) { row.swap(row2); deg.swap(deg2); }
+}
 int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     gm_phase_timer tm("finalize");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
@@ -730,11 +741,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     int32_t* d_cnt = nullptr;
     GM_TRY(gm_alloc(&d_cnt, 2, s));
     GM_HIP(hipMemsetAsync(d_cnt, 0, 8, s));
-    for (int o = 0; o < 2; ++o) {
-        GM_TRY(gm_balloc(b, &b->d_heavy[o], 2 * (size_t)cap, s));
-        const int blocks = (int)std::min<int64_t>(2048, (b->rows + 255) / 256);
-        hipLaunchKernelGGL(k_find_heavy, dim3(blocks), dim3(256), 0, s, o ? b->d_indptr_t : b->d_indptr, b->rows, b->d_heavy[o], d_cnt + o, cap, b->heavy_deg);
-    }
+    for (int o = 0; o < 2; ++o) GM_TRY(gm_balloc(b, &b->d_heavy[o], 2 * (size_t)cap, s));
     const int edge_tables = gm_knob().agg_edge_tables;
     if (b->edges > 0 && edge_tables) {
         GM_TRY(gm_balloc(b, &b->d_enorm[0], (size_t)b->edges, s)); GM_TRY(gm_balloc(b, &b->d_enorm[1], (size_t)b->edges, s)); GM_TRY(gm_balloc(b, &b->d_efeat, (size_t)b->edges, s));
@@ -742,24 +749,21 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
                            b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);
     }
     unsigned long long* d_counts = nullptr;
+    GM_TRY(gm_balloc(b, &b->d_norm_c, b->rows, s));
     if (b->rows > 0) {
         int4 *f0 = nullptr, *ff = nullptr;
         GM_TRY(gm_balloc(b, &f0, (size_t)b->rows, s)); GM_TRY(gm_balloc(b, &ff, (size_t)b->rows, s));
         b->d_fuse2 = f0; b->d_fuse2_feat = ff;
         GM_TRY(gm_alloc(&d_counts, 2, s));
         GM_HIP(hipMemsetAsync(d_counts, 0, 16, s));
-        hipLaunchKernelGGL(k_fuse2, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, (int64_t)b->rows, b->d_norm,
-                           b->d_feat_row, f0, ff, d_counts);
+        hipLaunchKernelGGL(k_row_tables, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, (int64_t)b->rows,
+                           b->d_norm, b->d_feat_row, f0, ff, d_counts, b->d_heavy[0], b->d_heavy[1], d_cnt, cap, b->heavy_deg, b->d_norm_c);
     }
     const int nc = b->centres; b->n_c = b->subs * nc;
     int32_t* d_cdeg = nullptr;
     GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
     hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
-                       b->d_crow, b->d_cnorm, d_cdeg);
-    GM_HIP(hipGetLastError());
-    GM_TRY(gm_balloc(b, &b->d_norm_c, b->rows, s));
-    hipLaunchKernelGGL(k_norm_neg, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, s, b->d_norm, (int64_t)b->rows, b->d_norm_c);
-    hipLaunchKernelGGL(k_norm_centres, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_norm, b->d_crow, b->n_c, b->d_norm_c);
+                       b->d_crow, b->d_cnorm, d_cdeg, b->d_norm_c);
     GM_HIP(hipGetLastError());
     // ---- the one round trip
     const int first = std::min(cap, GM_HEAVY_FIRST);
@@ -769,7 +773,9 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     const unsigned long long* h_counts = d_counts ? sg.download(d_counts, 2) : nullptr;
     const int32_t* h_cdeg = sg.download(d_cdeg, (size_t)b->n_c);
     GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
+    tm.lap("launches");
     GM_HIP(hipStreamSynchronize(s));
+    tm.lap("gpu-wait");
     gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
     if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
     b->sched_win = gm_agg_window(b->rows, b->edges);
@@ -786,15 +792,15 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
                 GM_HIP(hipStreamSynchronize(s));
                 std::copy(a, a + nh, h.begin()); std::copy(d, d + nh, hd.begin());
             }
-            std::vector<std::pair<int32_t, int32_t>> pr(nh);
-            for (size_t k = 0; k < nh; ++k) pr[k] = {h[k], hd[k]};
-            std::sort(pr.begin(), pr.end());
-            for (size_t k = 0; k < nh; ++k) { h[k] = pr[k].first; hd[k] = pr[k].second; }
+            sort_rows_with_degrees(h, hd, b->rows);
             if (nh > 1) GM_TRY(sg.upload(b->d_heavy[o], h));
+            tm.lap("hub-sort");
             gm_agg_sched sc;
             GM_TRY(gm_agg_schedule(b, b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s, &sg));
+            tm.lap("schedule");
             if (o == 0) { heavy0 = h; tab0 = sc.tab; }
             if (gm_knob().agg_stream) GM_TRY(gm_stream_tables(b, o, h.data(), hd.data(), (int)nh, sc.d_hub ? sc.parts : (int)nh, sc.d_hub ? &sc.tab : nullptr, s, &sg));
+            tm.lap("stream-tables");
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part; b->hub_words[o] = sc.hub_words; b->hub_parts[o] = sc.parts;
         } else if (gm_knob().agg_stream) GM_TRY(gm_stream_tables(b, o, nullptr, nullptr, 0, 0, nullptr, s, &sg));
     }
@@ -826,7 +832,7 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
             }
         }
     }
-    tm.lap("heavy");
+    tm.lap("mid-list");
     // ---- compact lists for the row-sparse backward: centre rows and the in-edges of centres
     std::vector<int32_t> eoff(b->n_c + 1, 0);
     for (int k = 0; k < b->n_c; ++k) eoff[k + 1] = eoff[k] + h_cdeg[k];

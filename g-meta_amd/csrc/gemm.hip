@@ -555,6 +555,10 @@ static int launch_gemm_nn(const gm_gemm_args& a, hipStream_t s) {
         // grid below the CU count, which leaves whole CUs to the kernels of the other stream (experiment knob).
         const int cus = gm_stream_cus(s);                                 // the stream's CU mask, if it has one
         int grid_cap = gm_knob().gemm_split_grid;
+        if (grid_cap <= 0 && a.n_tiles > 2 * cus && a.n_tiles <= 6 * cus && cus >= 128) grid_cap = cus - 2 * GM_NXCD;
+        // (round 6, measured on the 4-task arxiv shard -- the per-GPU share of an 8-GPU meta-batch, 1,101 query tiles: two CUs per XCD left to the
+        // other queue's small kernels, 4.07-4.16 -> 4.00-4.02 ms per meta-step; from ~8 tiles per CU upwards the cap only costs: task_num 8 / 16 even,
+        // task_num 32 24.8 -> 25.0 ms; CU-masked streams lose at every split at this size too: profiles/r06_t4_sweep.txt)
         if (grid_cap <= 0 || grid_cap > cus) grid_cap = cus;
         if (a.fuse2) {
             // fused aggregate + GEMM: A addresses the aggregate's input rows, rows of other degrees come finished from a.zside
@@ -658,6 +662,10 @@ struct WgradK {
     const float* G; int64_t ldg; int N; const float* Gb; int64_t ldgb;
     const float* a_scale; const int32_t* chunks; int n_chunks; float* partial; int RK; int TK, TN; int vec;
     gm_bound a_bound, g_bound;               // k_wgrad_split<., ., 2>: bounds of the A / G rows (two fp16 pieces per operand)
+    // k_wgrad_split<., ., ., true> (GA): A = the aggregate Z of a pass whose forward ran FUSED, formed here the way the fused GEMM's feeders formed it:
+    // f2[row] = {u0, u1, w0, w1} (gm_batch::d_fuse2 / d_fuse2_feat), row = w0 * gx[u0] + w1 * gx[u1]; entries flagged GM_FUSE_SELF read their finished row
+    // of A (the partial aggregate launch wrote it), GM_FUSE_ZERO rows read zrow
+    const int4* f2; const float* gx; int64_t ldgx; const float* zrow;
 };
 
 #define WG_PF 2     // float4 prefetch registers per thread: RK * (ldA + ldG) <= 2 * 1024 * 4 floats per stage
@@ -932,7 +940,15 @@ __device__ __forceinline__ gm_f32x16 wgs_mfma(gm_f16x8 a, gm_f16x8 b, gm_f32x16 
 __device__ const float gm_wgs_ones[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // the row "scales" of an unscaled operand
 // NP = 3: three bf16 pieces per operand, six products;  NP = 2: two fp16 pieces under the per-set power-of-two scales of w.a_bound / w.g_bound
 // (gemm_split.h), three products, the partial leaves multiplied by 1 / (s_a s_g).
-template <int KT, int NT, int NP = 3>
+// GA = true (round 6): the A operand is never read as a matrix -- the pass's forward ran the fused aggregate + GEMM, so Z_l exists only for the rows
+// of three or more sources; every other row is formed HERE from its one or two source rows (per-row table gm_batch::d_fuse2), in the aggregate
+// kernel's own fma order: the same floats as the unfused pass, bit for bit, and the differentiated passes no longer write and re-read Z_l.
+// The table rides in the loader's counted queue: the sources of stage s + 1 are fetched FIRST in the load group of stage s (the group's wait leaves
+// one load less outstanding, so they have landed before the next group is issued), the weights with the rows they scale; rows are wave-uniform, so
+// lane j & 7 fetches row j's entry, forms its two addresses (src_addr), and v_readlane broadcasts them into the SGPR base pairs of the group's loads.
+// (Forming them inside the stage's MFMA sequence instead of in front of the loads measured the same; that variant's first build came out with phi
+// copies of in-flight registers at its loop head -- tools/check_inflight_regs.py / tests/test_kernel_resources.py now replay every build's ISA.)
+template <int KT, int NT, int NP = 3, bool GA = false>
 __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     constexpr int K = KT * 128, N = NT * 128, COLS = K + N;
     constexpr int NTK = KT, NTN = 2 * NT;                                           // 32 x 32 tiles per wave: (K / 32) / 4 x (N / 32) / 2
@@ -986,26 +1002,81 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     const bool scaled = w.a_scale != nullptr;
     const uint64_t sscale = uni64(scaled ? (const void*)(w.a_scale + row0) : (const void*)gm_wgs_ones);
     float pf[2][2][8], ps[2];                                                       // [slot = stage parity][item][row], [slot]
+    float pf1[GA ? 2 : 1][8];                                                       // GA: the rows' second sources
+    typedef int i2v __attribute__((ext_vector_type(2)));
+    i2v tu = {0, 0}, tw[2] = {{0, 0}, {0, 0}};                                      // GA: {u0, u1} of the NEXT group's rows; {w0, w1} of the slot's rows (lane j & 7: row j)
+    const uint64_t stab = GA ? uni64(w.f2 + row0) : 0, sgx = GA ? uni64(w.gx) : 0, szr = GA ? uni64(w.zrow) : 0, sza = GA ? uni64(w.A) : 0;
+    const unsigned ldgx_b = GA ? (unsigned)w.ldgx * 4u : 0u;
     float bsum = 0.f;
     float op_scale[2] = {1.f, 1.f};                                                 // NP == 2: s_a, s_g of this chunk's set
     if constexpr (NP == 2) { const int set = w.chunks[chunk * 3]; op_scale[0] = gs_bound_scale(w.a_bound, set); op_scale[1] = gs_bound_scale(w.g_bound, set); }
     // Stage R0 / 16 -> slot SL: 17 loads per thread, ALWAYS issued (rows are clamped to the chunk, so a stage past the end re-reads the
     // last row and is never stored): every wait is the same vmcnt(17) and the loop body has no control flow around the asm
+    // GA: byte address of source row u of a table entry: zrow / the row's own finished aggregate in A / a row of gx.  Formed LANE-PARALLEL -- lane j & 7 holds
+    // row j's entry, so one pass of ~16 VALU instructions gives all 16 addresses of a load group, which v_readlane then broadcasts into SGPR pairs (the
+    // loads take a wave-uniform 64-bit base + the lane's column offset).  The first version formed them one after the other by scalar arithmetic: 16
+    // dependent chains of ~16 SALU instructions in front of every group's loads, and the weight gradients ran 40-60 % longer than on a stored Z.
+    auto src_addr = [&](int u) -> uint64_t {
+        const bool zero = (u & GM_FUSE_ZERO) != 0, self = (u & GM_FUSE_SELF) != 0;
+        const unsigned idx = zero ? 0u : (unsigned)(u & ~(GM_FUSE_SELF | GM_FUSE_ZERO));
+        const uint64_t base = zero ? szr : (self ? sza : sgx);
+        return base + (uint64_t)idx * (uint64_t)(self ? ld_b[0] : ldgx_b);
+    };
+    uint64_t nb0[8] = {}, nb1[8] = {};
+#define WGS_BASES()                                                                                                        \
+    do {                                                                                                                   \
+        const uint64_t a0_ = src_addr(tu.x), a1_ = src_addr(tu.y);                                                         \
+        const int a0l = (int)(unsigned)a0_, a0h = (int)(unsigned)(a0_ >> 32), a1l = (int)(unsigned)a1_, a1h = (int)(unsigned)(a1_ >> 32); \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                    \
+            nb0[j] = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(a0h, j) << 32) | (unsigned)__builtin_amdgcn_readlane(a0l, j); \
+            nb1[j] = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(a1h, j) << 32) | (unsigned)__builtin_amdgcn_readlane(a1l, j); \
+        }                                                                                                                  \
+    } while (0)
+    // table row of this lane for the stage at R0: lane j & 7 fetches row j of the wave's octet (clamped like the row loads)
+#define WGS_TAB_OFF(R0) ((unsigned)min((R0) + oct8[0] + (lane & 7), nrows - 1) * 16u)
 #define WGS_ISSUE(R0, SL)                                                                                                  \
     do {                                                                                                                   \
+        if constexpr (GA) {                                                                                                \
+            WGS_BASES();                                          /* the group's 16 row addresses, from the table sources the last group fetched */ \
+            { const unsigned offn = WGS_TAB_OFF((R0) + 16);              /* FIRST load of the group: the NEXT group's sources */ \
+              asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(tu) : "v"(offn), "s"(stab) : "memory"); }               \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {          /* (zrow holds K zero floats: the column offset stays inside it) */ \
+                /* s_nop 4: the base pair comes straight from v_readlane (a VALU write of an SGPR), and a VMEM instruction that reads such an SGPR needs five \
+                   wait states the compiler does not insert in front of inline asm (the first lane-parallel version faulted on exactly that) */ \
+                asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %4"                       \
+                             : "=&v"(pf[SL][0][j]), "=&v"(pf1[SL][j]) : "v"(col_b[0]), "s"(nb0[j]), "s"(nb1[j]) : "memory");  \
+            }                                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+                const unsigned off = (unsigned)min((R0) + oct8[1] + j, nrows - 1) * ld_b[1] + col_b[1];                    \
+                asm volatile("global_load_dword %0, %1, %2" : "=v"(pf[SL][1][j]) : "v"(off), "s"(sbase[1]) : "memory");    \
+            }                                                                                                              \
+            { const unsigned offw = WGS_TAB_OFF(R0) + 8u;                                                                  \
+              asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(tw[SL]) : "v"(offw), "s"(stab) : "memory"); }           \
+        } else {                                                                                                           \
         _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                                 \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
                 const unsigned off = (unsigned)min((R0) + oct8[it] + j, nrows - 1) * ld_b[it] + col_b[it];                 \
                 asm volatile("global_load_dword %0, %1, %2" : "=v"(pf[SL][it][j]) : "v"(off), "s"(sbase[it]) : "memory"); \
             }                                                                                                              \
         }                                                                                                                  \
+        }                                                                                                                  \
         const unsigned offs = scaled ? (unsigned)min((R0) + oct8[0] + (lane & 7), nrows - 1) * 4u : (unsigned)(lane & 7) * 4u; \
         asm volatile("global_load_dword %0, %1, %2" : "=v"(ps[SL]) : "v"(offs), "s"(sscale) : "memory");                  \
     } while (0)
 #define WGS_TIE(SL, IT) "+v"(pf[SL][IT][0]), "+v"(pf[SL][IT][1]), "+v"(pf[SL][IT][2]), "+v"(pf[SL][IT][3]), "+v"(pf[SL][IT][4]), "+v"(pf[SL][IT][5]), "+v"(pf[SL][IT][6]), "+v"(pf[SL][IT][7])
-    // slot SL has landed once at most the 17 loads of the stage issued after it are outstanding
-#define WGS_WAIT(SL) asm volatile("s_waitcnt vmcnt(17)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
-#define WGS_DRAIN(SL) asm volatile("s_waitcnt vmcnt(0)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory")
+#define WGS_TIE1(SL) "+v"(pf1[SL][0]), "+v"(pf1[SL][1]), "+v"(pf1[SL][2]), "+v"(pf1[SL][3]), "+v"(pf1[SL][4]), "+v"(pf1[SL][5]), "+v"(pf1[SL][6]), "+v"(pf1[SL][7])
+    // slot SL has landed once at most the loads of the stage issued after it are outstanding: 17 -- or, GA, 27 less the group's first (the next
+    // group's table sources, which the next WGS_ISSUE reads)
+#define WGS_WAIT(SL)                                                                                                       \
+    do {                                                                                                                   \
+        if constexpr (GA) asm volatile("s_waitcnt vmcnt(26)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), WGS_TIE1(SL), "+v"(ps[SL]), "+v"(tw[SL]), "+v"(tu) :: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(17)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory");               \
+    } while (0)
+#define WGS_DRAIN(SL)                                                                                                      \
+    do {                                                                                                                   \
+        if constexpr (GA) asm volatile("s_waitcnt vmcnt(0)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), WGS_TIE1(SL), "+v"(ps[SL]), "+v"(tw[SL]), "+v"(tu) :: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0)" : WGS_TIE(SL, 0), WGS_TIE(SL, 1), "+v"(ps[SL]) :: "memory");                \
+    } while (0)
     // split + store of ONE item, one plane at a time with the residual kept in place (x <- x - hi16(x), exact)
 #define WGS_STORE_IT(R0, SL, S_, IT)                                                                                       \
     do {                                                                                                                   \
@@ -1015,6 +1086,9 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
             _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
                 const int r = (R0) + oct8[it] + j;                                                                         \
                 float v_ = pf[SL][it][j];                                                                                  \
+                if constexpr (GA) if (it == 0)                           /* the aggregate kernel's chain: fma(x1, w1, fma(x0, w0, 0)) */ \
+                    v_ = __fmaf_rn(pf1[SL][j], __int_as_float(__builtin_amdgcn_readlane(tw[SL].y, j)),                     \
+                                   __fmaf_rn(v_, __int_as_float(__builtin_amdgcn_readlane(tw[SL].x, j)), 0.f));            \
                 if (it == 0) v_ *= __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ps[SL]), j));                   \
                 x[j] = r < nrows ? v_ : 0.f;                                        /* rows past the chunk end contribute zeros */ \
                 if (it == 1) bsum += x[j];                                                                                 \
@@ -1071,7 +1145,12 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     // registers; no control flow around the asm (a copy the compiler inserted on one arm of a branch read a register before its wait).
     const int nst = (nrows + 15) >> 4;
     char* const S0 = sm; char* const S1 = sm + STAGE;
+    if constexpr (GA) {                                 // sources of stage 0 (later ones ride in the groups)
+        const unsigned off0 = WGS_TAB_OFF(0);
+        asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=v"(tu) : "v"(off0), "s"(stab) : "memory");
+    }
     WGS_ISSUE(0, 0);
+    if constexpr (GA) asm volatile("s_waitcnt vmcnt(26)" : "+v"(tu) :: "memory");      // stage 1's sources (the group's first load) before its rows are issued
     WGS_ISSUE(16, 1);
     WGS_WAIT(0);
     WGS_STORE(0, 0, S0);
@@ -1087,7 +1166,10 @@ __global__ __launch_bounds__(WGS_THREADS) void k_wgrad_split(WgradK w) {
     }
     WGS_DRAIN(1);                                       // the last (never used) issue: nothing may land in a register after this point
 #undef WGS_ISSUE
+#undef WGS_TAB_OFF
+#undef WGS_BASES
 #undef WGS_TIE
+#undef WGS_TIE1
 #undef WGS_WAIT
 #undef WGS_DRAIN
 #undef WGS_STORE
@@ -1119,7 +1201,10 @@ template <int KT, int NT>
 static int launch_wgrad_split(const WgradK& w, hipStream_t s, int np) {
     constexpr int K = KT * 128, N = NT * 128;
     const size_t lds = 2 * 32 * (size_t)np * (size_t)(K + N);
-    if (np == 2) {
+    if (w.f2) {                                          // A formed from the per-row source table (three-piece kernels only: launch_wgrad checks)
+        GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT, 3, true>));
+        hipLaunchKernelGGL((k_wgrad_split<KT, NT, 3, true>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
+    } else if (np == 2) {
         GM_TRY(gm_func_full_lds((const void*)k_wgrad_split<KT, NT, 2>));
         hipLaunchKernelGGL((k_wgrad_split<KT, NT, 2>), dim3(w.n_chunks), dim3(WGS_THREADS), lds, s, w);
     } else {
@@ -1278,10 +1363,14 @@ static bool wgrad_fast_ok(const gm_wgrad_args& a) {
            (((uintptr_t)a.A & 15) == 0) && (((uintptr_t)a.G & 15) == 0);
 }
 // exact 3-way bf16 split of both operands, fp32 accumulation (k_wgrad_split): the same arithmetic as the split GEMM
-static bool wgrad_takes_split(const gm_wgrad_args& a) {
-    const int wsplit = gm_knob().wgrad_split;
-    return a.n_chunks > 0 && wgrad_fast_ok(a) && wsplit && gm_gemm_mode() == 1 && a.n_chunks >= (gm_knob().wgrad_split_min_chunks >= 0 ? gm_knob().wgrad_split_min_chunks : gm_num_cus() / 4) && (a.K == 128 || a.K == 256) && (a.N == 128 || a.N == 256);
+static bool wgrad_split_shape_ok(int n_chunks, int K, int N) {
+    return n_chunks > 0 && gm_knob().wgrad_split && gm_gemm_mode() == 1 && n_chunks >= (gm_knob().wgrad_split_min_chunks >= 0 ? gm_knob().wgrad_split_min_chunks : gm_num_cus() / 4) &&
+           (K == 128 || K == 256) && (N == 128 || N == 256);
 }
+static bool wgrad_takes_split(const gm_wgrad_args& a) { return wgrad_fast_ok(a) && wgrad_split_shape_ok(a.n_chunks, a.K, a.N); }
+// Would a weight gradient over `n_chunks` row chunks with these widths run on the split kernel -- the one that can form its A operand from the per-row
+// source table (gm_wgrad_args::fuse2)?  The forward of a differentiated pass asks before it leaves Z_l unwritten (model.hip).
+bool gm_wgrad_gather_ok(int n_chunks, int K, int N) { return wgrad_split_shape_ok(n_chunks, K, N); }
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     const int cat = wgrad_takes_split(a) ? ((a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? GM_PROF_WGRAD_SPLIT16 : GM_PROF_WGRAD_SPLIT) : GM_PROF_WGRAD;
     gm_prof_begin(cat, s, 2 * a.rows * a.K * a.N);
@@ -1323,8 +1412,11 @@ static int launch_wgrad(const gm_wgrad_args& a, hipStream_t s) {
     w.TK = (a.K + 31) / 32; w.TN = (a.N + 31) / 32;
     bool launched = false;
     const bool fast_ok = wgrad_fast_ok(a);
+    GM_REQUIRE(!a.fuse2 || (wgrad_takes_split(a) && a.gx && a.np != 2 && a.lda <= (int64_t)(1 << 20) && a.ldgx <= (int64_t)(1 << 20)), GM_EINVAL,
+               "wgrad: a table-formed A operand needs the split kernel (K=%d N=%d chunks=%d)", a.K, a.N, a.n_chunks);
     if (wgrad_takes_split(a)) {
         const int np = (a.np == 2 && a.a_bound.amax && a.g_bound.amax) ? 2 : 3;
+        if (a.fuse2) { w.f2 = (const int4*)a.fuse2; w.gx = a.gx; w.ldgx = a.ldgx; w.zrow = gm_zero_row(s); GM_REQUIRE(w.zrow, GM_ENOMEM, "wgrad: no zero row"); }
         w.a_bound = a.a_bound; w.g_bound = a.g_bound;
         if (a.K == 256 && a.N == 256) GM_TRY((launch_wgrad_split<2, 2>(w, s, np)));
         else if (a.K == 128 && a.N == 256) GM_TRY((launch_wgrad_split<1, 2>(w, s, np)));

@@ -190,6 +190,7 @@ struct gm_knobs {
     int centre_store;              // GM_CENTRE_STORE: the last layer's update stores only the centre rows of its activation -- in every pass (2, default), in the forward-only passes (1) -- or every row (0)
     int gemm_fused_rounds, gemm_plain_rounds, gemm_half_tiles, gemm_bn, gemm_mid_tiles, gemm_glds, gemm_nt, gemm_small, wgrad_split, dz_glds;
     int fuse_agg, head_stage, side_stream_priority;
+    int fuse_diff;                 // GM_FUSE_DIFF: the differentiated passes of the dense schedule take the fused aggregate + GEMM too, their weight gradients form Z's rows from the source table: 2 (default) everywhere except a support batch whose full launches take the stream aggregate, 1 everywhere, 0 never
     int agg_mid_win;               // GM_AGG_MID_WIN: rows per wave window over that list (0 = by its length)
     int agg_mid_list;              // GM_AGG_MID_LIST: the partial aggregate launch of a fused pass walks a compact list of its window rows (1, default) or every row (0)
     int query_streams;             // GM_QUERY_STREAMS: 2 = the query evaluations of gm_meta_step alternate between two streams; anything else (default 0) = one stream
@@ -407,11 +408,16 @@ struct gm_wgrad_args {
     float* wt_next;                     // optional (with sgd_next): the updated W also written transposed, [set][N][K] -- what the NEXT
                                         // step's dZ GEMM (dQ @ W^T on the row-major DMA kernel) reads, instead of a transpose launch
     int64_t rows;                       // total rows covered by the chunks (profiling: flops = 2*rows*K*N)
+    // optional (split kernel only: gm_wgrad_gather_ok): A = Z of a pass whose forward ran the FUSED aggregate + GEMM -- rows of one or two sources are formed
+    // from gx (row stride ldgx) through the per-row table fuse2 (gm_batch::d_fuse2 / d_fuse2_feat) in the aggregate's fma order, rows the table flags
+    // GM_FUSE_SELF are read from A (the partial aggregate launch wrote them), GM_FUSE_ZERO rows are zero
+    const void* fuse2; const float* gx; int64_t ldgx;
     gm_wgrad_hold* hold; int hold_this; // optional: hold this call's reduction back (hold_this = 1; its `partial` must then stay untouched) /
                                         // flush the held ones with this call's reduction (hold_this = 0)
 };
 #define GM_WGRAD_ROWS 1024
 int gm_launch_wgrad(const gm_wgrad_args& a, hipStream_t s);
+bool gm_wgrad_gather_ok(int n_chunks, int K, int N);
 
 // Rows per weight-gradient chunk for sets of the given sizes.  One workgroup (one CU: 128 accumulator VGPRs x 16 waves)
 // takes one chunk and writes a (K+1)xN partial, so the chunk count should sit just under a multiple of the CU count (256) --

@@ -588,7 +588,10 @@ struct PlaneDir {
 struct GcnCtx {
     const gm_batch* b; gm_layout L;
     PlaneDir* pd;                // non-NULL inside gm_meta_step
+    bool is_support = false;     // gm_meta_step's support-chain context (the serial dependency of the step; the query contexts carry the bulk work)
     int dq_zeroed = 0;           // the last forward GEMM already zero-filled bufA (= dQ) for the head/loss launch that follows
+    bool zfused[GM_MAX_GCN] = {};    // the last forward left Z[l] written at the rows of three or more sources only (fused aggregate + GEMM in a pass that IS
+                                     // differentiated): the backward's weight gradient forms the other rows from the per-row source table (gm_wgrad_args::fuse2)
     float* Z[GM_MAX_GCN]; float* H[GM_MAX_GCN]; float* X0; float* bufA; float* bufB; float* partial;
     float* partial_l[GM_MAX_GCN];    // dense backward: own partials for the layers above the first, whose reductions are held back and run
     gm_wgrad_hold hold;              // together with the first layer's (one launch less per layer and backward pass)
@@ -765,11 +768,19 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             gm_prof_agg_end(st);
         } else {                            // learner.py:41-47: aggregate first, then multiply
             const bool split_ok = c.Wsplit && gm_gemm_split_ok(b->n_tiles, fi, fo) && ((uintptr_t)(params + L.b_off[l]) & 15) == 0 && pstride % 4 == 0;
-            const bool fuse = fwd_only == 1 && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
+            // ... and, round 6, the passes that ARE differentiated by the dense backward (fwd_only == 2: the support passes, the last query pass): their only
+            // other reader of Z_l is the weight gradient, whose split kernel forms the same rows from the same table (gm_wgrad_gather_ok; three-piece
+            // arithmetic only) -- the differentiated passes no longer write and re-read Z_l either (GM_FUSE_DIFF=0: as before)
+            // GM_FUSE_DIFF=2: ... except where the pass's full launches would take the stream aggregate (a support batch with stream tables, agg_stream.hip):
+            // that kernel runs INSIDE the CUs the query stream's GEMM occupies, a partial window launch competes with it for them
+            const bool keeps_stream = gm_knob().fuse_diff == 2 && c.is_support && gm_knob().agg_stream && b->d_sptr[0] != nullptr;
+            const bool diff_ok = fwd_only == 2 && gm_knob().fuse_diff && !keeps_stream && c.np != 2 && !c.cone && gm_wgrad_gather_ok(b->n_chunks, fi, fo);
+            const bool fuse = (fwd_only == 1 || diff_ok) && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
                               (!gather || (b->store->feat_ld % 4 == 0 && b->store->feat_ld >= fi)) &&
                               // worth it only where a good part of the rows has one or two sources: on dense batches (Tissue shape: ~30 in-edges per
                               // row) nearly every row still goes through the ordinary aggregate and the gather feeders only cost (3.30 -> 3.21 ms)
                               2 * b->unfused_rows <= b->rows;
+            c.zfused[l] = fuse && fwd_only == 2;
             if (!(l == 0 && reuse_z1 && c.z1_valid)) {
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st, c.hub_set)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
@@ -893,6 +904,11 @@ static int gcn_backward(GcnCtx& c, const float* params, int64_t pstride, const f
             // Order: dZ GEMM (reads dQ and the CURRENT weights) -> weight gradient (reads dQ; its reduction writes the updated
             // weights and, for the next step's dZ GEMM, their transpose) -> transposed aggregate (overwrites dQ).
             w.A = c.Z[l]; w.lda = fi; w.G = dQ; w.ldg = fo;
+            if (c.zfused[l]) {                 // the forward ran fused: Z[l] holds the rows of three or more sources, the table forms the others
+                const bool gather = l == 0 && !c.x0_user;
+                w.fuse2 = gather ? b->d_fuse2_feat : b->d_fuse2;
+                w.gx = gather ? b->store->d_feat : (l > 0 ? c.H[l - 1] : c.x0_user); w.ldgx = gather ? b->store->feat_ld : fi;
+            }
             if (l > 0) {
                 gm_gemm_args g{}; g.A = dQ; g.lda = fo; g.C = T; g.ldc = fi; g.K = fo; g.N = fi;
                 g.row_scale = b->d_norm; g.tiles = b->d_tiles; g.n_tiles = b->n_tiles; g.rows = b->rows;
@@ -1419,7 +1435,7 @@ static int meta_plan(MetaPlan& p, const gm_batch* spt, const gm_batch* qry, cons
                      int Ct, int ns, int nq, int64_t* need) {
     GM_TRY(gm_make_layout(m, &p.L));
     p.T = spt->sets; p.K = hp->update_step; p.Pp = (p.L.P + 63) / 64 * 64;
-    p.S = GcnCtx{}; p.Q = GcnCtx{}; p.Q2 = GcnCtx{}; p.S.b = spt; p.Q.b = qry; p.Q2.b = qry; p.S.L = p.L; p.Q.L = p.L; p.Q2.L = p.L;
+    p.S = GcnCtx{}; p.Q = GcnCtx{}; p.Q2 = GcnCtx{}; p.S.is_support = true; p.S.b = spt; p.Q.b = qry; p.Q2.b = qry; p.S.L = p.L; p.Q.L = p.L; p.Q2.L = p.L;
     if (hp->cone) {                      // receptive-field tables: built on first use, cached in the batch
         const gm_cone *cs = nullptr, *cq = nullptr;
         GM_TRY(gm_batch_cone(spt, p.L.n_gcn, spt->stream, &cs));

@@ -450,6 +450,8 @@ class _Deferred:
                                        'step; re-run with GM_SPLIT_PIECES=3 (the default) or read .accs() before queueing the next step')
                 lib = _lib.lib()
                 lib.gm_set_split_pieces(3)
+                if getattr(m, '_unchecked', None) is self:       # this handle IS being checked: the re-run must not come back to it
+                    m._unchecked = None
                 try:
                     self._accs = m.forward_deferred(x_spt, y_spt, x_qry, y_qry).accs()
                 finally:

@@ -2,11 +2,13 @@
 h-hop extraction, sampling, induced-subgraph build and batching done by HIP kernels
 (gm_extract, include/gmeta_hip.h) on HBM-resident CSR instead of DGL + Python loops."""
 import collections
+import concurrent.futures
 import csv
 import ctypes as C
 import itertools
 import os
 import random
+import threading
 
 import numpy as np
 import torch
@@ -87,7 +89,11 @@ class SubgraphBatch:
         _lib.check(_lib.lib().gm_extract(store.handle, _lib.ptr(arr), len(arr), _lib.ptr(so), len(so) - 1, int(h), int(sample_nodes),
                                          C.c_uint64(int(rng_seed) & (2 ** 64 - 1)), int(bool(link_pred)), _lib.stream_ptr(), C.byref(out)),
                    'gm_extract')
-        return cls(out, store)
+        b = cls(out, store)
+        # what the host already knows is never read back from the device (a gm_batch_read synchronises the batch's stream)
+        b._cache[(_lib.F_SET_SUB_OFF,)] = so
+        b._cache[(_lib.F_GRAPH,)] = np.ascontiguousarray(arr[:, 0])
+        return b
 
     @classmethod
     def from_nodes(cls, store, seeds, set_offsets, node_lists, link_pred):
@@ -379,16 +385,16 @@ class Subgraphs(Dataset):
 
     def _labels(self, support_y, query_y):
         if self.task_setup == 'Disjoint':                                     # sdp.py:389-397
-            unique = np.unique(support_y)
+            # a handful of labels per task: plain Python beats five numpy calls (this runs per task between two meta-steps, under the GIL)
+            sl, ql = support_y.tolist(), query_y.tolist()
+            unique = sorted(set(sl))                                          # np.unique(support_y)
             # random.shuffle(unique) of the reference, applied to an index list: the same draws, the same permutation
             order = list(range(len(unique)))
             random.shuffle(order)
-            rank = np.empty(len(unique), np.int64)
-            rank[order] = np.arange(len(unique))                               # class unique[order[idx]] -> idx
-            sy = rank[np.searchsorted(unique, support_y)]
-            pos = np.minimum(np.searchsorted(unique, query_y), len(unique) - 1)
-            qy = np.where(unique[pos] == query_y, rank[pos], 0)                # a query class absent from the support keeps 0 (np.zeros, sdp.py:393)
-            return torch.from_numpy(sy), torch.from_numpy(qy.astype(np.int64))
+            rank = {unique[o]: idx for idx, o in enumerate(order)}            # class unique[order[idx]] -> idx
+            get = rank.get
+            return (torch.tensor([rank[c] for c in sl], dtype=torch.int64),
+                    torch.tensor([get(c, 0) for c in ql], dtype=torch.int64))   # a query class absent from the support keeps 0 (np.zeros, sdp.py:393)
         return torch.from_numpy(support_y.astype(np.int64)), torch.from_numpy(query_y.astype(np.int64))
 
     def _tuple(self, bs, bq, ys, yq):
@@ -459,15 +465,55 @@ class Subgraphs(Dataset):
         Q = SubgraphBatch.from_nodes(self.G, np.concatenate([t[2] for t in tasks]), off_q, lq, self.link_pred_mode)
         return S, Q
 
-    def _extract_tasks(self, indices):
-        arrs = [self._task_arrays(i) for i in indices]
+    # The support and the query batch of a meta-batch are independent builds (two gm_extract calls, each with two host round trips and ~0.1-0.3 ms
+    # of host-side table work between its kernels): the support batch is built by a helper thread on a stream of its own while the calling thread
+    # builds the query batch -- ctypes releases the GIL for the length of the call.  The caller's stream then waits for the helper stream's event, so
+    # consumers see both batches complete; gm_batch_destroy orders its frees behind the consumers' work (gm_batch_mark_use) as for prefetched batches.
+    # One helper per calling thread (the training thread and every prefetch worker have their own).  GMETA_EXTRACT_THREADS=1: one after the other.
+    _tls = threading.local()
+
+    def _helper(self):
+        if os.environ.get('GMETA_EXTRACT_THREADS', '2') == '1':
+            return None
+        h = getattr(self._tls, 'helper', None)
+        dev = torch.cuda.current_device()
+        if h is None or h[2] != dev:
+            ex = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='gmeta-extract')
+            h = self._tls.helper = (ex, ex.submit(self._helper_init, dev).result(), dev)
+        return h
+
+    @staticmethod
+    def _helper_init(dev):
+        torch.cuda.set_device(dev)
+        return torch.cuda.Stream()
+
+    def _extract_on(self, stream, seeds, off):
+        with torch.cuda.stream(stream):
+            b = SubgraphBatch.extract(self.G, seeds, off, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return b, ev
+
+    def _extract_tasks(self, indices, arrs=None):
+        if arrs is None:
+            arrs = [self._task_arrays(i) for i in indices]
         if self.sample_mode == 'reference':
             names = [self._task_names(i) for i in indices]
             S, Q = self._extract_reference([(a[0], n[0], a[1], n[1]) for a, n in zip(arrs, names)])
             return arrs, S, Q
         off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
-        S = SubgraphBatch.extract(self.G, np.concatenate([a[0] for a in arrs]), off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
-        Q = SubgraphBatch.extract(self.G, np.concatenate([a[1] for a in arrs]), off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        seeds_s = np.concatenate([a[0] for a in arrs]); seeds_q = np.concatenate([a[1] for a in arrs])
+        helper = self._helper() if len(seeds_q) >= 64 else None           # (tiny batches: the hand-over costs more than it hides)
+        if helper is None:
+            S = SubgraphBatch.extract(self.G, seeds_s, off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+            Q = SubgraphBatch.extract(self.G, seeds_q, off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+            return arrs, S, Q
+        fut = helper[0].submit(self._extract_on, helper[1], seeds_s, off_s)
+        try:
+            Q = SubgraphBatch.extract(self.G, seeds_q, off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+        finally:
+            S, ev = fut.result()                                              # (also re-raises the helper's failure)
+        torch.cuda.current_stream().wait_event(ev)
         return arrs, S, Q
 
     def __getitem__(self, index):
@@ -481,23 +527,49 @@ class Subgraphs(Dataset):
         meta-batch are extracted by two launches (support / query); returns the collated 10-tuple of lists."""
         if len(indices) == 0:           # an empty task shard (more ranks than tasks in a short trailing meta-batch)
             return tuple([] for _ in range(10))
-        arrs, S, Q = self._extract_tasks(indices)
-        ys_yq = [self._labels(a[2], a[3]) for a in arrs]
-        return collate([self._tuple(bs, bq, ys, yq) for bs, bq, (ys, yq) in zip(S.views(), Q.views(), ys_yq)])
+        return self._build(self._prepare(indices))
+
+    def _prepare(self, indices):
+        """Host half of get_batch that consumes the global Python RNG (the per-task label shuffle of sdp.py:390-397): per-task arrays and
+        relabelled targets, in task order.  batches(workers > 1) runs it in the consumer's thread, in meta-batch order, so that the draws do
+        not depend on which worker builds which meta-batch."""
+        arrs = [self._task_arrays(i) for i in indices]
+        return list(indices), arrs, [self._labels(a[2], a[3]) for a in arrs]
+
+    def _build(self, prep):
+        indices, arrs, labels = prep
+        arrs, S, Q = self._extract_tasks(indices, arrs)
+        # the ten slots of every task (what _tuple builds one view at a time), from ONE read of each batch's centre table and host-side slices
+        cols = [S.views(), [y[0] for y in labels], Q.views(), [y[1] for y in labels], None, None, None, None, None, None]
+        for b, k in ((S, 0), (Q, 1)):
+            off = b.set_sub_off.tolist()
+            cen = torch.from_numpy(b._read(_lib.F_CENTRE, b.subs * b.centres, np.int32).astype(np.int64).reshape(b.subs, b.centres))
+            if b.centres == 1:
+                cen = cen[:, 0]
+            gid = b._read(_lib.F_GRAPH, b.subs, np.int32).tolist()
+            cols[4 + k] = [cen[off[t]:off[t + 1]] for t in range(b.sets)]
+            cols[6 + k] = [_NodeLists(b, off[t], off[t + 1]) for t in range(b.sets)]
+            cols[8 + k] = [gid[off[t]:off[t + 1]] for t in range(b.sets)]
+        return tuple(cols)
 
     _PREFETCH_PRIORITY = 0      # stream priority of the prefetch thread (a high-priority stream measured no better: extraction is host-bound)
 
-    def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None):
+    def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None, workers=1):
         """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being extracted by a
         background thread on its own HIP stream while the caller runs the meta-step on the current one -- what
         DataLoader(num_workers>0) does for the reference (train.py:96,173), minus the per-worker copy of the memo cache
-        (sdp.py:296-297,319).  cone_layers = n_gcn also builds the receptive-field tables (gm_hparams_t.cone) there."""
+        (sdp.py:296-297,319).  cone_layers = n_gcn also builds the receptive-field tables (gm_hparams_t.cone) there.
+        workers > 1: that many builder threads (each with its own stream), meta-batches delivered in order -- for schedules whose
+        meta-step is shorter than one batch build (the receptive-field schedule at task_num 32: 2.2 ms against ~3 ms)."""
         import queue
         import threading
         index_lists = [list(int(i) for i in idx) for idx in index_lists]
         if prefetch <= 0 or len(index_lists) <= 1:
             for idx in index_lists:
                 yield self.get_batch(idx)
+            return
+        if workers > 1:
+            yield from self._batches_pool(index_lists, max(prefetch, workers), cone_layers, priority, workers)
             return
         dev = torch.cuda.current_device()
         q = queue.Queue(maxsize=prefetch)
@@ -539,6 +611,43 @@ class Subgraphs(Dataset):
                 except queue.Empty:
                     pass
                 th.join(timeout=0.05)
+
+    def _batches_pool(self, index_lists, depth, cone_layers, priority, workers):
+        dev = torch.cuda.current_device()
+        tls = threading.local()
+
+        def job(prep):
+            if not prep[0]:
+                return tuple([] for _ in range(10))
+            side = getattr(tls, 'side', None)
+            if side is None:
+                torch.cuda.set_device(dev)
+                side = tls.side = torch.cuda.Stream(priority=self._PREFETCH_PRIORITY if priority is None else int(priority))
+            with torch.cuda.stream(side):
+                b = self._build(prep)
+                if cone_layers:
+                    for x in (b[0][0], b[2][0]):
+                        root = x.view_of if x.view_of is not None else x
+                        _lib.check(_lib.lib().gm_batch_prepare_cone(root.handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone')
+                side.synchronize()
+            return b
+        pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix='gmeta-batches')
+        pending = collections.deque()
+        it = iter(index_lists)
+        try:
+            while True:
+                while len(pending) < depth:
+                    idx = next(it, None)
+                    if idx is None:
+                        break
+                    pending.append(pool.submit(job, self._prepare(idx) if idx else ([], [], [])))      # RNG draws here, in meta-batch order
+                if not pending:
+                    break
+                yield pending.popleft().result()
+        finally:
+            for f in pending:
+                f.cancel()
+            pool.shutdown(wait=True)
 
     def __len__(self):
         return self.batchsz

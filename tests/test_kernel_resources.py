@@ -80,3 +80,19 @@ def test_persistent_split_gemm_leaves_32_vgprs_per_simd_lane(objs):
     big = {k: regs[k] for k, d in names.items() if re.search(r'k_gemm_split_p<(true|false), 2, 4, 3>', d)}
     assert len(big) >= 1, names
     assert all(4 * v + 32 <= 512 for v in big.values()), big                                        # 16 waves = 4 per SIMD
+
+
+def test_weight_gradient_loader_never_touches_a_register_with_a_load_in_flight(objs):
+    """k_wgrad_split keeps two stages of operand rows in flight in registers the COMPILER allocates around hand-counted inline-asm loads: nothing tells it
+    that a destination register is not there yet, so a phi copy on the loop back-edge or a reused temporary silently reads / clobbers rows in flight (a round-6
+    variant of the loader came out with eleven such copies at its loop head and faulted on the GPU).  tools/check_inflight_regs.py replays every
+    instantiation's ISA -- prologue, loop body twice -- against the hardware rule (loads return in order, vmcnt(N) retires all but the newest N)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import check_inflight_regs as chk
+    with tempfile.TemporaryDirectory() as tmp:
+        dev = chk.device_elf(os.path.join(objs, 'gemm.o'), tmp)
+        names = sorted(set(n for n in chk.kernels(dev) if 'k_wgrad_split' in n))
+        assert len(names) >= 12, names                        # {1,2} x {1,2} tiles x (three-piece, two-piece, three-piece table-formed A)
+        bad = {n: chk.check(chk.disasm(dev, n))[:3] for n in names}
+    assert not any(bad.values()), {n: h for n, h in bad.items() if h}

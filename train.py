@@ -121,7 +121,9 @@ def main(args):
             chunk = order[step * args.task_num:(step + 1) * args.task_num]            # the last one may be short
             b = np.linspace(0, len(chunk), world + 1).round().astype(int)
             shards.append(chunk[int(b[rank]):int(b[rank + 1])])                       # may be empty on a short trailing batch: contributes zeros
-        it = iter(db_train.batches(shards, prefetch=args.num_workers, cone_layers=args.h if getattr(args, 'cone', 0) else 0))
+        # num_workers (train.py:96,173): meta-batches built ahead by that many builder threads (at most 4), delivered in order
+        it = iter(db_train.batches(shards, prefetch=args.num_workers, cone_layers=args.h if getattr(args, 'cone', 0) else 0,
+                                   workers=max(1, min(int(args.num_workers), 4))))
         for step in range(n_steps):
             s = time.time()
             batch = next(it)            # extracted by the prefetch thread while the previous meta-step ran (num_workers > 0)
