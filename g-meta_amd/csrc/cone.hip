@@ -41,7 +41,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_sums(const int32_t* in, int64_t
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 // exclusive scan of the block sums in place; bsum[nb] = grand total
-__global__ __launch_bounds__(SCAN_T) void k_scan_top(int32_t* bsum, int nb) {
+__global__ __launch_bounds__(SCAN_T) void k_scan_top(int32_t* bsum, int nb, int32_t* total_out) {
     __shared__ int sm[SCAN_T];
     int carry = 0;
     for (int c0 = 0; c0 < nb; c0 += SCAN_T) {
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_top(int32_t* bsum, int nb) {
         if (i < nb) bsum[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0) bsum[nb] = carry;
+    if (threadIdx.x == 0) { bsum[nb] = carry; if (total_out) *total_out = carry; }
 }
 // out[i] = exclusive prefix; out[n] = total when tail != 0.  in == out is allowed.
 __global__ __launch_bounds__(SCAN_T) void k_scan_final(const int32_t* in, int64_t n, const int32_t* bsum, int32_t* out, int tail) {
@@ -67,22 +67,12 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_final(const int32_t* in, int64_
     if (tail && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = bsum[gridDim.x];
 }
 
-// exclusive scan of n ints; *total (host) = sum.  Synchronises the stream.
-static int dev_scan(const int32_t* in, int32_t* out, int64_t n, int tail, int32_t* total, hipStream_t s) {
-    if (n <= 0) { if (total) *total = 0; if (tail) GM_HIP(hipMemsetAsync(out, 0, 4, s)); return GM_OK; }
+// exclusive scan of n ints on the stream; the sum stays on the device (*d_total, optional).  bsum: scratch of n / SCAN_B + 2 ints.
+static void dev_scan(const int32_t* in, int32_t* out, int64_t n, int tail, int32_t* d_total, int32_t* bsum, hipStream_t s) {
     const int nb = (int)((n + SCAN_B - 1) / SCAN_B);
-    int32_t* bsum = nullptr;
-    GM_TRY(gm_alloc(&bsum, (size_t)nb + 1, s));
     hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(SCAN_T), 0, s, in, n, bsum);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, s, bsum, nb);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(SCAN_T), 0, s, bsum, nb, d_total);
     hipLaunchKernelGGL(k_scan_final, dim3(nb), dim3(SCAN_T), 0, s, in, n, bsum, out, tail);
-    int32_t tot = 0;
-    hipError_t e = hipMemcpyAsync(&tot, bsum + nb, 4, hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    gm_dev_free(bsum, s);
-    if (e != hipSuccess) { gm_set_error("cone: scan failed: %s", hipGetErrorString(e)); return GM_EHIP; }
-    if (total) *total = tot;
-    return GM_OK;
 }
 
 // ------------------------------------------------------------------------------------------ build kernels
@@ -98,19 +88,21 @@ __global__ void k_check_pos(const int32_t* row, int n, const int32_t* pos, int32
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n && pos[row[k]] != k) atomicAdd(bad, 1);
 }
+// Round 6: the builder knows the level sizes only as UPPER BOUNDS while it queues its kernels (one host round trip at the very end instead of ~10 per
+// level): grids are sized by the bound, the actual count is read from device memory (n_ptr).
 // one wave per upper-level row: flag the sources of its in-edges, record its in-degree
-__global__ __launch_bounds__(256) void k_mark(const int32_t* up_row, int n_up, const int32_t* indptr, const int32_t* indices, int32_t* flags, int32_t* deg) {
+__global__ __launch_bounds__(256) void k_mark(const int32_t* up_row, const int32_t* n_ptr, const int32_t* indptr, const int32_t* indices, int32_t* flags, int32_t* deg) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (q >= n_up) return;
+    if (q >= *n_ptr) return;
     const int r = up_row[q], e0 = indptr[r], e1 = indptr[r + 1];
     for (int e = e0 + lane; e < e1; e += 64) flags[indices[e]] = 1;
     if (lane == 0) deg[q] = e1 - e0;
 }
-__global__ void k_set_off(const int32_t* scan, const int32_t* set_row_off, int sets, int64_t rows, int32_t total, int32_t* set_off) {
+__global__ void k_set_off(const int32_t* scan, const int32_t* set_row_off, int sets, int64_t rows, const int32_t* total, int32_t* set_off) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > sets) return;
     const int64_t r = set_row_off[t];
-    set_off[t] = (t == sets || r >= rows) ? total : scan[r];
+    set_off[t] = (t == sets || r >= rows) ? *total : scan[r];
 }
 // compact the flagged rows; scan[] becomes the row -> compact id map (-1 outside the level)
 __global__ void k_level_rows(const int32_t* flags, int32_t* scan, int64_t rows, const float* norm, const int32_t* feat_row,
@@ -124,19 +116,19 @@ __global__ void k_level_rows(const int32_t* flags, int32_t* scan, int64_t rows, 
     }
 }
 // forward CSR of the upper level: every in-edge of an upper row, sources renamed to compact ids of the lower level
-__global__ __launch_bounds__(256) void k_fill_in(const int32_t* up_row, int n_up, const int32_t* indptr, const int32_t* indices, const int32_t* pos_lo,
+__global__ __launch_bounds__(256) void k_fill_in(const int32_t* up_row, const int32_t* n_ptr, const int32_t* indptr, const int32_t* indices, const int32_t* pos_lo,
                                                  const int32_t* cptr, int32_t* cidx) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (q >= n_up) return;
+    if (q >= *n_ptr) return;
     const int r = up_row[q], e0 = indptr[r], n = indptr[r + 1] - e0, o = cptr[q];
     for (int j = lane; j < n; j += 64) cidx[o + j] = pos_lo[indices[e0 + j]];
 }
 // backward CSR: out-edges of a lower-level row that end in the upper level, in the batch's by-source order.
 // pass 0 counts, pass 1 fills (order preserved with a ballot prefix: deterministic).
-__global__ __launch_bounds__(256) void k_out_edges(const int32_t* lo_row, int n_lo, const int32_t* indptr_t, const int32_t* indices_t, const int32_t* pos_up,
+__global__ __launch_bounds__(256) void k_out_edges(const int32_t* lo_row, const int32_t* n_ptr, const int32_t* indptr_t, const int32_t* indices_t, const int32_t* pos_up,
                                                    int32_t* cnt, const int32_t* tptr, int32_t* tidx) {
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (p >= n_lo) return;
+    if (p >= *n_ptr) return;
     const int u = lo_row[p], e0 = indptr_t[u], e1 = indptr_t[u + 1];
     int base = tidx ? tptr[p] : 0;
     for (int eb = e0; eb < e1; eb += 64) {
@@ -148,32 +140,37 @@ __global__ __launch_bounds__(256) void k_out_edges(const int32_t* lo_row, int n_
     }
     if (!tidx && lane == 0) cnt[p] = base;
 }
-__global__ void k_find_heavy_c(const int32_t* indptr, int n, int32_t* list, int32_t* count, int cap, int thr) {
+// hub rows of a compact CSR, ascending (ordered compaction: flag -> scan -> scatter; no host sort): flag[r] = in-degree of r above thr, r < *n_ptr
+__global__ void k_heavy_flag(const int32_t* indptr, const int32_t* n_ptr, int bound, int thr, int32_t* flag) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n && indptr[r + 1] - indptr[r] > thr) { const int k = atomicAdd(count, 1); if (k < cap) list[k] = r; }
+    if (r < bound) flag[r] = (r < *n_ptr && indptr[r + 1] - indptr[r] > thr) ? 1 : 0;
+}
+__global__ void k_heavy_scatter(const int32_t* flag, const int32_t* pos, int bound, int cap, int32_t* list) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < bound && flag[r] && pos[r] < cap) list[pos[r]] = r;
 }
 
 // ------------------------------------------------------------------------------------------ host
 void gm_cone_free(gm_cone* c, hipStream_t s) {
     if (!c) return;
-    for (int l = 0; l <= GM_MAX_GCN; ++l) {
-        gm_cone_level& v = c->lv[l];
-        gm_dev_free(v.d_row, s); gm_dev_free(v.d_norm, s); gm_dev_free(v.d_feat_row, s); gm_dev_free(v.d_set_off, s);
-        gm_dev_free(v.d_tiles, s); gm_dev_free(v.d_chunks, s); gm_dev_free(v.d_set_chunk_off, s);
-        gm_dev_free(v.d_indptr, s); gm_dev_free(v.d_indices, s); gm_dev_free(v.d_indptr_t, s); gm_dev_free(v.d_indices_t, s);
-        gm_dev_free(v.d_heavy[0], s); gm_dev_free(v.d_heavy[1], s);
-    }
+    gm_dev_free(c->slab, s);        // every level array lives in it
     delete c;
 }
 
-static int upload(int32_t** d, const std::vector<int32_t>& v, hipStream_t s) {
-    GM_TRY(gm_alloc(d, v.size(), s));
-    if (!v.empty()) GM_HIP(hipMemcpyAsync(*d, v.data(), 4 * v.size(), hipMemcpyHostToDevice, s));
-    return GM_OK;
-}
+// 256-byte aligned carving; base == NULL: sizing pass
+struct ConeCarver {
+    char* base; size_t used = 0;
+    explicit ConeCarver(void* p) : base((char*)p) {}
+    template <class T> T* take(size_t n) {
+        const size_t bytes = ((n ? n : 1) * sizeof(T) + 255) / 256 * 256;
+        T* r = base ? (T*)(base + used) : nullptr;
+        used += bytes;
+        return r;
+    }
+};
 
-// GEMM row tiles and weight-gradient chunks of one level (never straddling two sets: each set has its own weights)
-static int level_tables(gm_cone_level& v, int sets, hipStream_t s) {
+// GEMM row tiles and weight-gradient chunks of one level (never straddling two sets: each set has its own weights); uploaded through pinned staging
+static int level_tables(gm_cone_level& v, int sets, gm_stager& sg) {
     std::vector<int32_t> tiles, chunks, coff(sets + 1, 0);
     const int64_t cr = gm_wgrad_chunk_rows(v.h_set_off);
     for (int t = 0; t < sets; ++t) {
@@ -183,95 +180,125 @@ static int level_tables(gm_cone_level& v, int sets, hipStream_t s) {
         coff[t + 1] = (int32_t)(chunks.size() / 3);
     }
     v.n_tiles = (int32_t)(tiles.size() / 3); v.n_chunks = (int32_t)(chunks.size() / 3);
-    GM_TRY(upload(&v.d_tiles, tiles, s)); GM_TRY(upload(&v.d_chunks, chunks, s)); GM_TRY(upload(&v.d_set_chunk_off, coff, s));
-    GM_HIP(hipStreamSynchronize(s));
+    GM_TRY(sg.upload(v.d_tiles, tiles)); GM_TRY(sg.upload(v.d_chunks, chunks)); GM_TRY(sg.upload(v.d_set_chunk_off, coff));
     return GM_OK;
 }
 
-static int heavy_list(const int32_t* indptr, int n, int nnz, int thr, int32_t** list, int32_t* count, hipStream_t s) {
-    *count = 0;
-    const int cap = nnz / thr + 1;
-    int32_t* d_cnt = nullptr;
-    GM_TRY(gm_alloc(list, cap, s)); GM_TRY(gm_alloc(&d_cnt, 1, s));
-    GM_HIP(hipMemsetAsync(d_cnt, 0, 4, s));
-    if (n > 0) hipLaunchKernelGGL(k_find_heavy_c, dim3((n + 255) / 256), dim3(256), 0, s, indptr, n, *list, d_cnt, cap, thr);
-    int32_t c = 0;
-    GM_HIP(hipMemcpyAsync(&c, d_cnt, 4, hipMemcpyDeviceToHost, s));
-    GM_HIP(hipStreamSynchronize(s));
-    gm_dev_free(d_cnt, s);
-    c = std::min(c, cap);
-    if (c > 1) {                          // deterministic order
-        std::vector<int32_t> h(c);
-        GM_HIP(hipMemcpyAsync(h.data(), *list, 4 * (size_t)c, hipMemcpyDeviceToHost, s));      // stream-ordered: a plain hipMemcpy would serialise with the default stream
-        GM_HIP(hipStreamSynchronize(s));
-        std::sort(h.begin(), h.end());
-        GM_HIP(hipMemcpyAsync(*list, h.data(), 4 * (size_t)c, hipMemcpyHostToDevice, s));
-        GM_HIP(hipStreamSynchronize(s));
-    }
-    *count = c;
-    return GM_OK;
-}
-
-static int cone_build(const gm_batch* b, int L, hipStream_t s, gm_cone* c, int32_t* posA, int32_t* posB, int32_t* flags, int32_t* d_bad) {
+// The build queues EVERYTHING from upper bounds and makes ONE host round trip at the end (round 6).  Before, every level cost ~10 round trips (three
+// scans, two hub lists with a host sort each, the set offsets, pageable table uploads): ~45 per meta-batch, each waiting for its few microseconds of
+// kernels to be scheduled beside a running meta-step -- 6 ms of a prefetched batch build at the arxiv shape, three times the receptive-field step it feeds.
+// Bounds: level L = the centres (exact); level L - 1 holds at most as many rows as the centres have in-edges (gm_batch::n_e1, which is also the
+// exact edge count into level L); deeper levels at most every row / every edge of the batch.  Level arrays are carved from ONE allocation of the
+// bounds' size (arxiv query batch, two layers: ~45 MB), grids are sized by the bounds and read the real counts from device memory.
+static int cone_build(const gm_batch* b, int L, hipStream_t s, gm_cone* c) {
     const int64_t rows = b->rows; const int sets = b->sets;
-    const int fill_blocks = (int)std::min<int64_t>(2048, (rows + 255) / 256);
     c->L = L; c->heavy_deg = gm_heavy_deg();
+    GM_REQUIRE(rows < ((int64_t)1 << 30) && b->edges < ((int64_t)1 << 30), GM_ERANGE, "cone: batch too large");
+    int64_t Bn[GM_MAX_GCN + 1], Be[GM_MAX_GCN + 1];               // row bound of level l; bound of the edges from level l - 1 into level l
+    Bn[L] = b->n_c; Be[L] = b->n_e1;
+    for (int l = L - 1; l >= 0; --l) { Bn[l] = (l == L - 1) ? std::min<int64_t>(rows, b->n_e1) : rows; Be[l] = l > 0 ? b->edges : 0; }
+    auto tile_cap = [&](int64_t n) { return (size_t)(n / GM_GEMM_BM + sets + 1) * 3; };
+    auto chunk_cap = [&](int64_t n) { return (size_t)(n / 128 + sets + 1) * 3; };      // (gm_wgrad_chunk_rows returns at least 128 rows per chunk)
+    auto hcap = [&](int64_t e) { return (size_t)(e / c->heavy_deg + 1); };
+    auto carve = [&](ConeCarver& cv) {
+        for (int l = 0; l <= L; ++l) {
+            gm_cone_level& v = c->lv[l];
+            v.d_row = cv.take<int32_t>(Bn[l]); v.d_norm = cv.take<float>(Bn[l]); v.d_set_off = cv.take<int32_t>(sets + 1);
+            v.d_feat_row = l == 0 ? cv.take<int32_t>(Bn[l]) : nullptr;
+            v.d_tiles = cv.take<int32_t>(tile_cap(Bn[l])); v.d_chunks = cv.take<int32_t>(chunk_cap(Bn[l])); v.d_set_chunk_off = cv.take<int32_t>(sets + 1);
+            if (l > 0) {
+                v.d_indptr = cv.take<int32_t>(Bn[l] + 1); v.d_indices = cv.take<int32_t>(Be[l]);
+                v.d_indptr_t = cv.take<int32_t>(Bn[l - 1] + 1); v.d_indices_t = cv.take<int32_t>(Be[l]);
+                v.d_heavy[0] = cv.take<int32_t>(hcap(Be[l])); v.d_heavy[1] = cv.take<int32_t>(hcap(Be[l]));
+            }
+        }
+    };
+    { ConeCarver size(nullptr); carve(size); GM_TRY(gm_dev_alloc(&c->slab, size.used + 256, s)); }
+    { ConeCarver cv(c->slab); carve(cv); }
+    // scratch of the build (freed, stream-ordered, when it returns): position maps, flags, degree / count arrays, scan partials, the device-side counts
+    const int64_t maxb = std::max<int64_t>(rows, 1);
+    void* tmp = nullptr;
+    ConeCarver ts(nullptr);
+    auto carve_tmp = [&](ConeCarver& cv, int32_t*& posA, int32_t*& posB, int32_t*& flags, int32_t*& deg, int32_t*& hpos, int32_t*& bsum, int32_t*& cnts) {
+        posA = cv.take<int32_t>(maxb); posB = cv.take<int32_t>(maxb); flags = cv.take<int32_t>(maxb); deg = cv.take<int32_t>(maxb + 1); hpos = cv.take<int32_t>(maxb + 1);
+        bsum = cv.take<int32_t>(maxb / SCAN_B + 4); cnts = cv.take<int32_t>(8 * (GM_MAX_GCN + 1));
+    };
+    int32_t *posA, *posB, *flags, *deg, *hpos, *bsum, *cnts;
+    carve_tmp(ts, posA, posB, flags, deg, hpos, bsum, cnts);
+    GM_TRY(gm_dev_alloc(&tmp, ts.used + 256, s));
+    { ConeCarver cv(tmp); carve_tmp(cv, posA, posB, flags, deg, hpos, bsum, cnts); }
+    // device-side counts, per level l: [0] n, [1] nnz (edges into l, by destination), [2] the same counted by source, [3] / [4] hub rows; cnts[8 L + 5] = bad
+    auto cnt = [&](int l, int k) { return cnts + 8 * l + k; };
+    gm_stager sg(s);
+    int rc = GM_OK;
+    auto fail = [&](int r) { gm_dev_free(tmp, s); return r; };
+    if (hipMemsetAsync(cnts, 0, 4 * 8 * (GM_MAX_GCN + 1), s) != hipSuccess) { gm_set_error("cone: memset failed"); return fail(GM_EHIP); }
     // ---- level L: the centres, in centre order
     gm_cone_level& top = c->lv[L];
-    top.n = b->n_c;
-    GM_TRY(gm_alloc(&top.d_row, top.n, s)); GM_TRY(gm_alloc(&top.d_norm, top.n, s));
-    GM_HIP(hipMemcpyAsync(top.d_row, b->d_crow, 4 * (size_t)top.n, hipMemcpyDeviceToDevice, s));
-    GM_HIP(hipMemcpyAsync(top.d_norm, b->d_cnorm, 4 * (size_t)top.n, hipMemcpyDeviceToDevice, s));
+    top.n = b->n_c; top.nnz = 0;
+    if (hipMemcpyAsync(top.d_row, b->d_crow, 4 * (size_t)top.n, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(top.d_norm, b->d_cnorm, 4 * (size_t)top.n, hipMemcpyDeviceToDevice, s) != hipSuccess) { gm_set_error("cone: copy failed"); return fail(GM_EHIP); }
     top.h_set_off.resize(sets + 1);
     for (int t = 0; t <= sets; ++t) top.h_set_off[t] = b->h_set_sub_off[t] * b->centres;
-    GM_TRY(upload(&top.d_set_off, top.h_set_off, s));
-    GM_TRY(level_tables(top, sets, s));
+    if ((rc = sg.upload(top.d_set_off, top.h_set_off)) != GM_OK || (rc = level_tables(top, sets, sg)) != GM_OK) return fail(rc);
+    { const int32_t n32 = top.n; if ((rc = sg.upload(cnt(L, 0), &n32, 4)) != GM_OK) return fail(rc); }
+    const int fill_blocks = (int)std::min<int64_t>(2048, (rows + 255) / 256);
     hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s, posA, rows, -1);
-    if (top.n > 0) hipLaunchKernelGGL(k_scatter_pos, dim3((top.n + 255) / 256), dim3(256), 0, s, top.d_row, top.n, posA);
-    GM_HIP(hipMemsetAsync(d_bad, 0, 4, s));
-    if (top.n > 0) hipLaunchKernelGGL(k_check_pos, dim3((top.n + 255) / 256), dim3(256), 0, s, top.d_row, top.n, posA, d_bad);
-    int32_t bad = 0;
-    GM_HIP(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, s));
-    GM_HIP(hipStreamSynchronize(s));
-    if (bad) { c->ok = false; return GM_OK; }      // two centres on one row (a self pair): callers fall back to the dense schedule
+    if (top.n > 0) {
+        hipLaunchKernelGGL(k_scatter_pos, dim3((top.n + 255) / 256), dim3(256), 0, s, top.d_row, top.n, posA);
+        hipLaunchKernelGGL(k_check_pos, dim3((top.n + 255) / 256), dim3(256), 0, s, top.d_row, top.n, posA, cnt(L, 5));
+    }
     // ---- levels L-1 .. 0
     for (int l = L - 1; l >= 0; --l) {
         gm_cone_level& up = c->lv[l + 1]; gm_cone_level& lo = c->lv[l];
-        int32_t* deg = nullptr;
-        GM_TRY(gm_alloc(&deg, (size_t)up.n + 1, s));
+        const int bu = (int)std::max<int64_t>(Bn[l + 1], 1), bl = (int)std::max<int64_t>(Bn[l], 1);
         GM_HIP(hipMemsetAsync(flags, 0, 4 * (size_t)rows, s));
-        if (up.n > 0) hipLaunchKernelGGL(k_mark, dim3((up.n + 3) / 4), dim3(256), 0, s, up.d_row, up.n, b->d_indptr, b->d_indices, flags, deg);
-        int32_t n_lo = 0, nnz = 0;
-        int rc = dev_scan(flags, posB, rows, 0, &n_lo, s);
-        if (rc == GM_OK) { GM_TRY(gm_alloc(&up.d_indptr, (size_t)up.n + 1, s)); rc = dev_scan(deg, up.d_indptr, up.n, 1, &nnz, s); }
-        gm_dev_free(deg, s);
-        GM_TRY(rc);
-        lo.n = n_lo; up.nnz = nnz;
-        GM_TRY(gm_alloc(&lo.d_row, lo.n, s)); GM_TRY(gm_alloc(&lo.d_norm, lo.n, s)); GM_TRY(gm_alloc(&lo.d_set_off, sets + 1, s));
-        if (l == 0) GM_TRY(gm_alloc(&lo.d_feat_row, lo.n, s));
-        hipLaunchKernelGGL(k_set_off, dim3((sets + 256) / 256), dim3(256), 0, s, posB, b->d_set_row_off, sets, rows, n_lo, lo.d_set_off);
+        GM_HIP(hipMemsetAsync(deg, 0, 4 * ((size_t)bu + 1), s));
+        hipLaunchKernelGGL(k_mark, dim3((bu + 3) / 4), dim3(256), 0, s, up.d_row, cnt(l + 1, 0), b->d_indptr, b->d_indices, flags, deg);
+        dev_scan(flags, posB, rows, 0, cnt(l, 0), bsum, s);                                  // row -> compact id of level l; its size
+        dev_scan(deg, up.d_indptr, bu, 1, cnt(l + 1, 1), bsum, s);                           // forward CSR bounds of level l + 1; nnz
+        hipLaunchKernelGGL(k_set_off, dim3((sets + 256) / 256), dim3(256), 0, s, posB, b->d_set_row_off, sets, rows, cnt(l, 0), lo.d_set_off);
         hipLaunchKernelGGL(k_level_rows, dim3(fill_blocks), dim3(256), 0, s, flags, posB, rows, b->d_norm, b->d_feat_row, lo.d_row, lo.d_norm, lo.d_feat_row);
-        lo.h_set_off.resize(sets + 1);
-        GM_HIP(hipMemcpyAsync(lo.h_set_off.data(), lo.d_set_off, 4 * (size_t)(sets + 1), hipMemcpyDeviceToHost, s));
-        GM_HIP(hipStreamSynchronize(s));
-        GM_TRY(level_tables(lo, sets, s));
         // forward CSR (by destination) and backward CSR (by source)
-        GM_TRY(gm_alloc(&up.d_indices, nnz, s)); GM_TRY(gm_alloc(&up.d_indices_t, nnz, s)); GM_TRY(gm_alloc(&up.d_indptr_t, (size_t)lo.n + 1, s));
-        if (up.n > 0) hipLaunchKernelGGL(k_fill_in, dim3((up.n + 3) / 4), dim3(256), 0, s, up.d_row, up.n, b->d_indptr, b->d_indices, posB, up.d_indptr, up.d_indices);
-        int32_t* cnt = nullptr;
-        GM_TRY(gm_alloc(&cnt, (size_t)lo.n + 1, s));
-        if (lo.n > 0) hipLaunchKernelGGL(k_out_edges, dim3((lo.n + 3) / 4), dim3(256), 0, s, lo.d_row, lo.n, b->d_indptr_t, b->d_indices_t, posA, cnt, (const int32_t*)nullptr, (int32_t*)nullptr);
-        int32_t nnz_t = 0;
-        rc = dev_scan(cnt, up.d_indptr_t, lo.n, 1, &nnz_t, s);
-        gm_dev_free(cnt, s);
-        GM_TRY(rc);
-        GM_REQUIRE(nnz_t == nnz, GM_EHIP, "cone: level %d has %d in-edges but %d out-edges (corrupt batch CSR?)", l + 1, nnz, nnz_t);
-        if (lo.n > 0) hipLaunchKernelGGL(k_out_edges, dim3((lo.n + 3) / 4), dim3(256), 0, s, lo.d_row, lo.n, b->d_indptr_t, b->d_indices_t, posA, (int32_t*)nullptr, up.d_indptr_t, up.d_indices_t);
+        hipLaunchKernelGGL(k_fill_in, dim3((bu + 3) / 4), dim3(256), 0, s, up.d_row, cnt(l + 1, 0), b->d_indptr, b->d_indices, posB, up.d_indptr, up.d_indices);
+        GM_HIP(hipMemsetAsync(deg, 0, 4 * ((size_t)bl + 1), s));
+        hipLaunchKernelGGL(k_out_edges, dim3((bl + 3) / 4), dim3(256), 0, s, lo.d_row, cnt(l, 0), b->d_indptr_t, b->d_indices_t, posA, deg, (const int32_t*)nullptr, (int32_t*)nullptr);
+        dev_scan(deg, up.d_indptr_t, bl, 1, cnt(l + 1, 2), bsum, s);
+        hipLaunchKernelGGL(k_out_edges, dim3((bl + 3) / 4), dim3(256), 0, s, lo.d_row, cnt(l, 0), b->d_indptr_t, b->d_indices_t, posA, (int32_t*)nullptr, up.d_indptr_t, up.d_indices_t);
+        // hub rows of both CSRs, ascending
+        for (int o = 0; o < 2; ++o) {
+            const int bound = o ? bl : bu;
+            hipLaunchKernelGGL(k_heavy_flag, dim3((bound + 255) / 256), dim3(256), 0, s, o ? up.d_indptr_t : up.d_indptr, cnt(o ? l : l + 1, 0), bound, c->heavy_deg, flags);
+            dev_scan(flags, hpos, bound, 0, cnt(l + 1, 3 + o), bsum, s);
+            hipLaunchKernelGGL(k_heavy_scatter, dim3((bound + 255) / 256), dim3(256), 0, s, flags, hpos, bound, (int)hcap(Be[l + 1]), up.d_heavy[o]);
+        }
         GM_HIP(hipGetLastError());
-        GM_TRY(heavy_list(up.d_indptr, up.n, nnz, c->heavy_deg, &up.d_heavy[0], &up.n_heavy[0], s));
-        GM_TRY(heavy_list(up.d_indptr_t, lo.n, nnz, c->heavy_deg, &up.d_heavy[1], &up.n_heavy[1], s));
         std::swap(posA, posB);
     }
+    // ---- the one round trip: counts and per-level set offsets
+    const int32_t* h_cnt = sg.download(cnts, (size_t)8 * (GM_MAX_GCN + 1));
+    const int32_t* h_off[GM_MAX_GCN + 1] = {};
+    for (int l = 0; l < L; ++l) h_off[l] = sg.download(c->lv[l].d_set_off, (size_t)sets + 1);
+    bool okd = h_cnt != nullptr;
+    for (int l = 0; l < L; ++l) okd = okd && h_off[l];
+    if (!okd) { gm_set_error("cone: pinned staging failed"); return fail(GM_ENOMEM); }
+    if (hipStreamSynchronize(s) != hipSuccess) { gm_set_error("cone: stream sync failed"); return fail(GM_EHIP); }
+    if (h_cnt[8 * L + 5]) { c->ok = false; gm_dev_free(tmp, s); return GM_OK; }      // two centres on one row (a self pair): callers fall back to the dense schedule
+    for (int l = L - 1; l >= 0; --l) {
+        gm_cone_level& up = c->lv[l + 1]; gm_cone_level& lo = c->lv[l];
+        lo.n = h_cnt[8 * l]; up.nnz = h_cnt[8 * (l + 1) + 1];
+        if (lo.n > Bn[l] || up.nnz > Be[l + 1] || h_cnt[8 * (l + 1) + 2] != up.nnz) {
+            gm_set_error("cone: level %d: %d rows (bound %lld), %d in-edges (bound %lld), %d counted by source (corrupt batch CSR?)", l, lo.n, (long long)Bn[l], up.nnz,
+                         (long long)Be[l + 1], h_cnt[8 * (l + 1) + 2]);
+            return fail(GM_EHIP);
+        }
+        for (int o = 0; o < 2; ++o) up.n_heavy[o] = std::min<int32_t>(h_cnt[8 * (l + 1) + 3 + o], (int32_t)hcap(Be[l + 1]));
+        lo.h_set_off.assign(h_off[l], h_off[l] + sets + 1);
+        if ((rc = level_tables(lo, sets, sg)) != GM_OK) return fail(rc);
+    }
+    gm_dev_free(tmp, s);
+    // the tables of the lower levels went up after the round trip: complete before a consumer on ANOTHER stream may use them (a few small copies, no kernels)
+    if (hipStreamSynchronize(s) != hipSuccess) { gm_set_error("cone: stream sync failed"); return GM_EHIP; }
     c->ok = true;
     return GM_OK;
 }
@@ -282,14 +309,7 @@ int gm_batch_cone(const gm_batch* b, int L, hipStream_t s, const gm_cone** out) 
     if (b->cone[L]) { *out = b->cone[L]; return GM_OK; }
     gm_phase_timer tm("cone");
     gm_cone* c = new gm_cone();
-    int32_t *posA = nullptr, *posB = nullptr, *flags = nullptr, *d_bad = nullptr;
-    int rc = gm_alloc(&posA, b->rows, s);
-    if (rc == GM_OK) rc = gm_alloc(&posB, b->rows, s);
-    if (rc == GM_OK) rc = gm_alloc(&flags, b->rows, s);
-    if (rc == GM_OK) rc = gm_alloc(&d_bad, 1, s);
-    if (rc == GM_OK) rc = cone_build(b, L, s, c, posA, posB, flags, d_bad);
-    if (rc == GM_OK && hipStreamSynchronize(s) != hipSuccess) { gm_set_error("cone: stream sync failed"); rc = GM_EHIP; }
-    gm_dev_free(posA, s); gm_dev_free(posB, s); gm_dev_free(flags, s); gm_dev_free(d_bad, s);
+    const int rc = cone_build(b, L, s, c);
     if (rc != GM_OK) { gm_cone_free(c, s); return rc; }
     b->cone[L] = c;
     *out = c;

@@ -75,6 +75,7 @@ struct gm_cone_level {
 struct gm_cone {
     int L = 0; bool ok = false; int heavy_deg = 64;
     gm_cone_level lv[GM_MAX_GCN + 1];
+    void* slab = nullptr;           // every device array of the levels is carved from this one allocation (sized from upper bounds: cone.hip)
 };
 struct gm_batch;
 int gm_batch_cone(const gm_batch* b, int L, hipStream_t s, const gm_cone** out);   // built on first use, cached in the batch
