@@ -7,6 +7,7 @@
 // consecutive floats, so a 256-wide row is one 1-KiB coalesced access per wave.
 #include <algorithm>
 #include <stdlib.h>
+#include <mutex>
 #include "gm_internal.h"
 
 #define AGG_BLOCK 256
@@ -536,10 +537,27 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
     return GM_OK;
 }
 
-void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather) {
-    if (!b->d_sptr[o] || !b->d_sseg[o] || (gather && (o != 0 || !b->d_su_feat))) return;
+int gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather, hipStream_t s) {
+    if (!gm_knob().agg_stream || a.s_out || a.bias || a.mask_h || a.mask_b || a.relu || a.relu_bits || a.rowlist || a.skip_on) return GM_OK;      // never a stream launch
+    gm_batch::stream_pending& sp = b->spend[o];
+    if (sp.pending) {
+        // first launch of this orientation that can take the stream kernel: build its tables now, on the launch's stream (the batch's slabs take them; a
+        // build on another stream than the batch's is ordered behind the batch's own by the caller's use of the batch, and marked for the frees)
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (sp.pending) {
+            gm_batch* mb = const_cast<gm_batch*>(b);
+            gm_stager sg(s);
+            GM_TRY(gm_stream_tables(mb, o, sp.hubs.data(), sp.deg.data(), (int)sp.hubs.size(), sp.n_parts, sp.has_tab ? &sp.tab : nullptr, s, &sg));
+            sp.pending = false;
+            sp.hubs = std::vector<int32_t>(); sp.deg = std::vector<int32_t>(); sp.tab = std::vector<int32_t>();
+            gm_batch_mark_use(b, s);
+        }
+    }
+    if (!b->d_sptr[o] || !b->d_sseg[o] || (gather && (o != 0 || !b->d_su_feat))) return GM_OK;
     a.stream = b; a.stream_o = o; a.stream_feat = gather ? 1 : 0;
     a.stream_xrows = gather ? b->store->total_nodes : b->rows;
+    return GM_OK;
 }
 
 extern "C" int64_t gm_aggregate_bytes(const gm_batch_t* b, int32_t width) {
@@ -563,7 +581,7 @@ extern "C" int gm_aggregate(const gm_batch_t* b, int32_t transposed, int32_t gat
     a.ldx = gather ? b->store->feat_ld : width; a.s_in = s_in; a.s_out = s_out; a.out = out; a.rows = b->rows; a.width = width;
     a.heavy = b->d_heavy[transposed ? 1 : 0]; a.n_heavy = b->n_heavy[transposed ? 1 : 0]; a.heavy_deg = b->heavy_deg;
     a.sched = b->d_sched[transposed ? 1 : 0]; a.sched_len = b->sched_len[transposed ? 1 : 0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, transposed ? 1 : 0, (hipStream_t)stream));
-    if (a.e_w) gm_agg_stream_args(a, b, transposed ? 1 : 0, gather != 0);
+    if (a.e_w) GM_TRY(gm_agg_stream_args(a, b, transposed ? 1 : 0, gather != 0, (hipStream_t)stream));
     gm_prof_agg_begin((hipStream_t)stream, gm_aggregate_bytes(b, width));
     int rc = gm_launch_aggregate(a, (hipStream_t)stream);
     gm_prof_agg_end((hipStream_t)stream);

@@ -334,16 +334,17 @@ int gm_stream_wgs(int64_t cost) {
     return (int)std::min<int64_t>(65536, std::max<int64_t>(gm_num_cus() * 3 / GM_NXCD * GM_NXCD, (wgs + GM_NXCD - 1) / GM_NXCD * GM_NXCD));
 }
 
+// Does a batch get stream tables at all?  Where the stream kernel pays (measured): sparse induced subgraphs (the arxiv shape: ~2
+// in-edges per row) in batches large enough to fill its pipelines.
+bool gm_stream_batch_ok(const gm_batch* b, int o) {
+    return b->rows > 0 && b->edges > 0 && b->d_enorm[o] && b->edges <= 8 * b->rows && b->rows >= gm_knob().agg_stream_min_rows;
+}
 // Stream tables of one orientation (o = 0: by destination; 1: by source).  hubs_host / deg_host: the orientation's ascending hub rows and
 // their degrees (host copies from the finalisation's round trip); n_parts: hub parts of the orientation's part table (the hub count when the
 // rows are not split).  Needs the batch's per-edge tables (d_enorm, d_efeat).
 int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, const std::vector<int32_t>* part_tab, hipStream_t s,
                      gm_stager* sg) {
-    if (b->rows <= 0 || b->edges <= 0 || !b->d_enorm[o]) return GM_OK;
-    // Where the stream kernel pays (measured): sparse induced subgraphs (the arxiv shape: ~2 in-edges per row -- a gather per ~0.5 KiB of
-    // output) in batches large enough to fill its pipelines.  Dense batches (Tissue shape, ~24 in-edges per row: 5.6 vs 3.2 ms per meta-step) and small ones
-    // (FirstMM shape) keep the window kernel, whose resident rows share their sources through L2.
-    if (b->edges > 8 * b->rows || b->rows < gm_knob().agg_stream_min_rows) return GM_OK;
+    if (!gm_stream_batch_ok(b, o)) return GM_OK;      // dense batches (Tissue shape, ~24 in-edges per row: 5.6 vs 3.2 ms per meta-step) and small ones (FirstMM shape) keep the window kernel
     const int32_t* indptr = o ? b->d_indptr_t : b->d_indptr;
     std::vector<int32_t> cum(n_hubs + 1, 0);
     for (int k = 0; k < n_hubs; ++k) cum[k + 1] = cum[k] + deg_host[k];

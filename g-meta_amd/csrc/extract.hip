@@ -799,10 +799,13 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
             GM_TRY(gm_agg_schedule(b, b->rows, b->sched_win, h.data(), hd.data(), b->n_heavy[o], &sc, s, &sg));
             tm.lap("schedule");
             if (o == 0) { heavy0 = h; tab0 = sc.tab; }
-            if (gm_knob().agg_stream) GM_TRY(gm_stream_tables(b, o, h.data(), hd.data(), (int)nh, sc.d_hub ? sc.parts : (int)nh, sc.d_hub ? &sc.tab : nullptr, s, &sg));
-            tm.lap("stream-tables");
+            {   // stream tables: at first use (gm_agg_stream_args), from these host copies
+                gm_batch::stream_pending& sp = b->spend[o];
+                sp.pending = true; sp.has_tab = sc.d_hub != nullptr; sp.n_parts = sc.d_hub ? sc.parts : (int)nh;
+                sp.hubs = h; sp.deg = hd; if (sp.has_tab) sp.tab = sc.tab;
+            }
             b->d_sched[o] = sc.d_sched; b->sched_len[o] = sc.len; b->d_hub[o] = sc.d_hub; b->d_hub_scratch[o] = sc.d_hub_scratch; b->hub_part[o] = sc.hub_part; b->hub_words[o] = sc.hub_words; b->hub_parts[o] = sc.parts;
-        } else if (gm_knob().agg_stream) GM_TRY(gm_stream_tables(b, o, nullptr, nullptr, 0, 0, nullptr, s, &sg));
+        } else b->spend[o].pending = true;                       // (no hub rows)
     }
     // ---- the window rows of the fused passes' partial aggregate launch as a compact ascending list + its block schedule (no host wait: the
     // list's length follows from counts the round trip above already brought: rows with more than GM_FUSE_MAXDEG in-edges minus the hub rows)

@@ -147,6 +147,11 @@ struct gm_batch {
     int32_t* d_sptr[2] = {nullptr, nullptr}; int32_t* d_su[2] = {nullptr, nullptr}; int32_t* d_su_feat = nullptr; float* d_sw[2] = {nullptr, nullptr};
     int32_t* d_scum[2] = {nullptr, nullptr}; int2* d_sseg[2] = {nullptr, nullptr}; int32_t* d_sxord[2] = {nullptr, nullptr};
     int32_t stream_nseg[2] = {0, 0}, stream_nwg[2] = {0, 0}, stream_hubwg[2] = {0, 0}, stream_nparts[2] = {0, 0}, stream_enorm[2] = {0, 0};
+    // The stream tables are built at the FIRST launch that can take the stream kernel (gm_agg_stream_args; round 6), from what the finalisation's round trip
+    // brought to the host: with the fused passes of the dense schedule only a large support batch ever gets there, and never the by-source orientation --
+    // built with every batch they were 0.23 ms of host time and eight kernels of each 32-task query batch for nothing.
+    struct stream_pending { bool pending = false; bool has_tab = false; int n_parts = 0; std::vector<int32_t> hubs, deg, tab; };
+    mutable stream_pending spend[2];
     int32_t* d_sched_mid = nullptr; int32_t sched_len_mid = 0;      // block schedule over the list (hub parts placed by the hub row's approximate list position)
     mutable int64_t unfused_src = -1;                // DISTINCT source rows of those in-edges (profiling only: counted on first use, gm_batch_unfused_sources)
     // compact row lists for the row-sparse backward (gm_hparams_t.sparse_bwd)
@@ -302,8 +307,9 @@ struct gm_agg_args {
     const gm_batch* stream; int stream_o; int stream_feat; int64_t stream_xrows;
 };
 // fills the stream fields of `a` for orientation o of batch b (gather: the sources are rows of the store's feature table); a no-op without tables
-void gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather);
+int gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather, hipStream_t s);      // (builds the orientation's tables at first use, on s)
 bool gm_stream_ok(const gm_agg_args& g);
+bool gm_stream_batch_ok(const gm_batch* b, int o);      // the batch is of the kind that gets stream tables (built at first use)
 int gm_launch_stream(const gm_agg_args& g, int nt, hipStream_t s);
 int gm_stream_tables(gm_batch* b, int o, const int32_t* hubs_host, const int32_t* deg_host, int n_hubs, int n_parts, const std::vector<int32_t>* part_tab, hipStream_t s,
                      gm_stager* sg);

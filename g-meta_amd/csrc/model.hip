@@ -773,7 +773,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
             // arithmetic only) -- the differentiated passes no longer write and re-read Z_l either (GM_FUSE_DIFF=0: as before)
             // GM_FUSE_DIFF=2: ... except where the pass's full launches would take the stream aggregate (a support batch with stream tables, agg_stream.hip):
             // that kernel runs INSIDE the CUs the query stream's GEMM occupies, a partial window launch competes with it for them
-            const bool keeps_stream = gm_knob().fuse_diff == 2 && c.is_support && gm_knob().agg_stream && b->d_sptr[0] != nullptr;
+            const bool keeps_stream = gm_knob().fuse_diff == 2 && c.is_support && gm_knob().agg_stream && gm_stream_batch_ok(b, 0);
             const bool diff_ok = fwd_only == 2 && gm_knob().fuse_diff && !keeps_stream && c.np != 2 && !c.cone && gm_wgrad_gather_ok(b->n_chunks, fi, fo);
             const bool fuse = (fwd_only == 1 || diff_ok) && gm_get_fuse_agg() && split_ok && !(l == 0 && reuse_z1) && fi >= 64 && fi % 4 == 0 && b->d_fuse2 && b->d_enorm[0] &&
                               (!gather || (b->store->feat_ld % 4 == 0 && b->store->feat_ld >= fi)) &&
@@ -785,7 +785,6 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                 gm_agg_args a{}; a.indptr = b->d_indptr; a.indices = b->d_indices; a.heavy = b->d_heavy[0]; a.n_heavy = b->n_heavy[0]; a.heavy_deg = b->heavy_deg; a.sched = b->d_sched[0]; a.sched_len = b->sched_len[0]; a.sched_win = b->sched_win; GM_TRY(gm_agg_hub(a, b, 0, st, c.hub_set)); a.s_in = b->d_norm; a.e_w = b->d_enorm[0]; a.out = c.Z[l]; a.rows = b->rows; a.width = fi;
                 if (gather) { a.x = b->store->d_feat; a.x_row = b->d_feat_row; a.x_idx = b->d_efeat; a.ldx = b->store->feat_ld; }
                 else { a.x = xin; a.ldx = fi; }
-                if (a.e_w) gm_agg_stream_args(a, b, 0, gather);             // full launches may take the LDS-DMA stream kernel (agg_stream.hip)
                 if (fuse) {
                     // only the rows the fused kernel does not form itself (more than GM_FUSE_MAXDEG sources): a partial launch
                     a.skip_on = 1; a.skip_lo = 0; a.skip_hi = GM_FUSE_MAXDEG;
@@ -808,6 +807,7 @@ static int gcn_forward(GcnCtx& c, const float* params, int64_t pstride, float* l
                     GM_TRY(gm_launch_aggregate(a, st));
                     gm_prof_agg_end(st);
                 } else {
+                    if (a.e_w) GM_TRY(gm_agg_stream_args(a, b, 0, gather, st));      // full launches may take the LDS-DMA stream kernel (agg_stream.hip)
                     gm_prof_agg_begin(st, gm_aggregate_bytes(b, fi));
                     {   // compulsory HBM bytes: a gather launch reads rows of the (cache-resident) feature table, at most all of it
                         int64_t strict = gm_aggregate_bytes(b, fi);
