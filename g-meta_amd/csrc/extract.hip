@@ -95,6 +95,7 @@ struct ExStore {
 #define EX_GL 8
 #define EX_GROUPS (GM_WAVE / EX_GL)
 #define EX_BIG_DEG 256
+#define EX_INFL 4          // neighbour loads in flight per lane (round 6: 2 before -- a node of 17..32 neighbours took two dependent round trips, now one)
 __device__ __forceinline__ int group_sum(int v) {
 #pragma unroll
     for (int o = EX_GL / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -104,18 +105,42 @@ __device__ __forceinline__ int group_sum(int v) {
 template <bool G>
 __device__ __forceinline__ int group_count(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, int gl) {
     int c = 0;
-    for (int64_t q = a + gl; __any(q < b); q += 2 * EX_GL) {
-        const int u0 = q < b ? idx[q] : -1, u1 = q + EX_GL < b ? idx[q + EX_GL] : -1;
-        if (u0 >= 0) c += bit_test<G>(seen, u0);
-        if (u1 >= 0) c += bit_test<G>(seen, u1);
+    for (int64_t q = a + gl; __any(q < b); q += EX_INFL * EX_GL) {
+        int u[EX_INFL];
+#pragma unroll
+        for (int k = 0; k < EX_INFL; ++k) u[k] = q + k * EX_GL < b ? idx[q + k * EX_GL] : -1;
+#pragma unroll
+        for (int k = 0; k < EX_INFL; ++k) if (u[k] >= 0) c += bit_test<G>(seen, u[k]);
     }
     return group_sum(c);
 }
 
+// Hub nodes (more than EX_BIG_DEG neighbours: thousands in a preferential-attachment parent, and every 2-hop neighbourhood holds dozens of them --
+// most of a subgraph's walk volume) are walked by a whole wave, EX_WINFL x 64 neighbour ids in flight (round 6: 64 before, a round trip per 64 ids).
+#define EX_WINFL 4
 // Marks every in-neighbour of v (graph-local id) in `seen`; called by a whole wave.
 __device__ __forceinline__ void wave_mark_preds(const ExStore& S, int64_t base, int v, uint32_t* seen, int lane) {
     const int64_t p0 = S.in_ptr[base + v], p1 = S.in_ptr[base + v + 1];
-    for (int64_t q = p0 + lane; q < p1; q += GM_WAVE) bit_set(seen, S.in_idx[q]);
+    for (int64_t q = p0 + lane; q < p1; q += EX_WINFL * GM_WAVE) {
+        int u[EX_WINFL];
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) u[k] = q + k * GM_WAVE < p1 ? S.in_idx[q + k * GM_WAVE] : -1;
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) if (u[k] >= 0) bit_set(seen, u[k]);
+    }
+}
+// neighbours of a hub node (list [a, b) of idx) inside the bitmap, per lane (the caller adds the lanes up)
+template <bool G>
+__device__ __forceinline__ int wave_count(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, int lane) {
+    int c = 0;
+    for (int64_t q = a + lane; q < b; q += EX_WINFL * GM_WAVE) {
+        int u[EX_WINFL];
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) u[k] = q + k * GM_WAVE < b ? idx[q + k * GM_WAVE] : -1;
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) if (u[k] >= 0) c += bit_test<G>(seen, u[k]);
+    }
+    return c;
 }
 
 // Phase A: node set (BFS or given), sampling, sorted node list, induced in/out degrees.
@@ -171,10 +196,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
                         if (slot < EX_BLOCK) { if (gl == 0) big[slot] = v; b = a; }      // (list full: the group walks it itself)
                     }
                 }
-                for (int64_t r = a + gl; __any(r < b); r += 2 * EX_GL) {
-                    const int u0 = r < b ? S.in_idx[r] : -1, u1 = r + EX_GL < b ? S.in_idx[r + EX_GL] : -1;
-                    if (u0 >= 0) bit_set(seen, u0);
-                    if (u1 >= 0) bit_set(seen, u1);
+                for (int64_t r = a + gl; __any(r < b); r += EX_INFL * EX_GL) {
+                    int u[EX_INFL];
+#pragma unroll
+                    for (int k = 0; k < EX_INFL; ++k) u[k] = r + k * EX_GL < b ? S.in_idx[r + k * EX_GL] : -1;
+#pragma unroll
+                    for (int k = 0; k < EX_INFL; ++k) if (u[k] >= 0) bit_set(seen, u[k]);
                 }
             }
             __syncthreads();
@@ -274,14 +301,24 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         __syncthreads();
         int ein = 0, eout = 0;
         int32_t* degi = degi_slab + (int64_t)seed * cap; int32_t* dego = dego_slab + (int64_t)seed * cap;
-        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += EX_WAVES * EX_GROUPS) {
-            const int r = r0 + grp;
-            int64_t ia = 0, ib = 0, oa = 0, ob = 0;
+        // The walk of a batch of eight nodes is a chain node id -> row bounds -> neighbour ids -> bitmap word.  The first two links are taken off the
+        // chain (round 6): the node ids are fetched TWO batches ahead and the row bounds ONE batch ahead, so an iteration issues three independent
+        // groups of loads and waits one round trip instead of three.
+        constexpr int RSTEP = EX_WAVES * EX_GROUPS;
+        int r = wave * EX_GROUPS + grp;
+        int v1 = r < ns ? nodes[r] : -1;                                              // node of the NEXT batch
+        int v2 = r + RSTEP < ns ? nodes[r + RSTEP] : -1;                              // ... of the one after
+        int64_t nia = 0, nib = 0, noa = 0, nob = 0;
+        if (v1 >= 0) { nia = S.in_ptr[base + v1]; nib = S.in_ptr[base + v1 + 1]; if (!S.sym) { noa = S.out_ptr[base + v1]; nob = S.out_ptr[base + v1 + 1]; } }
+        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += RSTEP, r += RSTEP) {
+            int64_t ia = nia, ib = nib, oa = noa, ob = nob;
+            const bool have = v1 >= 0;
+            v1 = v2;
+            v2 = r + 2 * RSTEP < ns ? nodes[r + 2 * RSTEP] : -1;
+            nia = nib = noa = nob = 0;
+            if (v1 >= 0) { nia = S.in_ptr[base + v1]; nib = S.in_ptr[base + v1 + 1]; if (!S.sym) { noa = S.out_ptr[base + v1]; nob = S.out_ptr[base + v1 + 1]; } }
             bool later = false;                                                          // a hub: its degrees come from the second pass
-            if (r < ns) {
-                const int v = nodes[r];
-                ia = S.in_ptr[base + v]; ib = S.in_ptr[base + v + 1];
-                if (!S.sym) { oa = S.out_ptr[base + v]; ob = S.out_ptr[base + v + 1]; }
+            if (have) {
                 if (ib - ia > EX_BIG_DEG || ob - oa > EX_BIG_DEG) {
                     int slot = EX_BLOCK;
                     if (gl == 0) slot = atomicAdd(nbig, 1);
@@ -291,15 +328,15 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
             }
             const int ci_ = group_count<G>(ia, ib, S.in_idx, seen, gl);
             const int co_ = S.sym ? ci_ : group_count<G>(oa, ob, S.out_idx, seen, gl);
-            if (r < ns && gl == 0 && !later) { degi[r] = ci_; dego[r] = co_; ein += ci_; eout += co_; }
+            if (have && gl == 0 && !later) { degi[r] = ci_; dego[r] = co_; ein += ci_; eout += co_; }
         }
         __syncthreads();
         const int nb = min(*nbig, EX_BLOCK);
         for (int k = wave; k < nb; k += EX_WAVES) {
             const int r = big[k], v = nodes[r];
             int ci_ = 0, co_ = 0;
-            for (int64_t q = S.in_ptr[base + v] + lane, e = S.in_ptr[base + v + 1]; q < e; q += GM_WAVE) ci_ += bit_test<G>(seen, S.in_idx[q]);
-            if (!S.sym) for (int64_t q = S.out_ptr[base + v] + lane, e = S.out_ptr[base + v + 1]; q < e; q += GM_WAVE) co_ += bit_test<G>(seen, S.out_idx[q]);
+            ci_ = wave_count<G>(S.in_ptr[base + v], S.in_ptr[base + v + 1], S.in_idx, seen, lane);
+            if (!S.sym) co_ = wave_count<G>(S.out_ptr[base + v], S.out_ptr[base + v + 1], S.out_idx, seen, lane);
             ci_ = wave_sum(ci_); co_ = S.sym ? ci_ : wave_sum(co_);
             if (lane == 0) { degi[r] = ci_; dego[r] = co_; ein += ci_; eout += co_; }
         }
@@ -328,12 +365,17 @@ __device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t*
                                               const uint32_t* pref, int row0, int32_t* out, int32_t* out2, int pos, int lane) {
     const int64_t a = ptr[base + v], b = ptr[base + v + 1];
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int64_t q = a; q < b; q += GM_WAVE) {
-        int u = 0, hit = 0;
-        if (q + lane < b) { u = idx[q + lane]; hit = bit_test<G>(seen, u); }
-        const unsigned long long m = __ballot(hit);
-        if (hit) { const int x = row0 + bit_rank<G>(seen, pref, u), p = pos + __popcll(m & lt); out[p] = x; if (out2) out2[p] = x; }
-        pos += __popcll(m);
+    for (int64_t q = a; q < b; q += EX_WINFL * GM_WAVE) {
+        int u[EX_WINFL];
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) u[k] = q + k * GM_WAVE + lane < b ? idx[q + k * GM_WAVE + lane] : -1;
+#pragma unroll
+        for (int k = 0; k < EX_WINFL; ++k) {                     // in list order
+            const int hit = u[k] >= 0 && bit_test<G>(seen, u[k]);
+            const unsigned long long m = __ballot(hit);
+            if (hit) { const int x = row0 + bit_rank<G>(seen, pref, u[k]), p = pos + __popcll(m & lt); out[p] = x; if (out2) out2[p] = x; }
+            pos += __popcll(m);
+        }
     }
 }
 // The same for one node per group of eight lanes (all lanes of the wave call it; a group without a node passes a == b)
@@ -341,14 +383,17 @@ template <bool G>
 __device__ __forceinline__ void group_fill_row(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, const uint32_t* pref, int row0,
                                                int32_t* out, int32_t* out2, int pos, int grp, int gl) {
     const unsigned lt = (1u << gl) - 1u;
-    for (int64_t q = a + gl; __any(q < b); q += 2 * EX_GL) {
-        const int u0 = q < b ? idx[q] : -1, u1 = q + EX_GL < b ? idx[q + EX_GL] : -1;
-        const int h0 = u0 >= 0 && bit_test<G>(seen, u0), h1 = u1 >= 0 && bit_test<G>(seen, u1);
-        const unsigned b0 = (unsigned)(__ballot(h0) >> (grp * EX_GL)) & 0xffu, b1 = (unsigned)(__ballot(h1) >> (grp * EX_GL)) & 0xffu;
-        if (h0) { const int x = row0 + bit_rank<G>(seen, pref, u0), p = pos + __popc(b0 & lt); out[p] = x; if (out2) out2[p] = x; }
-        pos += __popc(b0);
-        if (h1) { const int x = row0 + bit_rank<G>(seen, pref, u1), p = pos + __popc(b1 & lt); out[p] = x; if (out2) out2[p] = x; }
-        pos += __popc(b1);
+    for (int64_t q = a + gl; __any(q < b); q += EX_INFL * EX_GL) {
+        int u[EX_INFL];
+#pragma unroll
+        for (int k = 0; k < EX_INFL; ++k) u[k] = q + k * EX_GL < b ? idx[q + k * EX_GL] : -1;
+#pragma unroll
+        for (int k = 0; k < EX_INFL; ++k) {                      // in list order: the k-th batch of eight neighbours after the (k-1)-th
+            const int h = u[k] >= 0 && bit_test<G>(seen, u[k]);
+            const unsigned bm = (unsigned)(__ballot(h) >> (grp * EX_GL)) & 0xffu;
+            if (h) { const int x = row0 + bit_rank<G>(seen, pref, u[k]), p = pos + __popc(bm & lt); out[p] = x; if (out2) out2[p] = x; }
+            pos += __popc(bm);
+        }
     }
 }
 
@@ -405,13 +450,27 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
         if (tid == 0) *nbig = 0;
         __syncthreads();
         int32_t* ind2 = S.sym ? indices_t : nullptr;
-        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += EX_WAVES * EX_GROUPS) {
-            const int r = r0 + grp;
-            int64_t ia = 0, ib = 0, oa = 0, ob = 0; int pi = 0, po = 0;
-            if (r < ns) {
-                const int v = nodes[r];
-                ia = S.in_ptr[base + v]; ib = S.in_ptr[base + v + 1]; pi = indptr[row0 + r];
-                if (!S.sym) { oa = S.out_ptr[base + v]; ob = S.out_ptr[base + v + 1]; po = indptr_t[row0 + r]; }
+        // node ids two batches ahead, row bounds and output offsets one batch ahead (see k_nodes)
+        constexpr int RSTEP = EX_WAVES * EX_GROUPS;
+        int r = wave * EX_GROUPS + grp;
+        int v1 = r < ns ? nodes[r] : -1;
+        int v2 = r + RSTEP < ns ? nodes[r + RSTEP] : -1;
+        int64_t nia = 0, nib = 0, noa = 0, nob = 0; int npi = 0, npo = 0;
+        if (v1 >= 0) {
+            nia = S.in_ptr[base + v1]; nib = S.in_ptr[base + v1 + 1]; npi = indptr[row0 + r];
+            if (!S.sym) { noa = S.out_ptr[base + v1]; nob = S.out_ptr[base + v1 + 1]; npo = indptr_t[row0 + r]; }
+        }
+        for (int r0 = wave * EX_GROUPS; r0 < ns; r0 += RSTEP, r += RSTEP) {
+            int64_t ia = nia, ib = nib, oa = noa, ob = nob; const int pi = npi, po = npo;
+            const bool have = v1 >= 0;
+            v1 = v2;
+            v2 = r + 2 * RSTEP < ns ? nodes[r + 2 * RSTEP] : -1;
+            nia = nib = noa = nob = 0; npi = npo = 0;
+            if (v1 >= 0) {
+                nia = S.in_ptr[base + v1]; nib = S.in_ptr[base + v1 + 1]; npi = indptr[row0 + r + RSTEP];
+                if (!S.sym) { noa = S.out_ptr[base + v1]; nob = S.out_ptr[base + v1 + 1]; npo = indptr_t[row0 + r + RSTEP]; }
+            }
+            if (have) {
                 if (ib - ia > EX_BIG_DEG || ob - oa > EX_BIG_DEG) {
                     int slot = EX_BLOCK;
                     if (gl == 0) slot = atomicAdd(nbig, 1);
