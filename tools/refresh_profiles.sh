@@ -6,7 +6,7 @@ set -u
 tag=${1:-final}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="python bench.py --warmup 1 --no_cpu_baseline --extra_steps 0 --e2e_steps 0"
+B="env GMETA_NO_BOX=1 python bench.py --warmup 1 --no_cpu_baseline --extra_steps 0 --e2e_steps 0"
 db() { find "$1" -name '*.db' | head -1; }
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/p_ser -o x -- $B --serialize 1 --steps 3 > $out/${tag}_serialized_bench.log 2>&1
 python tools/prof_summary.py "$(db $out/p_ser)" > $out/${tag}_serialized_kernel_stats.txt
