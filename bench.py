@@ -782,15 +782,17 @@ def main():
         # the kernels' HIP events are kept per host thread: for them the two builds of a meta-batch run one after the other on this thread
         # (by default the support batch is built by a helper thread on its own stream while this one builds the query batch)
         os.environ['GMETA_EXTRACT_THREADS'] = '1'
-        lib.gm_profile_enable(1)
-        t_ex = time.perf_counter()
-        for _ in range(reps):
-            bx = db.get_batch(idx0)
-        torch.cuda.synchronize()
-        wall1_ms = (time.perf_counter() - t_ex) / reps * 1e3
-        ex = [prof_read(c) for c in (8, 9, 10)]
-        lib.gm_profile_enable(0)
-        del os.environ['GMETA_EXTRACT_THREADS']
+        try:
+            lib.gm_profile_enable(1)
+            t_ex = time.perf_counter()
+            for _ in range(reps):
+                bx = db.get_batch(idx0)
+            torch.cuda.synchronize()
+            wall1_ms = (time.perf_counter() - t_ex) / reps * 1e3
+            ex = [prof_read(c) for c in (8, 9, 10)]
+        finally:
+            lib.gm_profile_enable(0)
+            del os.environ['GMETA_EXTRACT_THREADS']
         by = extraction_bytes(store, db, idx0, bx, cfg['h'], link)
         k_ms = (ex[0][0] + ex[1][0]) / reps
         tot = by['expand'] + by['induce'] + by['write']

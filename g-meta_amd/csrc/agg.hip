@@ -540,9 +540,10 @@ int gm_launch_aggregate(const gm_agg_args& g, hipStream_t s) {
 int gm_agg_stream_args(gm_agg_args& a, const gm_batch* b, int o, bool gather, hipStream_t s) {
     if (!gm_knob().agg_stream || a.s_out || a.bias || a.mask_h || a.mask_b || a.relu || a.relu_bits || a.rowlist || a.skip_on) return GM_OK;      // never a stream launch
     gm_batch::stream_pending& sp = b->spend[o];
-    if (sp.pending) {
+    {
         // first launch of this orientation that can take the stream kernel: build its tables now, on the launch's stream (the batch's slabs take them; a
-        // build on another stream than the batch's is ordered behind the batch's own by the caller's use of the batch, and marked for the frees)
+        // build on another stream than the batch's is ordered behind the batch's own by the caller's use of the batch, and marked for the frees).  The flag
+        // is read under the lock: two streams may bring the same batch here at once (public gm_aggregate), and an uncontended lock costs nothing beside a launch
         static std::mutex mu;
         std::lock_guard<std::mutex> lk(mu);
         if (sp.pending) {

@@ -226,12 +226,13 @@ static int cone_build(const gm_batch* b, int L, hipStream_t s, gm_cone* c) {
     int32_t *posA, *posB, *flags, *deg, *hpos, *bsum, *cnts;
     carve_tmp(ts, posA, posB, flags, deg, hpos, bsum, cnts);
     GM_TRY(gm_dev_alloc(&tmp, ts.used + 256, s));
+    struct TmpGuard { void* p; hipStream_t s; ~TmpGuard() { gm_dev_free(p, s); } } tmp_guard{tmp, s};      // (stream-ordered free on every way out)
     { ConeCarver cv(tmp); carve_tmp(cv, posA, posB, flags, deg, hpos, bsum, cnts); }
     // device-side counts, per level l: [0] n, [1] nnz (edges into l, by destination), [2] the same counted by source, [3] / [4] hub rows; cnts[8 L + 5] = bad
     auto cnt = [&](int l, int k) { return cnts + 8 * l + k; };
     gm_stager sg(s);
     int rc = GM_OK;
-    auto fail = [&](int r) { gm_dev_free(tmp, s); return r; };
+    auto fail = [&](int r) { return r; };
     if (hipMemsetAsync(cnts, 0, 4 * 8 * (GM_MAX_GCN + 1), s) != hipSuccess) { gm_set_error("cone: memset failed"); return fail(GM_EHIP); }
     // ---- level L: the centres, in centre order
     gm_cone_level& top = c->lv[L];
@@ -283,7 +284,7 @@ static int cone_build(const gm_batch* b, int L, hipStream_t s, gm_cone* c) {
     for (int l = 0; l < L; ++l) okd = okd && h_off[l];
     if (!okd) { gm_set_error("cone: pinned staging failed"); return fail(GM_ENOMEM); }
     if (hipStreamSynchronize(s) != hipSuccess) { gm_set_error("cone: stream sync failed"); return fail(GM_EHIP); }
-    if (h_cnt[8 * L + 5]) { c->ok = false; gm_dev_free(tmp, s); return GM_OK; }      // two centres on one row (a self pair): callers fall back to the dense schedule
+    if (h_cnt[8 * L + 5]) { c->ok = false; return GM_OK; }      // two centres on one row (a self pair): callers fall back to the dense schedule
     for (int l = L - 1; l >= 0; --l) {
         gm_cone_level& up = c->lv[l + 1]; gm_cone_level& lo = c->lv[l];
         lo.n = h_cnt[8 * l]; up.nnz = h_cnt[8 * (l + 1) + 1];
@@ -296,7 +297,6 @@ static int cone_build(const gm_batch* b, int L, hipStream_t s, gm_cone* c) {
         lo.h_set_off.assign(h_off[l], h_off[l] + sets + 1);
         if ((rc = level_tables(lo, sets, sg)) != GM_OK) return fail(rc);
     }
-    gm_dev_free(tmp, s);
     // the tables of the lower levels went up after the round trip: complete before a consumer on ANOTHER stream may use them (a few small copies, no kernels)
     if (hipStreamSynchronize(s) != hipSuccess) { gm_set_error("cone: stream sync failed"); return GM_EHIP; }
     c->ok = true;
