@@ -485,7 +485,7 @@ class Subgraphs(Dataset):
     @staticmethod
     def _helper_init(dev):
         torch.cuda.set_device(dev)
-        return torch.cuda.Stream()
+        return torch.cuda.Stream(priority=Subgraphs._PREFETCH_PRIORITY)
 
     def _extract_on(self, stream, seeds, off):
         with torch.cuda.stream(stream):
@@ -552,7 +552,8 @@ class Subgraphs(Dataset):
             cols[8 + k] = [gid[off[t]:off[t + 1]] for t in range(b.sets)]
         return tuple(cols)
 
-    _PREFETCH_PRIORITY = 0      # stream priority of the prefetch thread (a high-priority stream measured no better: extraction is host-bound)
+    # stream priority of the builder threads (GMETA_BUILD_PRIORITY; torch convention: lower = more urgent).  A high-priority stream measured no better in round 4
+    _PREFETCH_PRIORITY = int(os.environ.get('GMETA_BUILD_PRIORITY', '0'))
 
     def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None, workers=1):
         """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being extracted by a
