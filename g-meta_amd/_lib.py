@@ -30,6 +30,7 @@ PROTOTYPES = {
     'gm_store_create': (C.c_int, [i32, vp, vp, vp, vp, i32, vp]),
     'gm_store_destroy': (None, [vp]),
     'gm_extract': (C.c_int, [vp, vp, i32, vp, i32, i32, i32, u64, i32, vp, vp]),
+    'gm_extract_pair': (C.c_int, [vp, vp, i32, vp, i32, vp, i32, vp, i32, i32, i32, u64, i32, vp, vp, vp]),
     'gm_batch_from_nodes': (C.c_int, [vp, vp, i32, vp, i32, vp, vp, i32, vp, vp]),
     'gm_batch_concat': (C.c_int, [vp, i32, vp, vp]),
     'gm_batch_destroy': (None, [vp]),

@@ -270,6 +270,7 @@ const gm_knobs& gm_knob() {
         k.dz_glds = env("GM_DZ_GLDS", 1);
         k.fuse_agg = env("GM_FUSE_AGG", 1);
         k.fuse_diff = env("GM_FUSE_DIFF", 2);
+        k.extract_pref16 = env("GM_EXTRACT_PREF16", 1);
         k.head_stage = env("GM_HEAD_STAGE", 1);
         k.head_threads = env("GM_HEAD_THREADS", 0);
         k.query_streams = env("GM_QUERY_STREAMS", 0);
@@ -305,7 +306,7 @@ static int gm_knobs::* gm_find_knob(const char* name) {
         {"GM_GEMM_BN", &gm_knobs::gemm_bn}, {"GM_GEMM_MID_TILES", &gm_knobs::gemm_mid_tiles}, {"GM_GEMM_GLDS", &gm_knobs::gemm_glds}, {"GM_GEMM_NT", &gm_knobs::gemm_nt},
         {"GM_GEMM_SMALL", &gm_knobs::gemm_small}, {"GM_WGRAD_SPLIT", &gm_knobs::wgrad_split}, {"GM_DZ_GLDS", &gm_knobs::dz_glds}, {"GM_HEAD_STAGE", &gm_knobs::head_stage}, {"GM_HEAD_THREADS", &gm_knobs::head_threads}, {"GM_QUERY_STREAMS", &gm_knobs::query_streams}, {"GM_AGG_MID_LIST", &gm_knobs::agg_mid_list}, {"GM_AGG_MID_WIN", &gm_knobs::agg_mid_win}, {"GM_AGG_STREAM", &gm_knobs::agg_stream}, {"GM_AGG_STREAM_DEPTH", &gm_knobs::agg_stream_depth}, {"GM_AGG_STREAM_MIN_ROWS", &gm_knobs::agg_stream_min_rows},
         {"GM_SPLIT16_MIN_ROWS", &gm_knobs::split16_min_rows}, {"GM_WGRAD_SPLIT_MIN_CHUNKS", &gm_knobs::wgrad_split_min_chunks}, {"GM_WGRAD_ROUND_BIAS", &gm_knobs::wgrad_round_bias}, {"GM_TIMING", &gm_knobs::timing},
-        {"GM_FUSE_DIFF", &gm_knobs::fuse_diff},
+        {"GM_FUSE_DIFF", &gm_knobs::fuse_diff}, {"GM_EXTRACT_PREF16", &gm_knobs::extract_pref16},
     };
     for (const auto& e : tab)
         if (!strcmp(name, e.name)) return e.field;

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <mutex>
+#include <type_traits>
 #include "gm_internal.h"
 
 #define EX_BLOCK 512
@@ -42,8 +43,13 @@ template <bool G> __device__ __forceinline__ void wst(uint32_t* p, uint32_t v) {
 }
 template <bool G> __device__ __forceinline__ bool bit_test(const uint32_t* bm, int v) { return (wld<G>(&bm[v >> 5]) >> (v & 31)) & 1u; }
 __device__ __forceinline__ void bit_set(uint32_t* bm, int v) { atomicOr(&bm[v >> 5], 1u << (v & 31)); }
-template <bool G> __device__ __forceinline__ int bit_rank(const uint32_t* bm, const uint32_t* pref, int v) {
-    return (int)wld<G>(&pref[v >> 5]) + __popc(wld<G>(&bm[v >> 5]) & ((1u << (v & 31)) - 1u));
+// The per-word prefix counts are 16-bit where a subgraph holds fewer than 65,536 nodes and the bitmaps live in LDS (PT = uint16_t; round 6): with the
+// 21-KiB membership bitmap of a 169 k-node parent that is 35 instead of 45 KiB per workgroup -- four resident workgroups per CU instead of three.
+template <bool G, typename PT> __device__ __forceinline__ int pref_ld(const PT* p) {
+    if constexpr (sizeof(PT) == 4) return (int)wld<G>(reinterpret_cast<const uint32_t*>(p)); else return (int)*p;
+}
+template <bool G, typename PT> __device__ __forceinline__ int bit_rank(const uint32_t* bm, const PT* pref, int v) {
+    return pref_ld<G, PT>(&pref[v >> 5]) + __popc(wld<G>(&bm[v >> 5]) & ((1u << (v & 31)) - 1u));
 }
 
 // Exclusive scan of part[0..EX_BLOCK) in LDS by wave 0; returns the total through *total (LDS).
@@ -67,8 +73,8 @@ __device__ __forceinline__ void scan_partials(int* part, int* total) {
 }
 
 // pref[w] = number of set bits in seen[0..w); returns the total.
-template <bool G>
-__device__ __forceinline__ int bitmap_prefix(const uint32_t* seen, uint32_t* pref, int W, int* part, int* total) {
+template <bool G, typename PT>
+__device__ __forceinline__ int bitmap_prefix(const uint32_t* seen, PT* pref, int W, int* part, int* total) {
     const int chunk = (W + EX_BLOCK - 1) / EX_BLOCK;
     const int w0 = threadIdx.x * chunk, w1 = min(W, w0 + chunk);
     int s = 0;
@@ -76,7 +82,10 @@ __device__ __forceinline__ int bitmap_prefix(const uint32_t* seen, uint32_t* pre
     part[threadIdx.x] = s;
     scan_partials(part, total);
     int run = part[threadIdx.x];
-    for (int w = w0; w < w1; ++w) { wst<G>(&pref[w], (uint32_t)run); run += __popc(wld<G>(&seen[w])); }
+    for (int w = w0; w < w1; ++w) {
+        if constexpr (sizeof(PT) == 4) wst<G>(reinterpret_cast<uint32_t*>(&pref[w]), (uint32_t)run); else pref[w] = (PT)run;
+        run += __popc(wld<G>(&seen[w]));
+    }
     __syncthreads();
     return *total;
 }
@@ -144,15 +153,22 @@ __device__ __forceinline__ int wave_count(const int64_t a, const int64_t b, cons
 }
 
 // Phase A: node set (BFS or given), sampling, sorted node list, induced in/out degrees.
-template <bool G>
+// P16: 16-bit prefix words (LDS bitmaps, subgraphs below 65,536 nodes).  NEEDX: keep the `expanded` bitmap that de-duplicates frontier expansions -- needed from
+// the third hop on (a hop-2 node is reached through many hop-1 nodes); with two hops it only catches parallel edges of the centre, and without it the
+// region behind `seen` shrinks to the 16-bit prefix words.
+template <bool G, bool P16 = false, bool NEEDX = true>
 __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* seeds, int n_seeds, int h, int sample_n,
                                                     uint64_t rng_seed, int link, const int32_t* given, const int64_t* given_off,
                                                     int cap, int32_t* nodes_slab, int32_t* degi_slab, int32_t* dego_slab,
                                                     int32_t* n_sub, int32_t* e_sub, int Wmax, uint32_t* gbits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* seen = G ? gbits + (size_t)blockIdx.x * 2 * Wmax : lds;
-    uint32_t* pref = seen + Wmax;             // doubles as the `expanded` bitmap during the BFS
-    int* part = (int*)(G ? lds : lds + 2 * Wmax);       // [EX_BLOCK]
+    static_assert(!(G && P16), "16-bit prefix words live in LDS");
+    typedef typename std::conditional<P16, uint16_t, uint32_t>::type PT;
+    uint32_t* xbm = seen + Wmax;              // the `expanded` bitmap of the BFS (NEEDX); the same region holds the prefix words afterwards
+    PT* pref = reinterpret_cast<PT*>(xbm);
+    const int PW = (P16 && !NEEDX) ? (Wmax + 1) / 2 : Wmax;      // words of that region
+    int* part = (int*)(G ? lds : lds + Wmax + PW);      // [EX_BLOCK]
     uint32_t* hist = (uint32_t*)(part + EX_BLOCK);   // [256]
     int* sc = (int*)(hist + 256);             // scalars: 0 total, 1 kk, 2 prefix, 3 edge count in, 4 edge count out
     const int seed = blockIdx.x;
@@ -163,7 +179,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
     const int W = (n + 31) >> 5;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
 
-    for (int w = tid; w < W; w += EX_BLOCK) { wst<G>(&seen[w], 0u); wst<G>(&pref[w], 0u); }
+    for (int w = tid; w < W; w += EX_BLOCK) { wst<G>(&seen[w], 0u); if (NEEDX) wst<G>(&xbm[w], 0u); }
     if (tid < 8) sc[tid] = 0;
     __syncthreads();
     if (given) {
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
     } else {
         const int H = link ? 2 : h;
         const int64_t p0 = S.in_ptr[base + ci], p1 = S.in_ptr[base + ci + 1];
-        if (tid == 0) { bit_set(seen, ci); bit_set(pref, ci); }
+        if (tid == 0) { bit_set(seen, ci); if (NEEDX) bit_set(xbm, ci); }
         for (int64_t q = p0 + tid; q < p1; q += EX_BLOCK) bit_set(seen, S.in_idx[q]);          // hop 1 (sdp.py:301,305,308)
         __syncthreads();
         if (H >= 2) {                                                                         // hop 2 (sdp.py:302,309)
@@ -185,9 +201,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
                 int v = -1; int64_t a = 0, b = 0;
                 if (q < p1) {
                     v = S.in_idx[q];
-                    int first = 0;
-                    if (gl == 0) { const uint32_t bit = 1u << (v & 31); first = !(atomicOr(&pref[v >> 5], bit) & bit); }
-                    first = __shfl(first, grp * EX_GL, 64);
+                    int first = 1;
+                    if constexpr (NEEDX) {
+                        first = 0;
+                        if (gl == 0) { const uint32_t bit = 1u << (v & 31); first = !(atomicOr(&xbm[v >> 5], bit) & bit); }
+                        first = __shfl(first, grp * EX_GL, 64);
+                    }
                     if (first) { a = S.in_ptr[base + v]; b = S.in_ptr[base + v + 1]; }
                     if (b - a > EX_BIG_DEG) {
                         int slot = EX_BLOCK;
@@ -218,7 +237,7 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
                     if (r + lane < b) {
                         u = S.in_idx[r + lane];
                         const uint32_t bit = 1u << (u & 31);
-                        first = !(atomicOr(&pref[u >> 5], bit) & bit);
+                        first = !(atomicOr(&xbm[u >> 5], bit) & bit);
                     }
                     unsigned long long m = __ballot(first);
                     while (m) {
@@ -284,12 +303,12 @@ __global__ __launch_bounds__(EX_BLOCK) void k_nodes(ExStore S, const gm_seed_t* 
         }
     }
     // ---- ascending node list + local-id prefix
-    const int ns = bitmap_prefix<G>(seen, pref, W, part, &sc[0]);
+    const int ns = bitmap_prefix<G, PT>(seen, pref, W, part, &sc[0]);
     if (ns > cap) { if (tid == 0) { n_sub[seed] = -ns; e_sub[seed] = 0; } return; }   // host reports the error
     int32_t* nodes = nodes_slab + (int64_t)seed * cap;
     for (int w = tid; w < W; w += EX_BLOCK) {
         uint32_t bits = wld<G>(&seen[w]);
-        int r = (int)wld<G>(&pref[w]);
+        int r = pref_ld<G, PT>(&pref[w]);
         while (bits) { const int b = __ffs(bits) - 1; bits &= bits - 1; nodes[r++] = w * 32 + b; }
     }
     __syncthreads();
@@ -360,9 +379,9 @@ __device__ __forceinline__ void scan_degrees(const int32_t* deg, int ns, int32_t
 
 // Ordered compaction of the neighbours of v that are inside the subgraph, remapped to batch rows (out2: optional second copy -- the
 // by-source CSR of a symmetric parent).
-template <bool G>
+template <bool G, typename PT>
 __device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t* idx, int64_t base, int v, const uint32_t* seen,
-                                              const uint32_t* pref, int row0, int32_t* out, int32_t* out2, int pos, int lane) {
+                                              const PT* pref, int row0, int32_t* out, int32_t* out2, int pos, int lane) {
     const int64_t a = ptr[base + v], b = ptr[base + v + 1];
     const unsigned long long lt = (1ull << lane) - 1ull;
     for (int64_t q = a; q < b; q += EX_WINFL * GM_WAVE) {
@@ -373,14 +392,14 @@ __device__ __forceinline__ void wave_fill_row(const int64_t* ptr, const int32_t*
         for (int k = 0; k < EX_WINFL; ++k) {                     // in list order
             const int hit = u[k] >= 0 && bit_test<G>(seen, u[k]);
             const unsigned long long m = __ballot(hit);
-            if (hit) { const int x = row0 + bit_rank<G>(seen, pref, u[k]), p = pos + __popcll(m & lt); out[p] = x; if (out2) out2[p] = x; }
+            if (hit) { const int x = row0 + bit_rank<G, PT>(seen, pref, u[k]), p = pos + __popcll(m & lt); out[p] = x; if (out2) out2[p] = x; }
             pos += __popcll(m);
         }
     }
 }
 // The same for one node per group of eight lanes (all lanes of the wave call it; a group without a node passes a == b)
-template <bool G>
-__device__ __forceinline__ void group_fill_row(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, const uint32_t* pref, int row0,
+template <bool G, typename PT>
+__device__ __forceinline__ void group_fill_row(const int64_t a, const int64_t b, const int32_t* idx, const uint32_t* seen, const PT* pref, int row0,
                                                int32_t* out, int32_t* out2, int pos, int grp, int gl) {
     const unsigned lt = (1u << gl) - 1u;
     for (int64_t q = a + gl; __any(q < b); q += EX_INFL * EX_GL) {
@@ -391,32 +410,45 @@ __device__ __forceinline__ void group_fill_row(const int64_t a, const int64_t b,
         for (int k = 0; k < EX_INFL; ++k) {                      // in list order: the k-th batch of eight neighbours after the (k-1)-th
             const int h = u[k] >= 0 && bit_test<G>(seen, u[k]);
             const unsigned bm = (unsigned)(__ballot(h) >> (grp * EX_GL)) & 0xffu;
-            if (h) { const int x = row0 + bit_rank<G>(seen, pref, u[k]), p = pos + __popc(bm & lt); out[p] = x; if (out2) out2[p] = x; }
+            if (h) { const int x = row0 + bit_rank<G, PT>(seen, pref, u[k]), p = pos + __popc(bm & lt); out[p] = x; if (out2) out2[p] = x; }
             pos += __popc(bm);
         }
     }
 }
 
 // Phase B: write the batched CSR (by destination and by source), parents, feature rows, norm, centres.
-template <bool G>
+// One launch may fill TWO batches (gm_extract_pair: the support and the query batch of a meta-batch): seeds [0, split) belong to o0, the rest to o1, each
+// batch numbered from its own subgraph 0.  (The 288-subgraph support launch of a 32-task meta-batch was ~0.1 ms of one workgroup's latency chain on an otherwise
+// empty GPU; as the head of the 2,592-workgroup joint launch it costs nothing.)
+struct FillOut {
+    const int32_t* sub_off; const int32_t* sub_eoff; int32_t* parent; int32_t* feat_row; float* norm;
+    int32_t* indptr; int32_t* indices; int32_t* indptr_t; int32_t* indices_t; int32_t* centre;
+};
+template <bool G, bool P16 = false>
 __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* seeds, int n_seeds, int link, int cap,
                                                    const int32_t* nodes_slab, const int32_t* degi_slab, const int32_t* dego_slab,
-                                                   const int32_t* sub_off, const int32_t* sub_eoff, int32_t* parent, int32_t* feat_row,
-                                                   float* norm, int32_t* indptr, int32_t* indices, int32_t* indptr_t,
-                                                   int32_t* indices_t, int32_t* centre, int Wmax, uint32_t* gbits) {
+                                                   FillOut o0, FillOut o1, int split, int Wmax, uint32_t* gbits) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* seen = G ? gbits + (size_t)blockIdx.x * 2 * Wmax : lds;
-    uint32_t* pref = seen + Wmax;
-    int* part = (int*)(G ? lds : lds + 2 * Wmax);
+    static_assert(!(G && P16), "16-bit prefix words live in LDS");
+    typedef typename std::conditional<P16, uint16_t, uint32_t>::type PT;
+    PT* pref = reinterpret_cast<PT*>(seen + Wmax);
+    int* part = (int*)(G ? lds : lds + Wmax + (P16 ? (Wmax + 1) / 2 : Wmax));
     int* sc = part + EX_BLOCK;
     const int seed = blockIdx.x;
     if (seed >= n_seeds) return;
+    const bool second = seed >= split;
+    const int ls = second ? seed - split : seed, nl = second ? n_seeds - split : split;      // subgraph number inside its batch; the batch's subgraph count
+    const int32_t* sub_off = second ? o1.sub_off : o0.sub_off; const int32_t* sub_eoff = second ? o1.sub_eoff : o0.sub_eoff;
+    int32_t* parent = second ? o1.parent : o0.parent; int32_t* feat_row = second ? o1.feat_row : o0.feat_row; float* norm = second ? o1.norm : o0.norm;
+    int32_t* indptr = second ? o1.indptr : o0.indptr; int32_t* indices = second ? o1.indices : o0.indices;
+    int32_t* indptr_t = second ? o1.indptr_t : o0.indptr_t; int32_t* indices_t = second ? o1.indices_t : o0.indices_t; int32_t* centre = second ? o1.centre : o0.centre;
     const int g = seeds[seed].graph;
     const int64_t base = S.node_off[g];
     const int n = (int)(S.node_off[g + 1] - base);
     const int W = (n + 31) >> 5;
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int row0 = sub_off[seed], ns = sub_off[seed + 1] - row0, e0 = sub_eoff[seed];
+    const int row0 = sub_off[ls], ns = sub_off[ls + 1] - row0, e0 = sub_eoff[ls];
     const int32_t* nodes = nodes_slab + (int64_t)seed * cap;
     const int32_t* degi = degi_slab + (int64_t)seed * cap;
     const int32_t* dego = dego_slab + (int64_t)seed * cap;
@@ -432,15 +464,15 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
         norm[row0 + r] = 1.0f / sqrtf((float)(d > 1 ? d : 1));          // in_degrees().clamp(min=1) ** -0.5 (learner.py:29)
     }
     __syncthreads();
-    bitmap_prefix<G>(seen, pref, W, part, &sc[0]);
+    bitmap_prefix<G, PT>(seen, pref, W, part, &sc[0]);
     scan_degrees(degi, ns, indptr + row0, e0, part, &sc[0]);
     scan_degrees(dego, ns, indptr_t + row0, e0, part, &sc[1]);
-    if (seed == n_seeds - 1 && tid == 0) { indptr[row0 + ns] = e0 + sc[0]; indptr_t[row0 + ns] = e0 + sc[1]; }
+    if (ls == nl - 1 && tid == 0) { indptr[row0 + ns] = e0 + sc[0]; indptr_t[row0 + ns] = e0 + sc[1]; }
     __syncthreads();
     if (tid == 0) {
         const int nc = link ? 2 : 1;
-        centre[seed * nc] = bit_rank<G>(seen, pref, seeds[seed].i);
-        if (link) centre[seed * nc + 1] = bit_rank<G>(seen, pref, seeds[seed].j);
+        centre[ls * nc] = bit_rank<G, PT>(seen, pref, seeds[seed].i);
+        if (link) centre[ls * nc + 1] = bit_rank<G, PT>(seen, pref, seeds[seed].j);
     }
     // eight rows per wave at a time (one per group of eight lanes); hub nodes by a whole wave afterwards.  A symmetric parent fills both
     // orientations from the one walk.
@@ -478,15 +510,15 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
                     if (slot < EX_BLOCK) { if (gl == 0) big[slot] = r; ia = ib = oa = ob = 0; }      // (list full: the group walks it itself)
                 }
             }
-            group_fill_row<G>(ia, ib, S.in_idx, seen, pref, row0, indices, ind2, pi, grp, gl);
-            if (!S.sym) group_fill_row<G>(oa, ob, S.out_idx, seen, pref, row0, indices_t, nullptr, po, grp, gl);
+            group_fill_row<G, PT>(ia, ib, S.in_idx, seen, pref, row0, indices, ind2, pi, grp, gl);
+            if (!S.sym) group_fill_row<G, PT>(oa, ob, S.out_idx, seen, pref, row0, indices_t, nullptr, po, grp, gl);
         }
         __syncthreads();
         const int nb = min(*nbig, EX_BLOCK);
         for (int k = wave; k < nb; k += EX_WAVES) {
             const int r = big[k], v = nodes[r];
-            wave_fill_row<G>(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, ind2, indptr[row0 + r], lane);
-            if (!S.sym) wave_fill_row<G>(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, nullptr, indptr_t[row0 + r], lane);
+            wave_fill_row<G, PT>(S.in_ptr, S.in_idx, base, v, seen, pref, row0, indices, ind2, indptr[row0 + r], lane);
+            if (!S.sym) wave_fill_row<G, PT>(S.out_ptr, S.out_idx, base, v, seen, pref, row0, indices_t, nullptr, indptr_t[row0 + r], lane);
         }
     }
 }
@@ -775,8 +807,24 @@ static void sort_rows_with_degrees(std::vector<int32_t>& row, std::vector<int32_
     }
     if (r0 != row.data()) { row.swap(row2); deg.swap(deg2); }
 }
+// The finalisation in two halves around its host round trip, so that a caller that builds TWO batches (gm_extract_pair) queues both batches' kernels,
+// waits once, and derives both batches' host-side tables while nothing is left to wait for.
+struct FinalizeCtx {
+    int cap = 0, first = 0;
+    int32_t* d_cnt = nullptr; unsigned long long* d_counts = nullptr; int32_t* d_cdeg = nullptr;
+    const int32_t* h_cnt = nullptr; const int32_t* h_heavy[2] = {nullptr, nullptr}; const int32_t* h_hdeg[2] = {nullptr, nullptr};
+    const unsigned long long* h_counts = nullptr; const int32_t* h_cdeg = nullptr;
+};
+static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
+static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
 int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
-    gm_phase_timer tm("finalize");
+    FinalizeCtx fc;
+    GM_TRY(finalize_launch(b, s, sg, fc));
+    GM_HIP(hipStreamSynchronize(s));
+    return finalize_finish(b, s, sg, fc);
+}
+static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc) {
+    gm_phase_timer tm("finalize-launch");
     std::vector<int32_t> sub_set(b->subs), tiles, chunks, set_chunk_off(b->sets + 1, 0);
     for (int t = 0; t < b->sets; ++t)
         for (int k = b->h_set_sub_off[t]; k < b->h_set_sub_off[t + 1]; ++k) sub_set[k] = t;
@@ -833,8 +881,17 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     const int32_t* h_cdeg = sg.download(d_cdeg, (size_t)b->n_c);
     GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
     tm.lap("launches");
-    GM_HIP(hipStreamSynchronize(s));
-    tm.lap("gpu-wait");
+    fc.cap = cap; fc.first = first; fc.d_cnt = d_cnt; fc.d_counts = d_counts; fc.d_cdeg = d_cdeg;
+    fc.h_cnt = h_cnt; fc.h_counts = h_counts; fc.h_cdeg = h_cdeg;
+    for (int o = 0; o < 2; ++o) { fc.h_heavy[o] = h_heavy[o]; fc.h_hdeg[o] = h_hdeg[o]; }
+    return GM_OK;
+}
+static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc) {      // (the stream has passed finalize_launch's downloads)
+    gm_phase_timer tm("finalize-finish");
+    const int cap = fc.cap, first = fc.first, nc = b->centres;
+    int32_t* d_cnt = fc.d_cnt; unsigned long long* d_counts = fc.d_counts; int32_t* d_cdeg = fc.d_cdeg;
+    const int32_t* h_cnt = fc.h_cnt; const unsigned long long* h_counts = fc.h_counts; const int32_t* h_cdeg = fc.h_cdeg;
+    const int32_t* h_heavy[2] = {fc.h_heavy[0], fc.h_heavy[1]}; const int32_t* h_hdeg[2] = {fc.h_hdeg[0], fc.h_hdeg[1]};
     gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
     if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
     b->sched_win = gm_agg_window(b->rows, b->edges);
@@ -950,15 +1007,26 @@ static int upload_small(gm_batch* b, gm_stager& sg) {
     return GM_OK;
 }
 
-static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets, int32_t n_sets,
-                        int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link, const int32_t* nodes_flat,
-                        const int64_t* nodes_off, void* stream, gm_batch_t** out) {
-    GM_REQUIRE(out, GM_EINVAL, "extract: out is NULL");
-    *out = nullptr;
+// One build of ONE batch (n_parts = 1) or of the two batches of a meta-batch together (n_parts = 2: seeds = [part 0 | part 1]; gm_extract_pair): the
+// node-set kernel runs over all subgraphs in one launch, so does the fill kernel (k_fill serves two batches), the two finalisations queue their kernels
+// back to back and share one host round trip.
+struct ExPart { const int32_t* set_offsets; int32_t n_sets; int32_t n_seeds; };
+static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int n_parts, const ExPart* parts, int32_t h, int32_t sample_nodes, uint64_t rng_seed,
+                        int32_t link, const int32_t* nodes_flat, const int64_t* nodes_off, void* stream, gm_batch_t** outs) {
+    GM_REQUIRE(outs && (n_parts == 1 || n_parts == 2), GM_EINVAL, "extract: out is NULL");
+    for (int p = 0; p < n_parts; ++p) outs[p] = nullptr;
     gm_phase_timer tm("extract");
-    GM_REQUIRE(store && seeds && set_offsets && n_seeds >= 1 && n_sets >= 1, GM_EINVAL, "extract: bad arguments");
-    GM_REQUIRE(set_offsets[0] == 0 && set_offsets[n_sets] == n_seeds, GM_EINVAL, "extract: set_offsets must span [0,n_seeds]");
+    GM_REQUIRE(store && seeds, GM_EINVAL, "extract: bad arguments");
+    int32_t n_seeds = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        const ExPart& q = parts[p];
+        GM_REQUIRE(q.set_offsets && q.n_seeds >= 1 && q.n_sets >= 1, GM_EINVAL, "extract: bad arguments");
+        GM_REQUIRE(q.set_offsets[0] == 0 && q.set_offsets[q.n_sets] == q.n_seeds, GM_EINVAL, "extract: set_offsets must span [0,n_seeds]");
+        n_seeds += q.n_seeds;
+    }
+    const int32_t split = parts[0].n_seeds;                  // seeds [0, split): part 0
     const bool given = nodes_flat != nullptr;
+    GM_REQUIRE(!given || n_parts == 1, GM_EINVAL, "extract: node lists are given per batch");
     if (!given) {
         GM_REQUIRE(link || (h >= 1 && h <= 3), GM_EINVAL, "extract: h=%d unsupported (the reference defines h in {1,2,3}, sdp.py:300-311)", h);
         GM_REQUIRE(sample_nodes >= 1, GM_EINVAL, "extract: sample_nodes must be >= 1");
@@ -990,24 +1058,33 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     // parent graphs beyond ~650k nodes do not fit the LDS bitmap pair: fall back to a per-workgroup slab in HBM
     const bool gpath = force_global || lds_a > 160 * 1024;
     if (gpath) lds_a = sizeof(uint32_t) * (EX_BLOCK + 256 + 16);
+    // 16-bit prefix words wherever a subgraph stays below 65,536 nodes (GM_EXTRACT_PREF16=0: 32-bit as before); the BFS keeps its `expanded` bitmap from three hops on
+    const bool p16 = !gpath && cap < 65536 && gm_knob().extract_pref16;
+    const bool needx = !given && !link && h >= 3;
+    const size_t Wp = p16 ? ((size_t)Wmax + 1) / 2 : (size_t)Wmax;              // words of the prefix region
+    if (!gpath) lds_a = sizeof(uint32_t) * ((size_t)Wmax + ((p16 && !needx) ? Wp : (size_t)Wmax) + EX_BLOCK + 256 + 16);
     hipStream_t st = (hipStream_t)stream;
     GM_TRY(gm_func_full_lds((const void*)k_nodes<false>));
+    GM_TRY(gm_func_full_lds((const void*)k_nodes<false, true, true>));
+    GM_TRY(gm_func_full_lds((const void*)k_nodes<false, true, false>));
     GM_TRY(gm_func_full_lds((const void*)k_fill<false>));
+    GM_TRY(gm_func_full_lds((const void*)k_fill<false, true>));
     ExStore S{store->d_node_off, store->d_in_ptr, store->d_in_idx, store->d_out_ptr, store->d_out_idx, store->symmetric ? 1 : 0};
 
     gm_seed_t* d_seeds = nullptr; int32_t *d_nodes = nullptr, *d_degi = nullptr, *d_dego = nullptr, *d_nsub = nullptr, *d_esub = nullptr;
-    int32_t* d_given = nullptr; int64_t* d_given_off = nullptr, *dummy = nullptr; (void)dummy;
+    int32_t* d_given = nullptr; int64_t* d_given_off = nullptr;
     int32_t* d_eoff = nullptr;
     uint32_t* d_gbits = nullptr;
-    gm_batch* b = new gm_batch();
+    gm_batch* bs[2] = {new gm_batch(), n_parts == 2 ? new gm_batch() : nullptr};
     int rc = GM_OK;
     auto cleanup = [&]() {
         gm_dev_free(d_gbits, st);
         gm_dev_free(d_seeds, st); gm_dev_free(d_nodes, st); gm_dev_free(d_degi, st); gm_dev_free(d_dego, st);
         gm_dev_free(d_nsub, st); gm_dev_free(d_esub, st); gm_dev_free(d_given, st); gm_dev_free(d_given_off, st); gm_dev_free(d_eoff, st);
     };
-#define EX_TRY(x) do { rc = (x); if (rc != GM_OK) { cleanup(); batch_free(b); delete b; return rc; } } while (0)
-#define EX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm_set_error("%s: %s", #x, hipGetErrorString(e_)); cleanup(); batch_free(b); delete b; return GM_EHIP; } } while (0)
+    auto drop = [&]() { cleanup(); for (int p = 0; p < n_parts; ++p) { batch_free(bs[p]); delete bs[p]; } };
+#define EX_TRY(x) do { rc = (x); if (rc != GM_OK) { drop(); return rc; } } while (0)
+#define EX_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { gm_set_error("%s: %s", #x, hipGetErrorString(e_)); drop(); return GM_EHIP; } } while (0)
     tm.lap("validate");
     gm_stager sg(st);                          // pinned staging: the build makes TWO host round trips (subgraph sizes, finalisation)
     EX_TRY(gm_alloc(&d_seeds, n_seeds, st));
@@ -1026,6 +1103,12 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
         EX_TRY(gm_alloc(&d_gbits, (size_t)n_seeds * 2 * Wmax, st));
         hipLaunchKernelGGL(k_nodes<true>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
                            d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, d_gbits);
+    } else if (p16 && !needx) {
+        hipLaunchKernelGGL((k_nodes<false, true, false>), dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
+                           d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, (uint32_t*)nullptr);
+    } else if (p16) {
+        hipLaunchKernelGGL((k_nodes<false, true, true>), dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
+                           d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, (uint32_t*)nullptr);
     } else {
         hipLaunchKernelGGL(k_nodes<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_a, st, S, d_seeds, n_seeds, h, sample_nodes, rng_seed, link ? 1 : 0,
                            d_given, d_given_off, (int)cap, d_nodes, d_degi, d_dego, d_nsub, d_esub, Wmax, (uint32_t*)nullptr);
@@ -1033,69 +1116,100 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int32_t
     gm_prof_end(GM_PROF_EX_NODES, st);
     EX_HIP(hipGetLastError());
     const int32_t* nsub = sg.download(d_nsub, (size_t)n_seeds); const int32_t* esub = sg.download(d_esub, (size_t)n_seeds);
-    if (!nsub || !esub) { gm_set_error("extract: pinned staging failed"); cleanup(); batch_free(b); delete b; return GM_ENOMEM; }
+    if (!nsub || !esub) { gm_set_error("extract: pinned staging failed"); drop(); return GM_ENOMEM; }
     EX_HIP(hipStreamSynchronize(st));
 
     tm.lap("k_nodes+sizes");
-    b->store = store; b->subs = n_seeds; b->sets = n_sets; b->centres = link ? 2 : 1; b->stream = st;
-    b->h_sub_off.assign(n_seeds + 1, 0); b->h_graph.resize(n_seeds);
-    std::vector<int32_t> eoff(n_seeds + 1, 0);
-    int64_t rows = 0, edges = 0;
-    for (int k = 0; k < n_seeds; ++k) {
-        if (nsub[k] <= 0 || esub[k] < 0) {
-            gm_set_error("extract: subgraph %d failed on device (nodes=%d, edges=%d, cap=%lld)", k, nsub[k], esub[k], (long long)cap);
-            cleanup(); batch_free(b); delete b; return GM_ERANGE;
+    // per batch: host prefix sums, device arrays; the edge offsets of both batches share one upload ([part 0: n0 + 1 | part 1: n1 + 1])
+    std::vector<int32_t> eoff((size_t)n_seeds + n_parts, 0);
+    int32_t* eoff_p[2] = {eoff.data(), eoff.data() + split + 1};
+    FillOut fo[2] = {};
+    for (int p = 0, k0 = 0; p < n_parts; k0 += parts[p].n_seeds, ++p) {
+        gm_batch* b = bs[p]; const ExPart& q = parts[p];
+        b->store = store; b->subs = q.n_seeds; b->sets = q.n_sets; b->centres = link ? 2 : 1; b->stream = st;
+        b->h_sub_off.assign(q.n_seeds + 1, 0); b->h_graph.resize(q.n_seeds);
+        int64_t rows = 0, edges = 0;
+        for (int k = 0; k < q.n_seeds; ++k) {
+            const int gk = k0 + k;
+            if (nsub[gk] <= 0 || esub[gk] < 0) {
+                gm_set_error("extract: subgraph %d failed on device (nodes=%d, edges=%d, cap=%lld)", gk, nsub[gk], esub[gk], (long long)cap);
+                drop(); return GM_ERANGE;
+            }
+            rows += nsub[gk]; edges += esub[gk];
+            if (rows > INT32_MAX - 2 || edges > INT32_MAX - 2) { gm_set_error("extract: batch exceeds 2^31 rows/edges; split the meta-batch"); drop(); return GM_ERANGE; }
+            b->h_sub_off[k + 1] = (int32_t)rows; eoff_p[p][k + 1] = (int32_t)edges; b->h_graph[k] = seeds[gk].graph;
         }
-        rows += nsub[k]; edges += esub[k];
-        if (rows > INT32_MAX - 2 || edges > INT32_MAX - 2) {
-            gm_set_error("extract: batch exceeds 2^31 rows/edges; split the meta-batch"); cleanup(); batch_free(b); delete b; return GM_ERANGE;
-        }
-        b->h_sub_off[k + 1] = (int32_t)rows; eoff[k + 1] = (int32_t)edges; b->h_graph[k] = seeds[k].graph;
+        b->rows = rows; b->edges = edges;
+        b->h_set_sub_off.assign(q.set_offsets, q.set_offsets + q.n_sets + 1);
+        b->h_set_row_off.resize(q.n_sets + 1);
+        for (int s = 0; s <= q.n_sets; ++s) b->h_set_row_off[s] = b->h_sub_off[q.set_offsets[s]];
+        EX_TRY(batch_alloc(b, st));
+        EX_TRY(upload_small(b, sg));
     }
-    b->rows = rows; b->edges = edges;
-    b->h_set_sub_off.assign(set_offsets, set_offsets + n_sets + 1);
-    b->h_set_row_off.resize(n_sets + 1);
-    for (int s = 0; s <= n_sets; ++s) b->h_set_row_off[s] = b->h_sub_off[set_offsets[s]];
-    EX_TRY(batch_alloc(b, st));
-    EX_TRY(upload_small(b, sg));
-    EX_TRY(gm_alloc(&d_eoff, n_seeds + 1, st));
+    EX_TRY(gm_alloc(&d_eoff, eoff.size(), st));
     EX_TRY(sg.upload(d_eoff, eoff));
+    for (int p = 0; p < n_parts; ++p) {
+        gm_batch* b = bs[p];
+        fo[p] = FillOut{b->d_sub_off, d_eoff + (p ? split + 1 : 0), b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t, b->d_indices_t, b->d_centre};
+    }
+    if (n_parts == 1) fo[1] = fo[0];
     gm_prof_begin(GM_PROF_EX_FILL, st, n_seeds);
     if (gpath) {
         hipLaunchKernelGGL(k_fill<true>, dim3(n_seeds), dim3(EX_BLOCK), sizeof(uint32_t) * (EX_BLOCK + 16), st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap,
-                           d_nodes, d_degi, d_dego, b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices,
-                           b->d_indptr_t, b->d_indices_t, b->d_centre, Wmax, d_gbits);
+                           d_nodes, d_degi, d_dego, fo[0], fo[1], (int)split, Wmax, d_gbits);
     } else {
-        const size_t lds_b = sizeof(uint32_t) * (2 * (size_t)Wmax + EX_BLOCK + 16);
-        hipLaunchKernelGGL(k_fill<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
-                           b->d_sub_off, d_eoff, b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t,
-                           b->d_indices_t, b->d_centre, Wmax, (uint32_t*)nullptr);
+        const size_t lds_b = sizeof(uint32_t) * ((size_t)Wmax + Wp + EX_BLOCK + 16);
+        if (p16) hipLaunchKernelGGL((k_fill<false, true>), dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
+                                    fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr);
+        else hipLaunchKernelGGL(k_fill<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
+                                fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr);
     }
     gm_prof_end(GM_PROF_EX_FILL, st);
     EX_HIP(hipGetLastError());
     tm.lap("alloc+k_fill");
+    // finalisation: both batches' kernels and downloads queued, ONE wait, then the host halves
     gm_prof_begin(GM_PROF_EX_FINAL, st, 1);
-    rc = gm_batch_finalize(b, st, sg);
+    FinalizeCtx fc[2];
+    for (int p = 0; p < n_parts; ++p) EX_TRY(finalize_launch(bs[p], st, sg, fc[p]));
+    EX_HIP(hipStreamSynchronize(st));
+    tm.lap("finalize-wait");
+    for (int p = 0; p < n_parts; ++p) EX_TRY(finalize_finish(bs[p], st, sg, fc[p]));
     gm_prof_end(GM_PROF_EX_FINAL, st);
-    EX_TRY(rc);
     tm.lap("finalize");
     cleanup();
 #undef EX_TRY
 #undef EX_HIP
-    *out = b;
+    for (int p = 0; p < n_parts; ++p) outs[p] = bs[p];
     return GM_OK;
 }
 
 extern "C" int gm_extract(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets, int32_t n_sets,
                           int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link_pred, void* stream, gm_batch_t** out) {
-    return extract_impl(store, seeds, n_seeds, set_offsets, n_sets, h, sample_nodes, rng_seed, link_pred, nullptr, nullptr, stream, out);
+    GM_REQUIRE(out, GM_EINVAL, "extract: out is NULL");
+    const ExPart part{set_offsets, n_sets, n_seeds};
+    return extract_impl(store, seeds, 1, &part, h, sample_nodes, rng_seed, link_pred, nullptr, nullptr, stream, out);
+}
+
+extern "C" int gm_extract_pair(const gm_store_t* store, const gm_seed_t* seeds_a, int32_t n_seeds_a, const int32_t* set_offsets_a, int32_t n_sets_a,
+                               const gm_seed_t* seeds_b, int32_t n_seeds_b, const int32_t* set_offsets_b, int32_t n_sets_b,
+                               int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link_pred, void* stream, gm_batch_t** out_a, gm_batch_t** out_b) {
+    GM_REQUIRE(out_a && out_b && seeds_a && seeds_b && n_seeds_a >= 1 && n_seeds_b >= 1, GM_EINVAL, "extract_pair: bad arguments");
+    *out_a = nullptr; *out_b = nullptr;
+    std::vector<gm_seed_t> all((size_t)n_seeds_a + n_seeds_b);
+    std::copy(seeds_a, seeds_a + n_seeds_a, all.begin()); std::copy(seeds_b, seeds_b + n_seeds_b, all.begin() + n_seeds_a);
+    const ExPart parts[2] = {{set_offsets_a, n_sets_a, n_seeds_a}, {set_offsets_b, n_sets_b, n_seeds_b}};
+    gm_batch_t* outs[2] = {nullptr, nullptr};
+    const int rc = extract_impl(store, all.data(), 2, parts, h, sample_nodes, rng_seed, link_pred, nullptr, nullptr, stream, outs);
+    *out_a = outs[0]; *out_b = outs[1];
+    return rc;
 }
 
 extern "C" int gm_batch_from_nodes(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds, const int32_t* set_offsets,
                                    int32_t n_sets, const int32_t* nodes_flat, const int64_t* nodes_off, int32_t link_pred, void* stream,
                                    gm_batch_t** out) {
-    GM_REQUIRE(nodes_flat && nodes_off, GM_EINVAL, "from_nodes: node lists are NULL");
-    return extract_impl(store, seeds, n_seeds, set_offsets, n_sets, 1, 1, 0, link_pred, nodes_flat, nodes_off, stream, out);
+    GM_REQUIRE(out && nodes_flat && nodes_off, GM_EINVAL, "from_nodes: node lists are NULL");
+    const ExPart part{set_offsets, n_sets, n_seeds};
+    return extract_impl(store, seeds, 1, &part, 1, 1, 0, link_pred, nodes_flat, nodes_off, stream, out);
 }
 
 extern "C" int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, void* stream, gm_batch_t** out) {

@@ -190,6 +190,7 @@ void gm_batch_mark_use(const gm_batch* b, hipStream_t st);
 struct gm_knobs {
     int agg_min_waves, agg_min_win, agg_sched, agg_hub_part, agg_unr, agg_nt, agg_variant, agg_edge_tables, heavy_deg;
     int extract_global_bitmap, feat_pad, timing;
+    int extract_pref16;            // GM_EXTRACT_PREF16: 16-bit per-word prefix counts in the extraction kernels' LDS (1, default): four resident workgroups per CU instead of three at the arxiv parent size
     int gemm_mode;                 // 0 exact fp32, 1 split-bf16, -1 not set (library default)
     int gemm_split_min_tiles;      // -1: a quarter of the current device's CUs
     int gemm_split_grid;           // 0: the current device's CU count

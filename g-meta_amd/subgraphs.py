@@ -96,6 +96,23 @@ class SubgraphBatch:
         return b
 
     @classmethod
+    def extract_pair(cls, store, seeds_a, set_offsets_a, seeds_b, set_offsets_b, h, sample_nodes, rng_seed, link_pred):
+        """The two batches extract() would return for (seeds_a, set_offsets_a) and (seeds_b, set_offsets_b), from one build (gm_extract_pair)."""
+        aa, ab = cls._seed_array(seeds_a), cls._seed_array(seeds_b)
+        sa, sb = np.ascontiguousarray(set_offsets_a, np.int32), np.ascontiguousarray(set_offsets_b, np.int32)
+        oa, ob = C.c_void_p(), C.c_void_p()
+        _lib.check(_lib.lib().gm_extract_pair(store.handle, _lib.ptr(aa), len(aa), _lib.ptr(sa), len(sa) - 1, _lib.ptr(ab), len(ab), _lib.ptr(sb), len(sb) - 1,
+                                              int(h), int(sample_nodes), C.c_uint64(int(rng_seed) & (2 ** 64 - 1)), int(bool(link_pred)), _lib.stream_ptr(),
+                                              C.byref(oa), C.byref(ob)), 'gm_extract_pair')
+        out = []
+        for h_, arr, so in ((oa, aa, sa), (ob, ab, sb)):
+            b = cls(h_, store)
+            b._cache[(_lib.F_SET_SUB_OFF,)] = so
+            b._cache[(_lib.F_GRAPH,)] = np.ascontiguousarray(arr[:, 0])
+            out.append(b)
+        return out[0], out[1]
+
+    @classmethod
     def from_nodes(cls, store, seeds, set_offsets, node_lists, link_pred):
         arr = cls._seed_array(seeds)
         so = np.ascontiguousarray(set_offsets, np.int32)
@@ -383,18 +400,23 @@ class Subgraphs(Dataset):
                                           np.array([lab[i] for i in qry]).astype(np.int32))
         return c
 
+    @staticmethod
+    def _labels_lists(support_y, query_y):
+        """sdp.py:389-397 on plain lists: a handful of labels per task, where plain Python beats five numpy calls (this runs per task between two
+        meta-steps, under the GIL)."""
+        sl, ql = support_y.tolist(), query_y.tolist()
+        unique = sorted(set(sl))                                              # np.unique(support_y)
+        # random.shuffle(unique) of the reference, applied to an index list: the same draws, the same permutation
+        order = list(range(len(unique)))
+        random.shuffle(order)
+        rank = {unique[o]: idx for idx, o in enumerate(order)}                # class unique[order[idx]] -> idx
+        get = rank.get
+        return [rank[c] for c in sl], [get(c, 0) for c in ql]                 # a query class absent from the support keeps 0 (np.zeros, sdp.py:393)
+
     def _labels(self, support_y, query_y):
         if self.task_setup == 'Disjoint':                                     # sdp.py:389-397
-            # a handful of labels per task: plain Python beats five numpy calls (this runs per task between two meta-steps, under the GIL)
-            sl, ql = support_y.tolist(), query_y.tolist()
-            unique = sorted(set(sl))                                          # np.unique(support_y)
-            # random.shuffle(unique) of the reference, applied to an index list: the same draws, the same permutation
-            order = list(range(len(unique)))
-            random.shuffle(order)
-            rank = {unique[o]: idx for idx, o in enumerate(order)}            # class unique[order[idx]] -> idx
-            get = rank.get
-            return (torch.tensor([rank[c] for c in sl], dtype=torch.int64),
-                    torch.tensor([get(c, 0) for c in ql], dtype=torch.int64))   # a query class absent from the support keeps 0 (np.zeros, sdp.py:393)
+            ys, yq = self._labels_lists(support_y, query_y)
+            return torch.tensor(ys, dtype=torch.int64), torch.tensor(yq, dtype=torch.int64)
         return torch.from_numpy(support_y.astype(np.int64)), torch.from_numpy(query_y.astype(np.int64))
 
     def _tuple(self, bs, bq, ys, yq):
@@ -469,12 +491,11 @@ class Subgraphs(Dataset):
     # of host-side table work between its kernels): the support batch is built by a helper thread on a stream of its own while the calling thread
     # builds the query batch -- ctypes releases the GIL for the length of the call.  The caller's stream then waits for the helper stream's event, so
     # consumers see both batches complete; gm_batch_destroy orders its frees behind the consumers' work (gm_batch_mark_use) as for prefetched batches.
-    # One helper per calling thread (the training thread and every prefetch worker have their own).  GMETA_EXTRACT_THREADS=1: one after the other.
+    # One helper per calling thread (the training thread and every prefetch worker have their own).  (GMETA_EXTRACT_MODE=threads; the default since is one
+    # joint build of both batches, gm_extract_pair.)
     _tls = threading.local()
 
     def _helper(self):
-        if os.environ.get('GMETA_EXTRACT_THREADS', '2') == '1':
-            return None
         h = getattr(self._tls, 'helper', None)
         dev = torch.cuda.current_device()
         if h is None or h[2] != dev:
@@ -503,7 +524,13 @@ class Subgraphs(Dataset):
             return arrs, S, Q
         off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
         seeds_s = np.concatenate([a[0] for a in arrs]); seeds_q = np.concatenate([a[1] for a in arrs])
-        helper = self._helper() if len(seeds_q) >= 64 else None           # (tiny batches: the hand-over costs more than it hides)
+        # default: ONE build for both batches (gm_extract_pair: one launch of each extraction kernel over all subgraphs, one round trip for both finalisations);
+        # GMETA_EXTRACT_MODE=threads: two gm_extract calls, the support batch on a helper thread / stream; =serial: one after the other
+        mode = os.environ.get('GMETA_EXTRACT_MODE', 'pair')
+        if mode == 'pair':
+            S, Q = SubgraphBatch.extract_pair(self.G, seeds_s, off_s, seeds_q, off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
+            return arrs, S, Q
+        helper = self._helper() if (mode == 'threads' and len(seeds_q) >= 64) else None
         if helper is None:
             S = SubgraphBatch.extract(self.G, seeds_s, off_s, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
             Q = SubgraphBatch.extract(self.G, seeds_q, off_q, self.h, self.sample_nodes, self.rng_seed, self.link_pred_mode)
@@ -534,6 +561,15 @@ class Subgraphs(Dataset):
         relabelled targets, in task order.  batches(workers > 1) runs it in the consumer's thread, in meta-batch order, so that the draws do
         not depend on which worker builds which meta-batch."""
         arrs = [self._task_arrays(i) for i in indices]
+        if self.task_setup == 'Disjoint' and len({(len(a[2]), len(a[3])) for a in arrs}) == 1:
+            # the usual case, every task of the same shape: the relabelled targets of all tasks as two tensors, one row view per task (a torch.tensor per
+            # task and side was a third of this function)
+            sy, qy = [], []
+            for a in arrs:
+                ys, yq = self._labels_lists(a[2], a[3])
+                sy.append(ys); qy.append(yq)
+            sy, qy = torch.tensor(sy, dtype=torch.int64), torch.tensor(qy, dtype=torch.int64)
+            return list(indices), arrs, list(zip(sy.unbind(0), qy.unbind(0)))
         return list(indices), arrs, [self._labels(a[2], a[3]) for a in arrs]
 
     def _build(self, prep):

@@ -90,6 +90,13 @@ void gm_store_destroy(gm_store_t* s);
 int gm_extract(const gm_store_t* store, const gm_seed_t* seeds, int32_t n_seeds,
                const int32_t* set_offsets, int32_t n_sets, int32_t h, int32_t sample_nodes,
                uint64_t rng_seed, int32_t link_pred, void* stream, gm_batch_t** out);
+/* The support AND the query batch of a meta-batch in one build (Subgraphs.__getitem__ extracts both per task, sdp.py:363-386; dgl.batch twice,
+ * sdp.py:399-406): the same two batches two gm_extract calls return -- bit for bit -- from ONE launch of the node-set kernel and ONE of the fill
+ * kernel over all subgraphs (a 32-task arxiv meta-batch: 288 + 2,304 of them) and one host round trip for both finalisations. */
+int gm_extract_pair(const gm_store_t* store, const gm_seed_t* seeds_a, int32_t n_seeds_a, const int32_t* set_offsets_a, int32_t n_sets_a,
+                    const gm_seed_t* seeds_b, int32_t n_seeds_b, const int32_t* set_offsets_b, int32_t n_sets_b,
+                    int32_t h, int32_t sample_nodes, uint64_t rng_seed, int32_t link_pred, void* stream,
+                    gm_batch_t** out_a, gm_batch_t** out_b);
 /* Same, but the node set of every subgraph is given (host, ascending, concatenated; subgraph k
  * owns nodes_flat[nodes_off[k]..nodes_off[k+1])): G.subgraph(nodes) + dgl.batch only.  Used to
  * replay node sets sampled elsewhere (e.g. by the reference's numpy RNG). */

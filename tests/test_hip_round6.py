@@ -140,23 +140,27 @@ def test_hundred_two_stream_steps_from_identical_state_are_bitwise_identical(arx
     assert bad == 0, '%d of 99 repeated steps differ from the first' % bad
 
 
-def test_helper_thread_build_is_the_one_thread_build(arxiv8):
-    """Subgraphs.get_batch builds the support batch on a helper thread / stream while the caller builds the query batch: same CSR, parents, centres and
-    relabelled targets as with GMETA_EXTRACT_THREADS=1, and a meta-step over either is bitwise the same."""
+@pytest.mark.parametrize('mode', ['serial', 'threads'])
+def test_joint_build_of_both_batches_is_the_two_separate_builds(arxiv8, mode):
+    """Subgraphs.get_batch builds the support and the query batch of a meta-batch in ONE gm_extract_pair call (one launch of each extraction kernel over all
+    subgraphs, one round trip for both finalisations): same CSRs, parents, centres, relabelled targets as two gm_extract calls -- one after the other, or
+    with the support batch on a helper thread / stream -- and a meta-step over either is bitwise the same."""
     db = arxiv8['db']
     idx = list(range(arxiv8['T'], 2 * arxiv8['T']))
     st = random.getstate()
     b2 = db.get_batch(idx)
     random.setstate(st)
-    os.environ['GMETA_EXTRACT_THREADS'] = '1'
+    os.environ['GMETA_EXTRACT_MODE'] = mode
     try:
         b1 = db.get_batch(idx)
     finally:
-        del os.environ['GMETA_EXTRACT_THREADS']
+        del os.environ['GMETA_EXTRACT_MODE']
     for side in (0, 2):
         x, y = b1[side][0].view_of, b2[side][0].view_of
-        assert (x.rows, x.edges, x.subs) == (y.rows, y.edges, y.subs)
+        assert (x.rows, x.edges, x.subs, x.sets) == (y.rows, y.edges, y.subs, y.sets)
         assert np.array_equal(x.parent(), y.parent()) and np.array_equal(x.sub_off, y.sub_off)
+        assert np.array_equal(x._read(8, x.subs * x.centres, np.int32), y._read(8, y.subs * y.centres, np.int32))
+        assert np.array_equal(x._read(9, x.rows, np.float32), y._read(9, y.rows, np.float32))
         for tr in (False, True):
             assert all(np.array_equal(p, q) for p, q in zip(x.csr(tr), y.csr(tr)))
     for slot in (1, 3, 4, 5):
@@ -164,6 +168,26 @@ def test_helper_thread_build_is_the_one_thread_build(arxiv8):
     assert b1[8] == b2[8] and b1[9] == b2[9]
     r1, r2 = _step(_meta(arxiv8), b1), _step(_meta(arxiv8), b2)
     assert np.array_equal(r1[0], r2[0]) and torch.equal(r1[1], r2[1]) and np.array_equal(r1[2], r2[2])
+
+
+@pytest.mark.parametrize('case', ['g2_shared', 'g3_linkpred', 'g1_h3'])
+def test_joint_build_on_reference_fixtures(case):
+    """gm_extract_pair on ragged multi-graph, link-prediction and h = 3 fixtures: each of the two batches equals its own gm_extract build."""
+    from hip_util import fixture_batches, make_store
+    from gmeta_amd.subgraphs import SubgraphBatch
+    fx = Fixture(case)
+    store = make_store(fx)
+    S, Q = fixture_batches(fx, store, replay=False)
+    sp, sq = fx.z['spt_seeds'], fx.z['qry_seeds']
+    T = sp.shape[0]
+    S2, Q2 = SubgraphBatch.extract_pair(store, sp.reshape(-1, 3), np.arange(T + 1) * sp.shape[1], sq.reshape(-1, 3), np.arange(T + 1) * sq.shape[1],
+                                        fx.args['h'], fx.args['sample_nodes'], 222, fx.link)
+    for x, y in ((S, S2), (Q, Q2)):
+        assert (x.rows, x.edges, x.subs, x.sets) == (y.rows, y.edges, y.subs, y.sets)
+        assert np.array_equal(x.parent(), y.parent()) and np.array_equal(x.sub_off, y.sub_off)
+        assert np.array_equal(x._read(8, x.subs * x.centres, np.int32), y._read(8, y.subs * y.centres, np.int32))
+        for tr in (False, True):
+            assert all(np.array_equal(p, q) for p, q in zip(x.csr(tr), y.csr(tr)))
 
 
 def test_builder_pool_delivers_in_order_with_the_same_label_draws(arxiv8):
@@ -179,3 +203,23 @@ def test_builder_pool_delivers_in_order_with_the_same_label_draws(arxiv8):
     for s, p in zip(seq, par):
         assert np.array_equal(s[0][0].view_of.parent(), p[0][0].view_of.parent()) and np.array_equal(s[2][0].view_of.parent(), p[2][0].view_of.parent())
         assert all(torch.equal(x, y) for x, y in zip(s[1], p[1])) and all(torch.equal(x, y) for x, y in zip(s[3], p[3]))
+
+
+@pytest.mark.parametrize('case', ['g1_sampled_h2', 'g2_shared', 'g3_linkpred', 'g1_h3'])
+def test_sixteen_bit_prefix_words_build_the_same_batches(case):
+    """The extraction kernels keep per-word prefix counts of the membership bitmap in 16 bits (four resident workgroups per CU instead of three) and, with two
+    hops, drop the BFS's `expanded` bitmap: node lists, both CSRs, centres and norms are those of the 32-bit build (GM_EXTRACT_PREF16 = 0), on sampled h = 2,
+    multi-graph, link-prediction and h = 3 fixtures (the last keeps the expanded bitmap)."""
+    from hip_util import fixture_batches, make_store
+    fx = Fixture(case)
+    store = make_store(fx)
+    out = []
+    for p16 in (1, 0):
+        with tuning(GM_EXTRACT_PREF16=p16):
+            out.append(fixture_batches(fx, store, replay=False))
+    for x, y in zip(out[0], out[1]):
+        assert (x.rows, x.edges, x.subs) == (y.rows, y.edges, y.subs)
+        assert np.array_equal(x.parent(), y.parent()) and np.array_equal(x.sub_off, y.sub_off)
+        assert np.array_equal(x._read(8, x.subs * x.centres, np.int32), y._read(8, y.subs * y.centres, np.int32))
+        for tr in (False, True):
+            assert all(np.array_equal(p, q) for p, q in zip(x.csr(tr), y.csr(tr)))
