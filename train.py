@@ -121,9 +121,11 @@ def main(args):
             chunk = order[step * args.task_num:(step + 1) * args.task_num]            # the last one may be short
             b = np.linspace(0, len(chunk), world + 1).round().astype(int)
             shards.append(chunk[int(b[rank]):int(b[rank + 1])])                       # may be empty on a short trailing batch: contributes zeros
-        # num_workers (train.py:96,173): meta-batches built ahead by that many builder threads (at most 4), delivered in order
+        # num_workers (train.py:96,173): depth of the look-ahead -- meta-batches built ahead by ONE builder thread on its own stream.  (Subgraphs.batches(workers=N) keeps
+        # N builds in flight; measured in round 6 it only helps while a build is host-latency-bound -- since the joint build of both batches it is GPU-bound and a
+        # second builder's kernels slow a short meta-step down more than they hide: profiles/r06_experiments_not_shipped.txt F)
         it = iter(db_train.batches(shards, prefetch=args.num_workers, cone_layers=args.h if getattr(args, 'cone', 0) else 0,
-                                   workers=max(1, min(int(args.num_workers), 4))))
+                                   workers=1))
         for step in range(n_steps):
             s = time.time()
             batch = next(it)            # extracted by the prefetch thread while the previous meta-step ran (num_workers > 0)
