@@ -15,7 +15,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = os.environ.get('ROCM_LLVM_BIN', '/opt/rocm/lib/llvm/bin')
-TOOLS = ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf')
+TOOLS = ('llvm-objcopy', 'clang-offload-bundler', 'llvm-readelf', 'llvm-objdump')
 CXXFILT = os.path.join(LLVM, 'llvm-cxxfilt') if os.path.exists(os.path.join(LLVM, 'llvm-cxxfilt')) else shutil.which('c++filt')
 
 
