@@ -35,6 +35,7 @@ PROTOTYPES = {
     'gm_batch_concat': (C.c_int, [vp, i32, vp, vp]),
     'gm_batch_destroy': (None, [vp]),
     'gm_batch_prepare_cone': (C.c_int, [vp, i32, vp]),
+    'gm_batch_prepare_cone_pair': (C.c_int, [vp, vp, i32, vp]),
     'gm_batch_cone_dims': (C.c_int, [vp, i32, vp, vp, vp]),
     'gm_batch_cone_read': (C.c_int, [vp, i32, i32, i32, vp, i64]),
     'gm_batch_dims': (C.c_int, [vp, vp, vp, vp, vp, vp]),

@@ -5,6 +5,7 @@
 // local ids are prefix popcounts.  Edge lists are read from HBM coalesced (wave per frontier node).
 #include <algorithm>
 #include <stdlib.h>
+#include <string.h>
 #include <mutex>
 #include <type_traits>
 #include "gm_internal.h"
@@ -813,7 +814,7 @@ struct FinalizeCtx {
     int cap = 0, first = 0;
     int32_t* d_cnt = nullptr; unsigned long long* d_counts = nullptr; int32_t* d_cdeg = nullptr;
     const int32_t* h_cnt = nullptr; const int32_t* h_heavy[2] = {nullptr, nullptr}; const int32_t* h_hdeg[2] = {nullptr, nullptr};
-    const unsigned long long* h_counts = nullptr; const int32_t* h_cdeg = nullptr;
+    const unsigned long long* h_counts = nullptr; const int32_t* h_cdeg = nullptr; const int32_t* h_centre = nullptr;
 };
 static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
 static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
@@ -879,7 +880,8 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
     for (int o = 0; o < 2; ++o) { h_heavy[o] = sg.download(b->d_heavy[o], (size_t)first); h_hdeg[o] = sg.download(b->d_heavy[o] + cap, (size_t)first); }
     const unsigned long long* h_counts = d_counts ? sg.download(d_counts, 2) : nullptr;
     const int32_t* h_cdeg = sg.download(d_cdeg, (size_t)b->n_c);
-    GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
+    fc.h_centre = sg.download(b->d_centre, (size_t)b->n_c);          // (the host side of a build reads it right after: Subgraphs._build)
+    GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && fc.h_centre && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
     tm.lap("launches");
     fc.cap = cap; fc.first = first; fc.d_cnt = d_cnt; fc.d_counts = d_counts; fc.d_cdeg = d_cdeg;
     fc.h_cnt = h_cnt; fc.h_counts = h_counts; fc.h_cdeg = h_cdeg;
@@ -894,6 +896,7 @@ static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
     const int32_t* h_heavy[2] = {fc.h_heavy[0], fc.h_heavy[1]}; const int32_t* h_hdeg[2] = {fc.h_hdeg[0], fc.h_hdeg[1]};
     gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
     if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
+    b->h_centre.assign(fc.h_centre, fc.h_centre + b->n_c);
     b->sched_win = gm_agg_window(b->rows, b->edges);
     std::vector<int32_t> heavy0, tab0;                       // forward orientation: sorted hub rows and their part table (for the list schedule below)
     for (int o = 0; o < 2; ++o) {
@@ -1289,6 +1292,7 @@ extern "C" int gm_batch_read(const gm_batch_t* b, int32_t field, void* host_dst,
     void* p; int64_t need;
     GM_TRY(field_ptr(b, field, &p, &need));
     GM_REQUIRE(bytes >= need, GM_EINVAL, "batch_read: destination holds %lld bytes, field needs %lld", (long long)bytes, (long long)need);
+    if (field == GM_F_CENTRE && (int64_t)b->h_centre.size() * 4 == need) { memcpy(host_dst, b->h_centre.data(), (size_t)need); return GM_OK; }
     GM_HIP(hipMemcpyAsync(host_dst, p, (size_t)need, hipMemcpyDeviceToHost, b->stream));
     GM_HIP(hipStreamSynchronize(b->stream));
     return GM_OK;

@@ -99,6 +99,7 @@ struct gm_batch {
     int32_t* d_indptr_t = nullptr;     // [rows+1]
     int32_t* d_indices_t = nullptr;    // [edges]
     int32_t* d_centre = nullptr;       // [subs*centres] local index
+    std::vector<int32_t> h_centre;     // host copy, brought by the finalisation's round trip (gm_batch_read serves it without another one)
     float* d_norm = nullptr;           // [rows]
     // derived launch tables (built by gm_batch_finalize)
     int32_t* d_sub_set = nullptr;      // [subs]  set of each subgraph

@@ -592,68 +592,29 @@ class Subgraphs(Dataset):
     _PREFETCH_PRIORITY = int(os.environ.get('GMETA_BUILD_PRIORITY', '0'))
 
     def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None, workers=1):
-        """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being extracted by a
-        background thread on its own HIP stream while the caller runs the meta-step on the current one -- what
+        """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being prepared (host half: one thread) and
+        extracted (a builder thread on its own HIP stream) while the caller runs the meta-step on the current one -- what
         DataLoader(num_workers>0) does for the reference (train.py:96,173), minus the per-worker copy of the memo cache
         (sdp.py:296-297,319).  cone_layers = n_gcn also builds the receptive-field tables (gm_hparams_t.cone) there.
         workers > 1: that many builder threads (each with its own stream), meta-batches delivered in order -- for schedules whose
         meta-step is shorter than one batch build (the receptive-field schedule at task_num 32: 2.2 ms against ~3 ms)."""
-        import queue
-        import threading
         index_lists = [list(int(i) for i in idx) for idx in index_lists]
         if prefetch <= 0 or len(index_lists) <= 1:
             for idx in index_lists:
                 yield self.get_batch(idx)
             return
-        if workers > 1:
-            yield from self._batches_pool(index_lists, max(prefetch, workers), cone_layers, priority, workers)
-            return
-        dev = torch.cuda.current_device()
-        q = queue.Queue(maxsize=prefetch)
-        stop = threading.Event()
-
-        def work():
-            try:
-                torch.cuda.set_device(dev)
-                side = torch.cuda.Stream(priority=self._PREFETCH_PRIORITY if priority is None else int(priority))
-                with torch.cuda.stream(side):
-                    for idx in index_lists:
-                        if stop.is_set():
-                            break
-                        b = self.get_batch(idx)
-                        if cone_layers and b[0]:        # (an empty task shard has nothing to prepare)
-                            for x in (b[0][0], b[2][0]):
-                                root = x.view_of if x.view_of is not None else x
-                                _lib.check(_lib.lib().gm_batch_prepare_cone(root.handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone')
-                        side.synchronize()
-                        q.put(('ok', b))
-                q.put(('end', None))
-            except BaseException as e:      # surface worker failures in the consumer
-                q.put(('err', e))
-        th = threading.Thread(target=work, daemon=True)
-        th.start()
-        try:
-            while True:
-                kind, val = q.get()
-                if kind == 'end':
-                    break
-                if kind == 'err':
-                    raise val
-                yield val
-        finally:
-            stop.set()
-            while th.is_alive():
-                try:
-                    q.get_nowait()
-                except queue.Empty:
-                    pass
-                th.join(timeout=0.05)
+        yield from self._batches_pool(index_lists, max(prefetch, workers), cone_layers, priority, max(1, workers))
 
     def _batches_pool(self, index_lists, depth, cone_layers, priority, workers):
+        """Three stages, meta-batches delivered in order: ONE thread runs the host halves (_prepare: task arrays, the label shuffles -- every draw of
+        the global Python RNG, in meta-batch order, whichever builder takes the batch), `workers` builder threads (own streams) run the GPU builds
+        (_build + the receptive-field tables), the caller consumes.  (Round 6: _prepare ran on the builder's thread when workers == 1 -- 0.3 ms of the
+        3.4 ms a builder needs per 32-task arxiv meta-batch with tables, the stage the receptive-field schedule waits for.)"""
         dev = torch.cuda.current_device()
         tls = threading.local()
 
-        def job(prep):
+        def job(prep_f):
+            prep = prep_f.result()
             if not prep[0]:
                 return tuple([] for _ in range(10))
             side = getattr(tls, 'side', None)
@@ -663,27 +624,37 @@ class Subgraphs(Dataset):
             with torch.cuda.stream(side):
                 b = self._build(prep)
                 if cone_layers:
-                    for x in (b[0][0], b[2][0]):
-                        root = x.view_of if x.view_of is not None else x
-                        _lib.check(_lib.lib().gm_batch_prepare_cone(root.handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone')
+                    tables(b)
                 side.synchronize()
             return b
+
+        def tables(b):
+            roots = [x.view_of if x.view_of is not None else x for x in (b[0][0], b[2][0])]
+            _lib.check(_lib.lib().gm_batch_prepare_cone_pair(roots[0].handle, roots[1].handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone_pair')
+
+        host = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='gmeta-prepare')
         pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix='gmeta-batches')
         pending = collections.deque()
         it = iter(index_lists)
+
+        def top_up():
+            while len(pending) < depth:
+                idx = next(it, None)
+                if idx is None:
+                    return
+                pending.append(pool.submit(job, host.submit(self._prepare, idx) if idx else host.submit(lambda: ([], [], []))))
         try:
             while True:
-                while len(pending) < depth:
-                    idx = next(it, None)
-                    if idx is None:
-                        break
-                    pending.append(pool.submit(job, self._prepare(idx) if idx else ([], [], [])))      # RNG draws here, in meta-batch order
+                top_up()
                 if not pending:
                     break
-                yield pending.popleft().result()
+                f = pending.popleft()
+                top_up()                    # `depth` builds queued or running while the caller works on this one
+                yield f.result()
         finally:
             for f in pending:
                 f.cancel()
+            host.shutdown(wait=True, cancel_futures=True)
             pool.shutdown(wait=True)
 
     def __len__(self):

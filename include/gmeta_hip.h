@@ -111,6 +111,9 @@ int gm_batch_concat(const gm_batch_t* const* parts, int32_t n_parts, void* strea
  * cannot use the schedule.  gm_batch_cone_read copies one table to the host (tests): what = 0 rows,
  * 1 indptr, 2 indices, 3 indptr_t, 4 indices_t, 5 set offsets. */
 int gm_batch_prepare_cone(const gm_batch_t* b, int32_t n_gcn, void* stream);
+/* The same for the two batches of a meta-batch (support, query) with ONE pair of host round trips for both
+ * (the builder thread of Subgraphs.batches calls this; results identical to two gm_batch_prepare_cone calls). */
+int gm_batch_prepare_cone_pair(const gm_batch_t* a, const gm_batch_t* b, int32_t n_gcn, void* stream);
 int gm_batch_cone_dims(const gm_batch_t* b, int32_t n_gcn, int32_t* ok, int64_t* level_rows, int64_t* level_edges);
 int gm_batch_cone_read(const gm_batch_t* b, int32_t n_gcn, int32_t level, int32_t what, void* host, int64_t host_bytes);
 void gm_batch_destroy(gm_batch_t* b);

@@ -192,17 +192,62 @@ def test_joint_build_on_reference_fixtures(case):
 
 def test_builder_pool_delivers_in_order_with_the_same_label_draws(arxiv8):
     """Subgraphs.batches(workers=3): meta-batches arrive in list order, and the Disjoint relabelling (a global-RNG shuffle per task, sdp.py:390-397) draws
-    exactly what the sequential get_batch loop draws -- the draws happen in the consumer's thread, in order."""
+    exactly what the sequential get_batch loop draws -- the draws happen on ONE host thread, in meta-batch order, whichever builder takes the batch."""
     db, T = arxiv8['db'], arxiv8['T']
     lists = [list(range(k * T, (k + 1) * T)) for k in range(3)] + [list(range(0, 3))]
     st = random.getstate()
     seq = [db.get_batch(i) for i in lists]
     random.setstate(st)
-    par = list(db.batches(lists, prefetch=2, workers=3, cone_layers=2))
-    assert len(par) == len(seq)
-    for s, p in zip(seq, par):
-        assert np.array_equal(s[0][0].view_of.parent(), p[0][0].view_of.parent()) and np.array_equal(s[2][0].view_of.parent(), p[2][0].view_of.parent())
-        assert all(torch.equal(x, y) for x, y in zip(s[1], p[1])) and all(torch.equal(x, y) for x, y in zip(s[3], p[3]))
+    for kw in (dict(prefetch=2, workers=3, cone_layers=2), dict(prefetch=1, workers=1), dict(prefetch=2, workers=1, cone_layers=2)):
+        random.setstate(st)
+        par = list(db.batches(lists, **kw))
+        assert len(par) == len(seq)
+        for s, p in zip(seq, par):
+            assert np.array_equal(s[0][0].view_of.parent(), p[0][0].view_of.parent()) and np.array_equal(s[2][0].view_of.parent(), p[2][0].view_of.parent())
+            assert all(torch.equal(x, y) for x, y in zip(s[1], p[1])) and all(torch.equal(x, y) for x, y in zip(s[3], p[3]))
+            assert all(torch.equal(x, y) for x, y in zip(s[4], p[4])) and all(torch.equal(x, y) for x, y in zip(s[5], p[5]))       # centre tables (host copy of the build's round trip)
+
+
+def _cone_tables(lib, b, L):
+    from gmeta_amd import _lib
+    ok = C.c_int32(); nrows = (C.c_int64 * (L + 1))(); nedges = (C.c_int64 * (L + 1))()
+    _lib.check(lib.gm_batch_cone_dims(b.handle, L, C.byref(ok), nrows, nedges), 'cone_dims')
+    out = [ok.value, list(nrows), list(nedges)]
+    if not ok.value:
+        return out
+    for l in range(L + 1):
+        n_lo = nrows[l - 1] if l else 0
+        for what, n in ((0, nrows[l]), (1, nrows[l] + 1 if l else 0), (2, nedges[l] if l else 0), (3, n_lo + 1 if l else 0), (4, nedges[l] if l else 0), (5, b.sets + 1)):
+            a = np.empty(max(int(n), 0), np.int32)
+            if a.size:
+                _lib.check(lib.gm_batch_cone_read(b.handle, L, l, what, a.ctypes.data, a.nbytes), 'cone_read')
+            out.append(a)
+    return out
+
+
+def test_receptive_field_tables_of_both_batches_in_one_call(arxiv8):
+    """gm_batch_prepare_cone_pair (one pair of host round trips for the support AND the query batch) builds the tables of two gm_batch_prepare_cone
+    calls, and a step over them is bitwise the step over those."""
+    import gmeta_amd
+    from gmeta_amd import _lib
+    lib = _lib.lib()
+    db, T, L = arxiv8['db'], arxiv8['T'], arxiv8['cfg']['h']
+    st = random.getstate()
+    one = db.get_batch(list(range(T)))
+    random.setstate(st)
+    two = db.get_batch(list(range(T)))
+    for x in (one[0][0].view_of, one[2][0].view_of):
+        _lib.check(lib.gm_batch_prepare_cone(x.handle, L, _lib.stream_ptr()), 'prepare_cone')
+    _lib.check(lib.gm_batch_prepare_cone_pair(two[0][0].view_of.handle, two[2][0].view_of.handle, L, _lib.stream_ptr()), 'prepare_cone_pair')
+    _lib.check(lib.gm_batch_prepare_cone_pair(two[0][0].view_of.handle, two[2][0].view_of.handle, L, _lib.stream_ptr()), 'prepare_cone_pair')      # cached: a no-op
+    for k in (0, 2):
+        ta, tb = _cone_tables(lib, one[k][0].view_of, L), _cone_tables(lib, two[k][0].view_of, L)
+        assert ta[:3] == tb[:3] and ta[0] == 1
+        assert all(np.array_equal(x, y) for x, y in zip(ta[3:], tb[3:]))
+    a1, g1, l1 = _step(_meta(arxiv8, cone=1), one)
+    a2, g2, l2 = _step(_meta(arxiv8, cone=1), two)
+    assert np.array_equal(a1, a2) and torch.equal(g1, g2) and np.array_equal(l1, l2)
+    assert lib.gm_batch_prepare_cone_pair(one[0][0].view_of.handle, one[0][0].view_of.handle, L, None) != 0      # two distinct batches
 
 
 @pytest.mark.parametrize('case', ['g1_sampled_h2', 'g2_shared', 'g3_linkpred', 'g1_h3'])
