@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdlib.h>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -33,11 +34,27 @@ static void pool_keep_memory() {
         (void)hipGetLastError();
 }
 
+// Slab sizes are rounded up to eight steps per octave: the slabs of a meta-batch follow its row / edge counts, which differ by a percent from one
+// meta-batch to the next; quantised sizes repeat.
+static size_t pool_size_class(size_t bytes) {
+    if (bytes < ((size_t)1 << 20)) return bytes;
+    size_t step = (size_t)1 << 17;                       // 1 MiB / 8
+    while ((step << 4) <= bytes) step <<= 1;             // step = 2^(floor(log2 bytes) - 3)
+    return (bytes + step - 1) / step * step;
+}
+
 int gm_dev_alloc(void** p, size_t bytes, hipStream_t s) {
     *p = nullptr;
     pool_keep_memory();
+    const bool timing = gm_knob().timing != 0;
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMallocAsync(p, bytes, s);
+    if (timing) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us > 50.0) fprintf(stderr, "[gm timing] hipMallocAsync(%zu MB) %.1f us\n", bytes >> 20, us);
+    }
     if (e != hipSuccess) {
+        if (gm_knob().timing) fprintf(stderr, "[gm timing] hipMallocAsync(%zu) failed: %s -- hipMalloc\n", bytes, hipGetErrorString(e));
         (void)hipGetLastError();
         e = hipMalloc(p, bytes);
     }
@@ -51,8 +68,77 @@ int gm_dev_alloc(void** p, size_t bytes, hipStream_t s) {
 void gm_dev_free(void* p, hipStream_t s) {
     if (!p) return;
     if (hipFreeAsync(p, s) != hipSuccess) {
+        if (gm_knob().timing) fprintf(stderr, "[gm timing] hipFreeAsync failed -- hipFree\n");
         (void)hipGetLastError();
         (void)hipFree(p);
+    }
+}
+
+// ---------------------------------------------------------------- slab cache
+// The big allocations of a batch (gm_batch::slabs, the scratch of a receptive-field build) do not go back to HIP's stream-ordered pool when a batch is
+// dropped.  With the release threshold raised the pool still hands ONE block of every build / drop cycle back to the OS inside hipFreeAsync and maps
+// a new one in the next build: 0.7 - 1.7 ms of host time per meta-batch at the arxiv shape, in whichever thread dropped the batch (ROCm 7.2; found
+// with GM_TIMING and tools/build_prof.py, reproduced in isolation by tools/pool_free_probe.py) -- the training thread's own loop, where a receptive-
+// field meta-step takes 2.2 ms.  A released slab carries an event recorded on the releasing stream (behind the batch's consumers: batch_free);
+// whoever takes it next waits for that event on ITS stream: the ordering the pool would give, without the unmapping.  The cache holds at most
+// GM_SLAB_CACHE_MB (default 4096) per process; what it holds at exit is left to the driver (a static destructor would run after HIP's teardown).
+struct SlabEntry { char* base; size_t cap; hipEvent_t ready; int dev; };
+static std::mutex g_slab_mu;
+static std::vector<SlabEntry> g_slab_cache;
+static size_t g_slab_cached = 0;
+
+int gm_slab_acquire(char** base, size_t* cap, size_t need, hipStream_t s) {
+    need = pool_size_class(std::max<size_t>(need, 256));
+    int dev = 0;
+    GM_HIP(hipGetDevice(&dev));
+    SlabEntry hit{nullptr, 0, nullptr, 0};
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mu);
+        int best = -1;
+        for (size_t k = 0; k < g_slab_cache.size(); ++k) {
+            const SlabEntry& e = g_slab_cache[k];
+            if (e.dev == dev && e.cap >= need && e.cap <= need + need / 4 && (best < 0 || e.cap < g_slab_cache[best].cap)) best = (int)k;
+        }
+        if (best >= 0) { hit = g_slab_cache[best]; g_slab_cache.erase(g_slab_cache.begin() + best); g_slab_cached -= hit.cap; }
+    }
+    if (hit.base) {
+        const hipError_t e = hipStreamWaitEvent(s, hit.ready, 0);
+        if (e != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(hit.ready); }
+        (void)hipEventDestroy(hit.ready);
+        *base = hit.base; *cap = hit.cap;
+        return GM_OK;
+    }
+    GM_TRY(gm_dev_alloc((void**)base, need, s));
+    *cap = need;
+    return GM_OK;
+}
+
+void gm_slab_release(char* base, size_t cap, hipStream_t s) {
+    if (!base) return;
+    static const size_t limit = (size_t)(getenv("GM_SLAB_CACHE_MB") ? std::max(0, atoi(getenv("GM_SLAB_CACHE_MB"))) : 4096) << 20;
+    hipEvent_t ev = nullptr;
+    int dev = 0;
+    if (cap > limit || hipGetDevice(&dev) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, s) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ev) (void)hipEventDestroy(ev);
+        gm_dev_free(base, s);
+        return;
+    }
+    std::vector<SlabEntry> evict;
+    {
+        std::lock_guard<std::mutex> lk(g_slab_mu);
+        g_slab_cache.push_back(SlabEntry{base, cap, ev, dev});
+        g_slab_cached += cap;
+        while (g_slab_cached > limit || g_slab_cache.size() > 256) {        // oldest first
+            evict.push_back(g_slab_cache.front());
+            g_slab_cached -= g_slab_cache.front().cap;
+            g_slab_cache.erase(g_slab_cache.begin());
+        }
+    }
+    for (const SlabEntry& e : evict) {
+        if (hipStreamWaitEvent(s, e.ready, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(e.ready); }
+        (void)hipEventDestroy(e.ready);
+        gm_dev_free(e.base, s);
     }
 }
 

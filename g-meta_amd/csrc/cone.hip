@@ -158,33 +158,33 @@ __global__ __launch_bounds__(SCAN_T) void k_level_rows(const int32_t* flags, int
     if (bid == (int)gridDim.x - 1 && threadIdx.x == SCAN_T - 1) *total = run;
 }
 // forward CSR of the upper level: every in-edge of an upper row, sources renamed to compact ids of the lower level
+// ... and the out-degree of every lower row into the upper level (integer atomics: the counts do not depend on their order), which sizes the backward CSR
 __global__ __launch_bounds__(256) void k_fill_in(const int32_t* up_row, const int32_t* n_ptr, const int32_t* indptr, const int32_t* indices, const int32_t* pos_lo,
-                                                 const int32_t* cptr, int32_t* cidx) {
+                                                 const int32_t* cptr, int32_t* cidx, int32_t* deg_t) {
     const int q = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (q >= *n_ptr) return;
     const int r = up_row[q], e0 = indptr[r], n = indptr[r + 1] - e0, o = cptr[q];
-    for (int j = lane; j < n; j += 64) cidx[o + j] = pos_lo[indices[e0 + j]];
+    for (int j = lane; j < n; j += 64) { const int u = pos_lo[indices[e0 + j]]; cidx[o + j] = u; atomicAdd(&deg_t[u], 1); }
 }
-// backward CSR: out-edges of a lower-level row that end in the upper level, in the batch's by-source order.
-// pass 0 counts, pass 1 fills (order preserved with a ballot prefix: deterministic).
-__global__ __launch_bounds__(256) void k_out_edges(const int32_t* lo_row, const int32_t* n_ptr, int bound, const int32_t* indptr_t, const int32_t* indices_t, const int32_t* pos_up,
-                                                   int32_t* cnt, const int32_t* tptr, int32_t* tidx) {
+// backward CSR: out-edges of a lower-level row that end in the upper level, in the batch's by-source order (order preserved with a ballot prefix:
+// deterministic); the row bounds tptr come from the scan of k_fill_in's counts.
+__global__ __launch_bounds__(256) void k_out_edges(const int32_t* lo_row, const int32_t* n_ptr, const int32_t* indptr_t, const int32_t* indices_t, const int32_t* pos_up,
+                                                   const int32_t* tptr, int32_t* tidx) {
     // eight lanes per lower-level row, eight rows per wave (round 6: a whole wave per row before -- 940 k waves for the ~2 out-edges of a level-0 row of the
-    // arxiv query batch, 59 us a launch, eight launches per meta-batch)
+    // arxiv query batch, 59 us a launch)
     const int lane = threadIdx.x & 63, grp = lane >> 3, gl = lane & 7;
     const int p = blockIdx.x * 32 + (threadIdx.x >> 3);
     const bool have = p < *n_ptr;
     int e0 = 0, e1 = 0;
     if (have) { const int u = lo_row[p]; e0 = indptr_t[u]; e1 = indptr_t[u + 1]; }
-    int base = (have && tidx) ? tptr[p] : 0;
+    int base = have ? tptr[p] : 0;
     for (int eb = e0; __any(eb < e1); eb += 8) {
         const int e = eb + gl;
         const int q = e < e1 ? pos_up[indices_t[e]] : -1;
         const unsigned m = (unsigned)(__ballot(q >= 0) >> (grp * 8)) & 0xffu;
-        if (tidx && q >= 0) tidx[base + __popc(m & ((1u << gl) - 1u))] = q;
+        if (q >= 0) tidx[base + __popc(m & ((1u << gl) - 1u))] = q;
         base += __popc(m);
     }
-    if (!tidx && gl == 0 && p < bound) cnt[p] = have ? base : 0;      // (zeros up to the bound: the scan that follows runs over it)
 }
 // hub rows of a compact CSR (in-degree above thr, r < *n_ptr), ascending, by one chained compaction; *total = their number (the list keeps the first `cap`)
 __global__ __launch_bounds__(SCAN_T) void k_heavy_rows(const int32_t* indptr, const int32_t* n_ptr, int thr, int cap, int32_t* list, int32_t* total, ScanChain c) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(SCAN_T) void k_heavy_rows(const int32_t* indptr, co
 // ------------------------------------------------------------------------------------------ host
 void gm_cone_free(gm_cone* c, hipStream_t s) {
     if (!c) return;
-    gm_dev_free(c->slab, s);        // every level array lives in it
+    (void)s;                        // (the level arrays live in the batch's slabs: batch_free releases them)
     delete c;
 }
 
@@ -253,11 +253,11 @@ struct ConeBuild {
     const gm_batch* b; int L; hipStream_t s; gm_cone* c;
     int64_t Bn[GM_MAX_GCN + 1], Be[GM_MAX_GCN + 1];               // row bound of level l; bound of the edges from level l - 1 into level l
     int32_t* d_tab[GM_MAX_GCN + 1] = {}; size_t tab_cap[GM_MAX_GCN + 1] = {};      // per level: set offsets | chunk offsets | tiles | chunks (level_tables)
-    void* tmp = nullptr;                                          // scratch of the build: position maps, flags, degree / count arrays, scan status words, the device-side counts
+    char* tmp = nullptr; size_t tmp_cap = 0;                      // scratch of the build: position maps, flags, degree / count arrays, scan status words, the device-side counts
     gm_stager sg;
     const int32_t* h_cnt = nullptr;                               // the download: counts, then the lower levels' set offsets
     ConeBuild(const gm_batch* b_, int L_, hipStream_t s_, gm_cone* c_) : b(b_), L(L_), s(s_), c(c_), sg(s_) {}
-    ~ConeBuild() { gm_dev_free(tmp, s); }                         // (stream-ordered, behind the kernels that used it, on every way out)
+    ~ConeBuild() { gm_slab_release(tmp, tmp_cap, s); }            // (behind the kernels that used it, on every way out)
     ConeBuild(const ConeBuild&) = delete;
     ConeBuild& operator=(const ConeBuild&) = delete;
     size_t hcap(int64_t e) const { return (size_t)(e / c->heavy_deg + 1); }
@@ -290,19 +290,20 @@ int ConeBuild::launch() {
             }
         }
     };
-    { ConeCarver size(nullptr); carve(size); GM_TRY(gm_dev_alloc(&c->slab, size.used + 256, s)); }
+    // (from the batch's slabs -- gm_balloc_bytes leaves room for a two-layer build in the first one -- and released with them)
+    { ConeCarver size(nullptr); carve(size); GM_TRY(gm_balloc_bytes(const_cast<gm_batch*>(b), &c->slab, size.used + 256, s)); }
     { ConeCarver cv(c->slab); carve(cv); }
     const int64_t maxb = std::max<int64_t>(rows, 1);
     const size_t n_st = (size_t)(maxb / SCAN_B + 2), n_ticket = 8 * (GM_MAX_GCN + 1) + 8, n_soff = (size_t)L * (sets + 1);
     ConeCarver ts(nullptr);
-    int32_t *posA, *posB, *flags, *deg, *cnts, *ticket; unsigned long long* st;
+    int32_t *posA, *posB, *flags, *deg, *deg_t, *cnts, *ticket; unsigned long long* st;
     auto carve_tmp = [&](ConeCarver& cv) {
         // zeroed by one memset: [status words | tickets | counts + set-offset copies]; counts + copies come down in one download
         st = cv.take<unsigned long long>(n_st); ticket = cv.take<int32_t>(n_ticket); cnts = cv.take<int32_t>(cnt_ints() + n_soff);
-        posA = cv.take<int32_t>(maxb); posB = cv.take<int32_t>(maxb); flags = cv.take<int32_t>(maxb); deg = cv.take<int32_t>(maxb + 1);
+        posA = cv.take<int32_t>(maxb); posB = cv.take<int32_t>(maxb); flags = cv.take<int32_t>(maxb); deg_t = cv.take<int32_t>(maxb + 1); deg = cv.take<int32_t>(maxb + 1);
     };
     carve_tmp(ts);
-    GM_TRY(gm_dev_alloc(&tmp, ts.used + 256, s));
+    GM_TRY(gm_slab_acquire(&tmp, &tmp_cap, ts.used + 256, s));
     { ConeCarver cv(tmp); carve_tmp(cv); }
     const size_t zero_bytes = (size_t)((char*)posA - (char*)st);
     // device-side counts, per level l: [0] n, [1] nnz (edges into l, by destination), [2] the same counted by source, [3] / [4] hub rows; cnts[8 L + 5] = bad
@@ -320,22 +321,21 @@ int ConeBuild::launch() {
     hipLaunchKernelGGL(k_fill_i32, dim3(fill_blocks), dim3(256), 0, s, posA, rows, -1);
     hipLaunchKernelGGL(k_scatter_pos, dim3((top.n + 255) / 256 + 1), dim3(256), 0, s, top.d_row, top.n, posA, cnt(L, 0));
     if (top.n > 0) hipLaunchKernelGGL(k_check_pos, dim3((top.n + 255) / 256), dim3(256), 0, s, top.d_row, top.n, posA, cnt(L, 5));
-    // ---- levels L-1 .. 0: eleven launches each
+    // ---- levels L-1 .. 0: ten launches each
     for (int l = L - 1; l >= 0; --l) {
         gm_cone_level& up = c->lv[l + 1]; gm_cone_level& lo = c->lv[l];
         const int bu = (int)std::max<int64_t>(Bn[l + 1], 1), bl = (int)std::max<int64_t>(Bn[l], 1);
         const int row_blocks = (int)std::max<int64_t>(1, (rows + SCAN_B - 1) / SCAN_B);
-        GM_HIP(hipMemsetAsync(flags, 0, 4 * (size_t)rows, s));
+        GM_HIP(hipMemsetAsync(flags, 0, (size_t)((char*)deg - (char*)flags), s));           // flags and deg_t (adjacent)
         hipLaunchKernelGGL(k_mark, dim3((bu + 3) / 4), dim3(256), 0, s, up.d_row, cnt(l + 1, 0), bu, b->d_indptr, b->d_indices, flags, deg);
         ++chain.gen;                                                                           // the level's rows (ascending), row -> compact id, its size
         hipLaunchKernelGGL(k_level_rows, dim3(row_blocks), dim3(SCAN_T), 0, s, flags, posB, (int)rows, b->d_norm, b->d_feat_row, lo.d_row, lo.d_norm, lo.d_feat_row, cnt(l, 0), chain);
         hipLaunchKernelGGL(k_set_off, dim3((sets + 256) / 256), dim3(256), 0, s, lo.d_row, cnt(l, 0), b->d_set_row_off, sets, rows, lo.d_set_off, soff_copy + (size_t)l * (sets + 1));
         dev_scan(deg, up.d_indptr, bu, 1, cnt(l + 1, 1), chain, s);                            // forward CSR bounds of level l + 1; nnz
         // forward CSR (by destination) and backward CSR (by source)
-        hipLaunchKernelGGL(k_fill_in, dim3((bu + 3) / 4), dim3(256), 0, s, up.d_row, cnt(l + 1, 0), b->d_indptr, b->d_indices, posB, up.d_indptr, up.d_indices);
-        hipLaunchKernelGGL(k_out_edges, dim3((bl + 31) / 32), dim3(256), 0, s, lo.d_row, cnt(l, 0), bl, b->d_indptr_t, b->d_indices_t, posA, deg, (const int32_t*)nullptr, (int32_t*)nullptr);
-        dev_scan(deg, up.d_indptr_t, bl, 1, cnt(l + 1, 2), chain, s);
-        hipLaunchKernelGGL(k_out_edges, dim3((bl + 31) / 32), dim3(256), 0, s, lo.d_row, cnt(l, 0), bl, b->d_indptr_t, b->d_indices_t, posA, (int32_t*)nullptr, up.d_indptr_t, up.d_indices_t);
+        hipLaunchKernelGGL(k_fill_in, dim3((bu + 3) / 4), dim3(256), 0, s, up.d_row, cnt(l + 1, 0), b->d_indptr, b->d_indices, posB, up.d_indptr, up.d_indices, deg_t);
+        dev_scan(deg_t, up.d_indptr_t, bl, 1, cnt(l + 1, 2), chain, s);
+        hipLaunchKernelGGL(k_out_edges, dim3((bl + 31) / 32), dim3(256), 0, s, lo.d_row, cnt(l, 0), b->d_indptr_t, b->d_indices_t, posA, up.d_indptr_t, up.d_indices_t);
         // hub rows of both CSRs, ascending
         for (int o = 0; o < 2; ++o) {
             const int bound = o ? bl : bu;

@@ -4,6 +4,7 @@
 // over the parent graph's nodes, so the node list comes out in ascending order for free and
 // local ids are prefix popcounts.  Edge lists are read from HBM coalesced (wave per frontier node).
 #include <algorithm>
+#include <initializer_list>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -552,12 +553,14 @@ __global__ void k_edge_tables(const int32_t* indices, const int32_t* indices_t, 
 // row / edge counts (gm_batch::d_fuse2 / d_fuse2_feat, unfused_rows / unfused_edges), and the keep-flag row scale gm_batch::d_norm_c with the sign bit set on
 // every row (k_centre_rows clears it on the centre rows afterwards).  Hub rows: in-degree (o = 0) / out-degree (o = 1) above `thr`.
 __global__ void k_row_tables(const int32_t* indptr, const int32_t* indices, const int32_t* indptr_t, int64_t rows, const float* norm, const int32_t* feat_row,
-                             int4* f2, int4* f2_feat, unsigned long long* counts, int32_t* heavy0, int32_t* heavy1, int32_t* hcnt, int cap, int thr, float* norm_c) {
+                             int4* f2, int4* f2_feat, unsigned long long* counts, int32_t* heavy0, int32_t* heavy1, int32_t* hcnt, int cap, int thr, float* norm_c,
+                             int2* first0, int2* first1, int n_first) {
     unsigned long long nr = 0, ne = 0;
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
         const int p = indptr[r], d = indptr[r + 1] - p, dt = indptr_t[r + 1] - indptr_t[r];
-        if (d > thr) { const int k = atomicAdd(hcnt, 1); if (k < cap) { heavy0[k] = (int32_t)r; heavy0[cap + k] = d; } }         // [rows: cap][degrees: cap]
-        if (dt > thr) { const int k = atomicAdd(hcnt + 1, 1); if (k < cap) { heavy1[k] = (int32_t)r; heavy1[cap + k] = dt; } }
+        // [rows: cap][degrees: cap]; the first n_first (row, degree) pairs also go to the round trip's scratch (one download for everything the host waits for)
+        if (d > thr) { const int k = atomicAdd(hcnt, 1); if (k < cap) { heavy0[k] = (int32_t)r; heavy0[cap + k] = d; } if (k < n_first) first0[k] = make_int2((int)r, d); }
+        if (dt > thr) { const int k = atomicAdd(hcnt + 1, 1); if (k < cap) { heavy1[k] = (int32_t)r; heavy1[cap + k] = dt; } if (k < n_first) first1[k] = make_int2((int)r, dt); }
         const float nrm = norm[r];
         norm_c[r] = __uint_as_float(__float_as_uint(nrm) | 0x80000000u);
         const int self = (int)r | GM_FUSE_SELF;
@@ -658,10 +661,11 @@ __global__ __launch_bounds__(MID_BLOCK) void k_mid_scatter(const int32_t* indptr
 // centre rows, their norms and in-degrees (row-sparse backward tables)
 // (norm_c != NULL: also clears the keep-flag scale's sign bit on the centre rows -- after k_row_tables set it on every row)
 __global__ void k_centre_rows(const int32_t* sub_off, const int32_t* centre, int nc, int n_c, const int32_t* indptr, const float* norm,
-                              int32_t* crow, float* cnorm, int32_t* cdeg, float* norm_c) {
+                              int32_t* crow, float* cnorm, int32_t* cdeg, float* norm_c, int32_t* centre_copy) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_c) return;
     const int row = sub_off[k / nc] + centre[k];
+    centre_copy[k] = centre[k];
     crow[k] = row; cnorm[k] = norm[row]; cdeg[k] = indptr[row + 1] - indptr[row];
     if (norm_c) norm_c[row] = __uint_as_float(__float_as_uint(norm[row]) & 0x7fffffffu);
 }
@@ -736,12 +740,13 @@ int gm_batch_hub_alt(const gm_batch* cb, hipStream_t s) {
 }
 
 int gm_balloc_bytes(gm_batch* b, void** p, size_t bytes, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(b->slab_mu);          // (lazily built tables -- receptive-field levels, stream tables, gains -- may come from another thread than the build's)
     bytes = (bytes + 255) / 256 * 256;
     if (b->slabs.empty() || b->slabs.back().cap - b->slabs.back().used < bytes) {
         // slab size: what the big arrays of this batch will need in total when the sizes are known (rows / edges), else 8 MiB steps
-        const size_t guess = (size_t)b->rows * 64 + (size_t)b->edges * 24 + ((size_t)1 << 20);
-        gm_batch::slab sl{nullptr, std::max(bytes, b->slabs.empty() ? guess : std::max<size_t>(guess / 4, (size_t)8 << 20)), 0};
-        GM_TRY(gm_dev_alloc((void**)&sl.base, sl.cap, s));
+        const size_t guess = (size_t)b->rows * 74 + (size_t)b->edges * 27 + ((size_t)2 << 20) + (size_t)b->rows * 20 + (size_t)b->edges * 8;
+        gm_batch::slab sl{nullptr, 0, 0};
+        GM_TRY(gm_slab_acquire(&sl.base, &sl.cap, std::max(bytes, b->slabs.empty() ? guess : std::max<size_t>(guess / 4, (size_t)8 << 20)), s));
         b->slabs.push_back(sl);
     }
     gm_batch::slab& sl = b->slabs.back();
@@ -750,15 +755,22 @@ int gm_balloc_bytes(gm_batch* b, void** p, size_t bytes, hipStream_t s) {
 }
 
 static void batch_free(gm_batch* b) {
+    gm_phase_timer tm("batch-free");
     hipStream_t s = b->stream;
     for (int o = 0; o < 4; ++o) if (b->hub_ev[o]) { (void)hipEventDestroy(b->hub_ev[o]); b->hub_ev[o] = nullptr; }
     if (b->used_ev) {
         if (hipStreamWaitEvent(s, b->used_ev, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipEventSynchronize(b->used_ev); }
         (void)hipEventDestroy(b->used_ev); b->used_ev = nullptr;
     }
-    for (auto& sl : b->slabs) gm_dev_free(sl.base, s);       // every array of the batch lives in these (gm_balloc)
+    tm.lap("events");
+    for (auto& sl : b->slabs) {      // every array of the batch lives in these (gm_balloc)
+        gm_slab_release(sl.base, sl.cap, s);
+        if (gm_knob().timing) { char nm[64]; snprintf(nm, sizeof nm, "slab %zu MB (%zu used)", sl.cap >> 20, sl.used >> 20); tm.lap(nm); }
+    }
     b->slabs.clear();
+    tm.lap("slabs");
     for (int l = 0; l <= GM_MAX_GCN; ++l) { gm_cone_free(b->cone[l], s); b->cone[l] = nullptr; }
+    tm.lap("cones");
 }
 
 // Launch tables derived from the set layout: GEMM row tiles never straddle two sets (each set has its own
@@ -812,9 +824,13 @@ static void sort_rows_with_degrees(std::vector<int32_t>& row, std::vector<int32_
 // waits once, and derives both batches' host-side tables while nothing is left to wait for.
 struct FinalizeCtx {
     int cap = 0, first = 0;
-    int32_t* d_cnt = nullptr; unsigned long long* d_counts = nullptr; int32_t* d_cdeg = nullptr;
-    const int32_t* h_cnt = nullptr; const int32_t* h_heavy[2] = {nullptr, nullptr}; const int32_t* h_hdeg[2] = {nullptr, nullptr};
+    char* scratch = nullptr; hipStream_t s = nullptr;            // device side of the round trip (finalize_launch); released by finalize_finish or on the way out
+    const int32_t* h_cnt = nullptr; const int32_t* h_first[2] = {nullptr, nullptr};      // hub-row counts; the first (row, degree) pairs of both hub lists
     const unsigned long long* h_counts = nullptr; const int32_t* h_cdeg = nullptr; const int32_t* h_centre = nullptr;
+    FinalizeCtx() = default;
+    FinalizeCtx(const FinalizeCtx&) = delete;
+    FinalizeCtx& operator=(const FinalizeCtx&) = delete;
+    ~FinalizeCtx() { if (scratch) gm_dev_free(scratch, s); }
 };
 static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
 static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc);
@@ -823,6 +839,20 @@ int gm_batch_finalize(gm_batch* b, hipStream_t s, gm_stager& sg) {
     GM_TRY(finalize_launch(b, s, sg, fc));
     GM_HIP(hipStreamSynchronize(s));
     return finalize_finish(b, s, sg, fc);
+}
+// several small host tables into ONE region of the batch's slabs (batch_free releases nothing else) with ONE copy through pinned staging; each part
+// starts on a 256-byte boundary.  (One hipMemcpyAsync per table before: ~20 of the ~43 copies of a meta-batch build.)
+struct TabPart { int32_t** d; const std::vector<int32_t>* v; };
+static int upload_tables(gm_batch* b, gm_stager& sg, hipStream_t s, std::initializer_list<TabPart> parts) {
+    auto pad = [](size_t n) { return (std::max<size_t>(n, 1) + 63) / 64 * 64; };
+    size_t tot = 0;
+    for (const TabPart& p : parts) tot += pad(p.v->size());
+    int32_t* base = nullptr;
+    GM_TRY(gm_balloc(b, &base, tot, s));
+    std::vector<int32_t> h(tot, 0);
+    size_t o = 0;
+    for (const TabPart& p : parts) { std::copy(p.v->begin(), p.v->end(), h.begin() + o); *p.d = base + o; o += pad(p.v->size()); }
+    return sg.upload(base, h);
 }
 static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc) {
     gm_phase_timer tm("finalize-launch");
@@ -837,18 +867,25 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
         set_chunk_off[t + 1] = (int32_t)(chunks.size() / 3);
     }
     b->n_tiles = (int32_t)(tiles.size() / 3); b->n_chunks = (int32_t)(chunks.size() / 3);
-    GM_TRY(gm_balloc(b, &b->d_sub_set, sub_set.size(), s)); GM_TRY(gm_balloc(b, &b->d_tiles, tiles.size(), s));
-    GM_TRY(gm_balloc(b, &b->d_chunks, chunks.size(), s)); GM_TRY(gm_balloc(b, &b->d_set_chunk_off, set_chunk_off.size(), s));
-    GM_TRY(sg.upload(b->d_sub_set, sub_set)); GM_TRY(sg.upload(b->d_tiles, tiles)); GM_TRY(sg.upload(b->d_chunks, chunks));
-    GM_TRY(sg.upload(b->d_set_chunk_off, set_chunk_off));
+    GM_TRY(upload_tables(b, sg, s, {{&b->d_sub_set, &sub_set}, {&b->d_tiles, &tiles}, {&b->d_chunks, &chunks}, {&b->d_set_chunk_off, &set_chunk_off}}));
     tm.lap("tables");
     // ---- device side, nothing here waits for the host: hub-row lists of both orientations, per-edge tables, the fused launch's row table +
     // counts, centre rows with their in-degrees
     b->heavy_deg = gm_heavy_deg_for(b->rows, b->edges);
     const int cap = (int)(b->edges / b->heavy_deg + 1);
-    int32_t* d_cnt = nullptr;
-    GM_TRY(gm_alloc(&d_cnt, 2, s));
-    GM_HIP(hipMemsetAsync(d_cnt, 0, 8, s));
+    // scratch of the round trip in ONE allocation, ONE memset, ONE download (eight copies before):
+    // ints [0,4) fused-launch counts (2 x u64) | [4,6) hub-row counts | [8, 8 + n_c) centre in-degrees | n_c local centre ids | 2 x first (row, degree) pairs of the hub lists
+    const int nc = b->centres; b->n_c = b->subs * nc;
+    const int first = std::min(cap, GM_HEAVY_FIRST);
+    const size_t o_cdeg = 8, o_centre = o_cdeg + b->n_c, o_first = (o_centre + b->n_c + 1) / 2 * 2, scr_ints = o_first + 4 * (size_t)first;
+    char* scratch = nullptr;
+    GM_TRY(gm_dev_alloc((void**)&scratch, 4 * scr_ints, s));
+    fc.scratch = scratch; fc.s = s;
+    GM_HIP(hipMemsetAsync(scratch, 0, 32, s));
+    unsigned long long* d_counts = (unsigned long long*)scratch;
+    int32_t* d_cnt = (int32_t*)scratch + 4;
+    int32_t* d_cdeg = (int32_t*)scratch + o_cdeg;
+    int2* d_first[2] = {(int2*)((int32_t*)scratch + o_first), (int2*)((int32_t*)scratch + o_first) + first};
     for (int o = 0; o < 2; ++o) GM_TRY(gm_balloc(b, &b->d_heavy[o], 2 * (size_t)cap, s));
     const int edge_tables = gm_knob().agg_edge_tables;
     if (b->edges > 0 && edge_tables) {
@@ -856,45 +893,33 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
         hipLaunchKernelGGL(k_edge_tables, dim3((int)std::min<int64_t>(4096, (b->edges + 255) / 256)), dim3(256), 0, s, b->d_indices, b->d_indices_t, (int64_t)b->edges,
                            b->d_norm, b->d_feat_row, b->d_enorm[0], b->d_enorm[1], b->d_efeat);
     }
-    unsigned long long* d_counts = nullptr;
     GM_TRY(gm_balloc(b, &b->d_norm_c, b->rows, s));
     if (b->rows > 0) {
         int4 *f0 = nullptr, *ff = nullptr;
         GM_TRY(gm_balloc(b, &f0, (size_t)b->rows, s)); GM_TRY(gm_balloc(b, &ff, (size_t)b->rows, s));
         b->d_fuse2 = f0; b->d_fuse2_feat = ff;
-        GM_TRY(gm_alloc(&d_counts, 2, s));
-        GM_HIP(hipMemsetAsync(d_counts, 0, 16, s));
         hipLaunchKernelGGL(k_row_tables, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, (int64_t)b->rows,
-                           b->d_norm, b->d_feat_row, f0, ff, d_counts, b->d_heavy[0], b->d_heavy[1], d_cnt, cap, b->heavy_deg, b->d_norm_c);
+                           b->d_norm, b->d_feat_row, f0, ff, d_counts, b->d_heavy[0], b->d_heavy[1], d_cnt, cap, b->heavy_deg, b->d_norm_c, d_first[0], d_first[1], first);
     }
-    const int nc = b->centres; b->n_c = b->subs * nc;
-    int32_t* d_cdeg = nullptr;
-    GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s)); GM_TRY(gm_alloc(&d_cdeg, b->n_c, s));
+    GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s));
     hipLaunchKernelGGL(k_centre_rows, dim3((b->n_c + 255) / 256), dim3(256), 0, s, b->d_sub_off, b->d_centre, nc, b->n_c, b->d_indptr, b->d_norm,
-                       b->d_crow, b->d_cnorm, d_cdeg, b->d_norm_c);
+                       b->d_crow, b->d_cnorm, d_cdeg, b->d_norm_c, (int32_t*)scratch + o_centre);
     GM_HIP(hipGetLastError());
     // ---- the one round trip
-    const int first = std::min(cap, GM_HEAVY_FIRST);
-    const int32_t* h_cnt = sg.download(d_cnt, 2);
-    const int32_t* h_heavy[2] = {nullptr, nullptr}; const int32_t* h_hdeg[2] = {nullptr, nullptr};
-    for (int o = 0; o < 2; ++o) { h_heavy[o] = sg.download(b->d_heavy[o], (size_t)first); h_hdeg[o] = sg.download(b->d_heavy[o] + cap, (size_t)first); }
-    const unsigned long long* h_counts = d_counts ? sg.download(d_counts, 2) : nullptr;
-    const int32_t* h_cdeg = sg.download(d_cdeg, (size_t)b->n_c);
-    fc.h_centre = sg.download(b->d_centre, (size_t)b->n_c);          // (the host side of a build reads it right after: Subgraphs._build)
-    GM_REQUIRE(h_cnt && h_heavy[0] && h_heavy[1] && h_hdeg[0] && h_hdeg[1] && h_cdeg && fc.h_centre && (h_counts || !d_counts), GM_ENOMEM, "finalize: pinned staging failed");
+    const int32_t* h_scr = sg.download((const int32_t*)scratch, scr_ints);
+    GM_REQUIRE(h_scr, GM_ENOMEM, "finalize: pinned staging failed");
     tm.lap("launches");
-    fc.cap = cap; fc.first = first; fc.d_cnt = d_cnt; fc.d_counts = d_counts; fc.d_cdeg = d_cdeg;
-    fc.h_cnt = h_cnt; fc.h_counts = h_counts; fc.h_cdeg = h_cdeg;
-    for (int o = 0; o < 2; ++o) { fc.h_heavy[o] = h_heavy[o]; fc.h_hdeg[o] = h_hdeg[o]; }
+    fc.cap = cap; fc.first = first;
+    fc.h_cnt = h_scr + 4; fc.h_counts = (const unsigned long long*)h_scr; fc.h_cdeg = h_scr + o_cdeg; fc.h_centre = h_scr + o_centre;
+    fc.h_first[0] = h_scr + o_first; fc.h_first[1] = h_scr + o_first + 2 * (size_t)first;
     return GM_OK;
 }
 static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCtx& fc) {      // (the stream has passed finalize_launch's downloads)
     gm_phase_timer tm("finalize-finish");
     const int cap = fc.cap, first = fc.first, nc = b->centres;
-    int32_t* d_cnt = fc.d_cnt; unsigned long long* d_counts = fc.d_counts; int32_t* d_cdeg = fc.d_cdeg;
+
     const int32_t* h_cnt = fc.h_cnt; const unsigned long long* h_counts = fc.h_counts; const int32_t* h_cdeg = fc.h_cdeg;
-    const int32_t* h_heavy[2] = {fc.h_heavy[0], fc.h_heavy[1]}; const int32_t* h_hdeg[2] = {fc.h_hdeg[0], fc.h_hdeg[1]};
-    gm_dev_free(d_cnt, s); gm_dev_free(d_counts, s); gm_dev_free(d_cdeg, s);
+    gm_dev_free(fc.scratch, s); fc.scratch = nullptr;
     if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
     b->h_centre.assign(fc.h_centre, fc.h_centre + b->n_c);
     b->sched_win = gm_agg_window(b->rows, b->edges);
@@ -904,7 +929,7 @@ static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
         if (b->n_heavy[o] > 0) {         // deterministic order (atomic append order is not)
             const size_t nh = b->n_heavy[o];
             std::vector<int32_t> h(nh), hd(nh);
-            if ((int)nh <= first) { std::copy(h_heavy[o], h_heavy[o] + nh, h.begin()); std::copy(h_hdeg[o], h_hdeg[o] + nh, hd.begin()); }
+            if ((int)nh <= first) { for (size_t k = 0; k < nh; ++k) { h[k] = fc.h_first[o][2 * k]; hd[k] = fc.h_first[o][2 * k + 1]; } }
             else {                       // more hub rows than the first fetch carried: one more round trip for this orientation
                 const int32_t* a = sg.download(b->d_heavy[o], nh); const int32_t* d = sg.download(b->d_heavy[o] + cap, nh);
                 GM_REQUIRE(a && d, GM_ENOMEM, "finalize: pinned staging failed");
@@ -978,12 +1003,7 @@ static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
         ecoff[t + 1] = (int32_t)(ec.size() / 3);
     }
     b->n_c_tiles = (int32_t)(ct.size() / 3); b->n_c_chunks = (int32_t)(cc.size() / 3); b->n_e1_chunks = (int32_t)(ec.size() / 3);
-    auto up = [&](int32_t** d, const std::vector<int32_t>& v) -> int {
-        GM_TRY(gm_balloc(b, d, v.size(), s));          // (the batch's slabs: batch_free releases nothing else)
-        return sg.upload(*d, v);
-    };
-    GM_TRY(up(&b->d_c_tiles, ct)); GM_TRY(up(&b->d_c_chunks, cc)); GM_TRY(up(&b->d_c_set_chunk_off, ccoff));
-    GM_TRY(up(&b->d_e1_chunks, ec)); GM_TRY(up(&b->d_e1_set_chunk_off, ecoff));
+    GM_TRY(upload_tables(b, sg, s, {{&b->d_c_tiles, &ct}, {&b->d_c_chunks, &cc}, {&b->d_c_set_chunk_off, &ccoff}, {&b->d_e1_chunks, &ec}, {&b->d_e1_set_chunk_off, &ecoff}}));
     gm_dev_free(d_eoff, s);
     return GM_OK;
 }

@@ -4,6 +4,7 @@
 #include "gm_bound.h"
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -75,7 +76,7 @@ struct gm_cone_level {
 struct gm_cone {
     int L = 0; bool ok = false; int heavy_deg = 64;
     gm_cone_level lv[GM_MAX_GCN + 1];
-    void* slab = nullptr;           // every device array of the levels is carved from this one allocation (sized from upper bounds: cone.hip)
+    void* slab = nullptr;           // every device array of the levels is carved from this one region of the BATCH's slabs (sized from upper bounds: cone.hip); released with the batch
 };
 struct gm_batch;
 int gm_batch_cone(const gm_batch* b, int L, hipStream_t s, const gm_cone** out);   // built on first use, cached in the batch
@@ -174,6 +175,7 @@ struct gm_batch {
     // meta-batch builds and drops two batches per step (3 ms of frees in Subgraphs.get_batch before this)
     struct slab { char* base; size_t cap, used; };
     std::vector<slab> slabs;
+    std::mutex slab_mu;
     mutable hipEvent_t used_ev = nullptr;   // last consumer on ANOTHER stream: the frees wait for it (gm_batch_mark_use)
 };
 struct gm_stager;
@@ -238,6 +240,9 @@ struct gm_phase_timer {
 // ---- device allocation helpers (stream-ordered pool so that per-batch builds do not sync the device)
 int gm_dev_alloc(void** p, size_t bytes, hipStream_t s);
 void gm_dev_free(void* p, hipStream_t s);
+// big, batch-lived blocks: a process-level cache in front of the stream-ordered pool (common.hip: why); *cap >= need
+int gm_slab_acquire(char** base, size_t* cap, size_t need, hipStream_t s);
+void gm_slab_release(char* base, size_t cap, hipStream_t s);
 template <class T>
 static inline int gm_alloc(T** p, size_t n, hipStream_t s) { return gm_dev_alloc((void**)p, (n ? n : 1) * sizeof(T), s); }
 

@@ -515,15 +515,20 @@ class Subgraphs(Dataset):
             ev.record(stream)
         return b, ev
 
-    def _extract_tasks(self, indices, arrs=None):
+    @staticmethod
+    def _pack_seeds(arrs):
+        """Seed tables and set offsets of the support / query batch of a meta-batch (the arguments of gm_extract / gm_extract_pair)."""
+        off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
+        return np.concatenate([a[0] for a in arrs]), off_s, np.concatenate([a[1] for a in arrs]), off_q
+
+    def _extract_tasks(self, indices, arrs=None, packed=None):
         if arrs is None:
             arrs = [self._task_arrays(i) for i in indices]
         if self.sample_mode == 'reference':
             names = [self._task_names(i) for i in indices]
             S, Q = self._extract_reference([(a[0], n[0], a[1], n[1]) for a, n in zip(arrs, names)])
             return arrs, S, Q
-        off_s = np.cumsum([0] + [len(a[0]) for a in arrs]); off_q = np.cumsum([0] + [len(a[1]) for a in arrs])
-        seeds_s = np.concatenate([a[0] for a in arrs]); seeds_q = np.concatenate([a[1] for a in arrs])
+        seeds_s, off_s, seeds_q, off_q = packed if packed is not None else self._pack_seeds(arrs)
         # default: ONE build for both batches (gm_extract_pair: one launch of each extraction kernel over all subgraphs, one round trip for both finalisations);
         # GMETA_EXTRACT_MODE=threads: two gm_extract calls, the support batch on a helper thread / stream; =serial: one after the other
         mode = os.environ.get('GMETA_EXTRACT_MODE', 'pair')
@@ -569,12 +574,15 @@ class Subgraphs(Dataset):
                 ys, yq = self._labels_lists(a[2], a[3])
                 sy.append(ys); qy.append(yq)
             sy, qy = torch.tensor(sy, dtype=torch.int64), torch.tensor(qy, dtype=torch.int64)
-            return list(indices), arrs, list(zip(sy.unbind(0), qy.unbind(0)))
-        return list(indices), arrs, [self._labels(a[2], a[3]) for a in arrs]
+            labels = list(zip(sy.unbind(0), qy.unbind(0)))
+        else:
+            labels = [self._labels(a[2], a[3]) for a in arrs]
+        # (the packed seed tables too: a builder thread of batches() then goes from its job's first line straight into the library)
+        return list(indices), arrs, labels, None if self.sample_mode == 'reference' else self._pack_seeds(arrs)
 
     def _build(self, prep):
-        indices, arrs, labels = prep
-        arrs, S, Q = self._extract_tasks(indices, arrs)
+        indices, arrs, labels, packed = prep
+        arrs, S, Q = self._extract_tasks(indices, arrs, packed)
         # the ten slots of every task (what _tuple builds one view at a time), from ONE read of each batch's centre table and host-side slices
         cols = [S.views(), [y[0] for y in labels], Q.views(), [y[1] for y in labels], None, None, None, None, None, None]
         for b, k in ((S, 0), (Q, 1)):
@@ -608,14 +616,43 @@ class Subgraphs(Dataset):
     def _batches_pool(self, index_lists, depth, cone_layers, priority, workers):
         """Three stages, meta-batches delivered in order: ONE thread runs the host halves (_prepare: task arrays, the label shuffles -- every draw of
         the global Python RNG, in meta-batch order, whichever builder takes the batch), `workers` builder threads (own streams) run the GPU builds
-        (_build + the receptive-field tables), the caller consumes.  (Round 6: _prepare ran on the builder's thread when workers == 1 -- 0.3 ms of the
-        3.4 ms a builder needs per 32-task arxiv meta-batch with tables, the stage the receptive-field schedule waits for.)"""
+        (_build + the receptive-field tables), the caller consumes.
+        Who starts what matters more than how long it takes (tools/e2e_timeline.py, receptive-field schedule at task_num 32: a 2.2 ms meta-step):
+        the interpreter lock is handed over only when its holder blocks, so a host half started by the CALLER's next() ran its 0.4 ms of pure Python
+        exactly while the caller wanted to get to its meta-step and the builder to its build -- both waited for all of it.  (A builder that is faster
+        than the caller idles until the caller's next() queues a job: it is in step with the caller, and so is whatever it starts at the top of a job.)
+        Here a host half is started by a BUILDER when its batches exist and it goes back into the library for the tables / the final wait -- the
+        caller is inside its meta-step then -- `depth` + 1 meta-batches ahead of the build it feeds; the caller's next() only queues closures."""
         dev = torch.cuda.current_device()
         tls = threading.local()
+        n = len(index_lists)
+        slots = [[threading.Event(), None] for _ in range(n)]        # host half k: done flag, result / exception
+        go = threading.Semaphore(depth + 1)                           # host halves allowed to start
+        stop = threading.Event()
 
-        def job(prep_f):
-            prep = prep_f.result()
+        trash = collections.deque()              # delivered meta-batches the caller has let go of: taken apart HERE, not in the caller's loop
+
+        def host():
+            for k, idx in enumerate(index_lists):
+                go.acquire()
+                if stop.is_set():
+                    break
+                while trash:
+                    trash.popleft()
+                try:
+                    slots[k][1] = ('ok', self._prepare(idx) if idx else ([], [], [], None))
+                except BaseException as e:      # surfaces in the builder that takes this meta-batch, then in the caller
+                    slots[k][1] = ('err', e)
+                slots[k][0].set()
+
+        def job(k):
+            slots[k][0].wait()
+            kind, prep = slots[k][1]
+            slots[k][1] = None
+            if kind == 'err':
+                raise prep
             if not prep[0]:
+                go.release()
                 return tuple([] for _ in range(10))
             side = getattr(tls, 'side', None)
             if side is None:
@@ -623,26 +660,24 @@ class Subgraphs(Dataset):
                 side = tls.side = torch.cuda.Stream(priority=self._PREFETCH_PRIORITY if priority is None else int(priority))
             with torch.cuda.stream(side):
                 b = self._build(prep)
+                go.release()                 # the next host half starts while this thread is inside the library again (tables / the wait below)
                 if cone_layers:
-                    tables(b)
+                    roots = [x.view_of if x.view_of is not None else x for x in (b[0][0], b[2][0])]
+                    _lib.check(_lib.lib().gm_batch_prepare_cone_pair(roots[0].handle, roots[1].handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone_pair')
                 side.synchronize()
             return b
 
-        def tables(b):
-            roots = [x.view_of if x.view_of is not None else x for x in (b[0][0], b[2][0])]
-            _lib.check(_lib.lib().gm_batch_prepare_cone_pair(roots[0].handle, roots[1].handle, int(cone_layers), _lib.stream_ptr()), 'gm_batch_prepare_cone_pair')
-
-        host = concurrent.futures.ThreadPoolExecutor(max_workers=1, thread_name_prefix='gmeta-prepare')
+        th = threading.Thread(target=host, name='gmeta-prepare', daemon=True)
+        th.start()
         pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix='gmeta-batches')
         pending = collections.deque()
-        it = iter(index_lists)
+        held = collections.deque()
+        nxt = [0]
 
         def top_up():
-            while len(pending) < depth:
-                idx = next(it, None)
-                if idx is None:
-                    return
-                pending.append(pool.submit(job, host.submit(self._prepare, idx) if idx else host.submit(lambda: ([], [], []))))
+            while len(pending) < depth and nxt[0] < n:
+                pending.append(pool.submit(job, nxt[0]))
+                nxt[0] += 1
         try:
             while True:
                 top_up()
@@ -650,12 +685,25 @@ class Subgraphs(Dataset):
                     break
                 f = pending.popleft()
                 top_up()                    # `depth` builds queued or running while the caller works on this one
-                yield f.result()
+                r = f.result()
+                # The last reference to a meta-batch decides which thread takes it apart (64 views, two batches, their tables: 0.2 ms of library
+                # calls and object teardown at task_num 32).  The caller drops its reference to batch k when it takes batch k + 1; this generator
+                # keeps one until the caller asks for batch k + 2 and then leaves it to the host thread (which runs while the caller is inside its
+                # meta-step) -- one more meta-batch alive in HBM.
+                held.append(r)
+                if len(held) > 2:
+                    trash.append(held.popleft())
+                del r, f
+                yield held[-1]
         finally:
+            held.clear(); trash.clear()
+            stop.set()
             for f in pending:
                 f.cancel()
-            host.shutdown(wait=True, cancel_futures=True)
+            for _ in range(n + 1):
+                go.release()
             pool.shutdown(wait=True)
+            th.join()
 
     def __len__(self):
         return self.batchsz

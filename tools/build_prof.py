@@ -55,6 +55,9 @@ if os.environ.get('PHASES'):
             t = time.perf_counter()
             _lib.check(_lib.lib().gm_batch_prepare_cone_pair(b[0][0].view_of.handle, b[2][0].view_of.handle, L, _lib.stream_ptr()), 'cone'); tick('cone tables, both batches (gm_batch_prepare_cone_pair)', t)
         t = time.perf_counter(); torch.cuda.synchronize(); tick('final sync', t)
+        roots = [b[0][0].view_of, b[2][0].view_of]
+        t = time.perf_counter(); del b; tick('drop the 10-tuple (views, lists, tensors)', t)
+        t = time.perf_counter(); del roots; tick('gm_batch_destroy x 2', t)
     for k, v in acc.items():
         print('  %-48s %.3f ms' % (k, v / n * 1e3))
     print('  total %.3f ms' % (sum(acc.values()) / n * 1e3))

@@ -28,7 +28,15 @@ def timed(name, fn):
                 acc[name] += dt; cnt[name] += 1
     return w
 db._prepare = timed('prepare', db._prepare)
-db._build = timed('build', db._build)
+_b0 = timed('build', db._build)
+marks = {'end': None}
+def _build_marked(prep, **kw):
+    t = time.perf_counter()
+    if marks['end'] is not None:
+        with lock:
+            acc['builder: gap between the end of one job and the start of the next build'] += t - marks['end']; cnt['builder: gap between the end of one job and the start of the next build'] += 1
+    return _b0(prep, **kw)
+db._build = _build_marked
 lib = _lib.lib()
 real_cone = lib.gm_batch_prepare_cone
 class LibProxy:
@@ -39,7 +47,12 @@ proxy.gm_batch_prepare_cone_pair = timed('cone (both batches)', lib.gm_batch_pre
 _lib_lib = _lib.lib
 _lib.lib = lambda: proxy
 real_sync = torch.cuda.Stream.synchronize
-torch.cuda.Stream.synchronize = timed('stream sync', real_sync)
+_s0 = timed('stream sync', real_sync)
+def _sync_marked(self):
+    r = _s0(self)
+    marks['end'] = time.perf_counter()
+    return r
+torch.cuda.Stream.synchronize = _sync_marked
 idx = [list(range(k * T, (k + 1) * T)) for k in range(NB)]
 n_e = int(os.environ.get('STEPS', '100'))
 for wk in [int(x) for x in sys.argv[1:]] or [1, 2]:
