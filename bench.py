@@ -637,10 +637,10 @@ def main():
             if kw.get('cone') and a.roofline_steps > 0:
                 extra[name].update(schedule_roofline(lib, maml, step, drain, a.roofline_steps, ms_e))
             if name == 'cone+hoist_z1' and a.e2e_steps > 0:
-                # the same schedule with a FRESH extraction (+ receptive-field tables) per step: one batch build takes longer than this meta-step, so
-                # two builder threads feed it (Subgraphs.batches(workers=2): what train.py does from --num_workers 2 upwards)
+                # the same schedule with a FRESH extraction (+ receptive-field tables) per step, built while the previous meta-steps run
+                # (Subgraphs.batches): one host thread for the host halves, N builder threads (best of 1 / 2 / 4 reported; train.py --num_workers)
                 base_l = [list(range((a.n_batches + k) * T, (a.n_batches + k + 1) * T)) for k in range(a.e2e_steps + 2)]
-                n_e = max(2 * a.e2e_steps, 20)
+                n_e = max(2 * a.e2e_steps, 60)
                 by_wk = {}
                 for wk in (1, 2, 4):
                     it = iter(db.batches([base_l[k % len(base_l)] for k in range(n_e + wk + 2)], prefetch=wk + 1, cone_layers=cfg['h'], workers=wk))
@@ -657,8 +657,8 @@ def main():
                 extra[name]['end_to_end'] = dict(by_wk[best], by_builder_threads={str(k): v['ms_per_step'] for k, v in by_wk.items()},
                                                  what='Subgraphs.batches(prefetch=workers+1, workers=N): extraction + sampling + induced batches + receptive-field tables of '
                                                       'every meta-batch built on the GPU by N builder threads (own streams) while the previous meta-steps run; Meta.forward per '
-                                                      'step.  One build is a chain of small kernels and host round trips -- longer than this meta-step -- so several are kept in flight '
-                                                      '(train.py --num_workers; the reference uses DataLoader workers the same way, train.py:96,173)')
+                                                      'step.  Round 6: one builder keeps up with this 2.2 ms meta-step (a build is ~2.3 ms of host wall; dropped batches go to a slab '
+                                                      'cache instead of hipFreeAsync, which cost 0.7-1.7 ms per meta-batch in the training thread); more builders contend for the GPU')
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
         if lib.gm_get_gemm_mode() == 1:      # the same dense schedule with every GEMM on the exact-fp32 MFMA kernels (include/gmeta_hip.h, gm_set_gemm_mode)
             lib.gm_set_gemm_mode(0)

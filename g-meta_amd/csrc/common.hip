@@ -67,7 +67,14 @@ int gm_dev_alloc(void** p, size_t bytes, hipStream_t s) {
 
 void gm_dev_free(void* p, hipStream_t s) {
     if (!p) return;
-    if (hipFreeAsync(p, s) != hipSuccess) {
+    const bool timing = gm_knob().timing != 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipFreeAsync(p, s);
+    if (timing) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us > 50.0) fprintf(stderr, "[gm timing] hipFreeAsync %.1f us\n", us);
+    }
+    if (e != hipSuccess) {
         if (gm_knob().timing) fprintf(stderr, "[gm timing] hipFreeAsync failed -- hipFree\n");
         (void)hipGetLastError();
         (void)hipFree(p);
