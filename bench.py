@@ -622,8 +622,11 @@ def main():
     # loop-invariant recomputation (never the headline `value`)
     extra = {}
     if world == 1 and a.extra_steps > 0 and not (a.sparse_bwd or a.hoist_z1 or a.serialize or a.cone):
+        _skip = set(os.environ.get('GMETA_BENCH_SKIP', '').split(','))
         for name, kw in (('sparse_bwd', dict(sparse_bwd=1)), ('sparse_bwd+hoist_z1', dict(sparse_bwd=1, hoist_z1=1)),
                          ('cone', dict(sparse_bwd=0, hoist_z1=0, cone=1)), ('cone+hoist_z1', dict(cone=1, hoist_z1=1))):
+            if 'flagged' in _skip:
+                break
             for k_, v_ in kw.items():
                 setattr(maml, k_, v_)
             step(0); drain()
@@ -642,9 +645,9 @@ def main():
                 base_l = [list(range((a.n_batches + k) * T, (a.n_batches + k + 1) * T)) for k in range(a.e2e_steps + 2)]
                 n_e = max(2 * a.e2e_steps, 60)
                 by_wk = {}
-                for wk in (1, 2, 4):
-                    it = iter(db.batches([base_l[k % len(base_l)] for k in range(n_e + wk + 2)], prefetch=wk + 1, cone_layers=cfg['h'], workers=wk))
-                    for _ in range(wk + 2):
+                for wk in tuple(int(x) for x in os.environ.get('GMETA_BENCH_BUILDERS', '1,2,4').split(',')):
+                    it = iter(db.batches([base_l[k % len(base_l)] for k in range(n_e + len(base_l))], prefetch=wk + 1, cone_layers=cfg['h'], workers=wk))
+                    for _ in range(len(base_l)):          # one pass over the distinct meta-batches first (their per-task host tables are memoised from then on)
                         maml(*next(it), data['feats'])
                     torch.cuda.synchronize(); te = time.perf_counter()
                     for _ in range(n_e):
@@ -660,7 +663,7 @@ def main():
                                                       'step.  Round 6: one builder keeps up with this 2.2 ms meta-step (a build is ~2.3 ms of host wall; dropped batches go to a slab '
                                                       'cache instead of hipFreeAsync, which cost 0.7-1.7 ms per meta-batch in the training thread); more builders contend for the GPU')
         maml.sparse_bwd = 0; maml.hoist_z1 = 0; maml.cone = 0
-        if lib.gm_get_gemm_mode() == 1:      # the same dense schedule with every GEMM on the exact-fp32 MFMA kernels (include/gmeta_hip.h, gm_set_gemm_mode)
+        if lib.gm_get_gemm_mode() == 1 and 'exact' not in _skip:      # the same dense schedule with every GEMM on the exact-fp32 MFMA kernels (include/gmeta_hip.h, gm_set_gemm_mode)
             lib.gm_set_gemm_mode(0)
             step(0); drain()
             torch.cuda.synchronize(); te = time.perf_counter()
@@ -686,7 +689,7 @@ def main():
                                                   'what': 'default schedule with GM_SPLIT_PIECES=2 (opt-in): the split launches inside gm_meta_step take two fp16 pieces per operand, '
                                                           'three products -- operands NARROWER than the reference\'s fp32 (learner.py:36,47), reported for context only'}
                 lib.gm_set_split_pieces(-1)
-        if lib.gm_get_gemm_mode() == 1:
+        if lib.gm_get_gemm_mode() == 1 and 'store' not in _skip:
             # the same schedule with the forward-only evaluations storing EVERY row of the last layer's activation (only the centre rows are ever read)
             _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', 0), 'set_tuning')
             step(0); drain()
@@ -700,7 +703,7 @@ def main():
                                         'what': 'default schedule with GM_CENTRE_STORE=0: the last GraphConv also stores the rows of its activation that nobody reads '
                                                 '(bitwise the same step; the default computes every row and stores the centre rows the head gathers, learner.py h[to_fetch])'}
             _lib.check(lib.gm_set_tuning(b'GM_CENTRE_STORE', 2), 'set_tuning')
-        if lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1:
+        if lib.gm_get_fuse_agg() == 1 and lib.gm_get_gemm_mode() == 1 and 'unfused' not in _skip:
             # the same schedule with every pass writing Z (fused aggregate + GEMM off): step time, and the aggregate's roofline over an
             # all-full-launch sample -- the figure of the earlier rounds (the large query launches are aggregate launches again)
             lib.gm_set_fuse_agg(0)
@@ -755,18 +758,34 @@ def main():
     # ---- end to end ("report also with extraction included"): every step extracts its own meta-batch
     e2e = None
     if world == 1 and a.e2e_steps > 0:
+        # e2e_steps + 2 distinct meta-batches, walked n_e times in a row like the epochs of train.py (the task tables are fixed at construction,
+        # sdp.py:150-292; their per-task host arrays are memoised after the first visit, as the reference memoises its subgraphs)
         lists = [list(range((a.n_batches + k) * T, (a.n_batches + k + 1) * T)) for k in range(a.e2e_steps + 2)]
-        it = iter(db.batches(lists, prefetch=1, cone_layers=cfg['h'] if a.cone else 0))
-        for _ in range(2):
+        n_e = max(3 * a.e2e_steps, 30)
+        if os.environ.get('GMETA_BENCH_GC_FREEZE'):
+            import gc
+            gc.collect(); gc.freeze()
+        it = iter(db.batches([lists[k % len(lists)] for k in range(len(lists) + n_e)], prefetch=1, cone_layers=cfg['h'] if a.cone else 0))
+        for _ in range(len(lists)):
             maml(*next(it), data['feats'])
         torch.cuda.synchronize(); te = time.perf_counter()
-        for _ in range(a.e2e_steps):
+        for _ in range(n_e):
             maml(*next(it), data['feats'])
         torch.cuda.synchronize()
-        ms_e = (time.perf_counter() - te) / a.e2e_steps * 1e3
-        e2e = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1), 'steps': a.e2e_steps,
-               'what': 'Subgraphs.get_batch (h-hop extraction + sampling + induced batch on the GPU, prefetched one step ahead on a second '
-                       'thread/stream) + Meta.forward per step; same schedule as `value`'}
+        ms_e = (time.perf_counter() - te) / n_e * 1e3
+        del it
+        # the pre-extracted step again, right here: by now the chip has run several seconds of phases back to back (the timed region started on a
+        # cooler one; profiles/r03_gemm_hot_vs_cool.txt), so the cost of building beside the step is ms_per_step - this, not ms_per_step - `ms_per_step` of the line
+        step(0); drain()
+        torch.cuda.synchronize(); te = time.perf_counter()
+        for k in range(n_e):
+            step(k)
+        drain(); torch.cuda.synchronize()
+        ms_same = (time.perf_counter() - te) / n_e * 1e3
+        e2e = {'ms_per_step': round(ms_e, 3), 'meta_tasks_per_s': round(T / (ms_e * 1e-3), 1), 'steps': n_e, 'pre_extracted_ms_per_step_measured_right_after': round(ms_same, 3),
+               'what': 'Subgraphs.batches (h-hop extraction + sampling + induced batches of every meta-batch built on the GPU one step ahead, on a builder '
+                       'thread / stream of its own) + Meta.forward per step; same schedule as `value`; the meta-batches of the second and later epochs '
+                       '(per-task host tables memoised)'}
     # ---- extraction kernels against the HBM roofline (SURVEY 8(d) "k-hop expansion, induce: HBM bandwidth"): one more extraction of the first
     # meta-batch with HIP events around k_nodes / k_fill / the finalisation (gm_profile_read categories 8-10), bytes from the actual batch
     extraction = None

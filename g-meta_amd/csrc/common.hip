@@ -257,6 +257,8 @@ static thread_local ProfCat g_prof[GM_PROF_CATS];
 extern "C" void gm_profile_enable(int32_t on) {
     g_prof_on = on;
     gm_prof_reset();
+    if (!on)        // the timing events go with the measurement (hundreds per profiled meta-step)
+        for (int k = 0; k < GM_PROF_CATS; ++k) { for (hipEvent_t e : g_prof[k].ev) (void)hipEventDestroy(e); g_prof[k].ev.clear(); }
 }
 void gm_prof_reset(int n_cats) { for (int k = 0; k < n_cats && k < GM_PROF_CATS; ++k) { ProfCat& c = g_prof[k]; c.used = 0; c.work = 0; c.launches = 0; c.open = false; } }
 

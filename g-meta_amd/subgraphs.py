@@ -596,8 +596,27 @@ class Subgraphs(Dataset):
             cols[8 + k] = [gid[off[t]:off[t + 1]] for t in range(b.sets)]
         return tuple(cols)
 
-    # stream priority of the builder threads (GMETA_BUILD_PRIORITY; torch convention: lower = more urgent).  A high-priority stream measured no better in round 4
+    # The builder threads' streams are created ONCE per (device, builder slot, priority) and kept for the life of the process.  HIP deals streams of one
+    # priority round-robin onto a small set of hardware queues (GPU_MAX_HW_QUEUES, 4), so which queue a NEW stream gets depends on how many streams the
+    # process has created before; every batches() call starts new threads, and a stream per call meant that sooner or later a builder landed on the
+    # hardware queue of the meta-step's own stream and its build serialised with the step (bench.py after its builder-pool phases, a training run in
+    # its later epochs: 4.77 instead of 4.13 ms per 4-task meta-step with a build per step).  Builder slot 0 is the third stream of a typical process
+    # (after the caller's and the meta-step's query stream): a queue of its own.  GMETA_BUILD_PRIORITY (torch convention: lower = more urgent; default
+    # 0): -1 also gives the builders queues of their own, but their wide kernels then run ahead of a short meta-step's small ones (receptive-field
+    # schedule, build per step: 2.90 instead of 2.6-2.7 ms).
     _PREFETCH_PRIORITY = int(os.environ.get('GMETA_BUILD_PRIORITY', '0'))
+    _builder_streams = {}
+    _builder_streams_lock = threading.Lock()
+
+    @classmethod
+    def _builder_stream(cls, dev, slot, priority):
+        key = (int(dev), int(slot), int(priority))
+        with cls._builder_streams_lock:
+            st = cls._builder_streams.get(key)
+            if st is None:
+                torch.cuda.set_device(dev)
+                st = cls._builder_streams[key] = torch.cuda.Stream(device=dev, priority=int(priority))
+            return st
 
     def batches(self, index_lists, prefetch=1, cone_layers=0, priority=None, workers=1):
         """Iterate get_batch(idx) for idx in index_lists with the NEXT `prefetch` meta-batches being prepared (host half: one thread) and
@@ -630,15 +649,11 @@ class Subgraphs(Dataset):
         go = threading.Semaphore(depth + 1)                           # host halves allowed to start
         stop = threading.Event()
 
-        trash = collections.deque()              # delivered meta-batches the caller has let go of: taken apart HERE, not in the caller's loop
-
         def host():
             for k, idx in enumerate(index_lists):
                 go.acquire()
                 if stop.is_set():
                     break
-                while trash:
-                    trash.popleft()
                 try:
                     slots[k][1] = ('ok', self._prepare(idx) if idx else ([], [], [], None))
                 except BaseException as e:      # surfaces in the builder that takes this meta-batch, then in the caller
@@ -657,7 +672,9 @@ class Subgraphs(Dataset):
             side = getattr(tls, 'side', None)
             if side is None:
                 torch.cuda.set_device(dev)
-                side = tls.side = torch.cuda.Stream(priority=self._PREFETCH_PRIORITY if priority is None else int(priority))
+                with slot_lock:
+                    slot = slot_next[0]; slot_next[0] += 1
+                side = tls.side = self._builder_stream(dev, slot, self._PREFETCH_PRIORITY if priority is None else int(priority))
             with torch.cuda.stream(side):
                 b = self._build(prep)
                 go.release()                 # the next host half starts while this thread is inside the library again (tables / the wait below)
@@ -671,8 +688,8 @@ class Subgraphs(Dataset):
         th.start()
         pool = concurrent.futures.ThreadPoolExecutor(max_workers=workers, thread_name_prefix='gmeta-batches')
         pending = collections.deque()
-        held = collections.deque()
         nxt = [0]
+        slot_next, slot_lock = [0], threading.Lock()
 
         def top_up():
             while len(pending) < depth and nxt[0] < n:
@@ -685,18 +702,8 @@ class Subgraphs(Dataset):
                     break
                 f = pending.popleft()
                 top_up()                    # `depth` builds queued or running while the caller works on this one
-                r = f.result()
-                # The last reference to a meta-batch decides which thread takes it apart (64 views, two batches, their tables: 0.2 ms of library
-                # calls and object teardown at task_num 32).  The caller drops its reference to batch k when it takes batch k + 1; this generator
-                # keeps one until the caller asks for batch k + 2 and then leaves it to the host thread (which runs while the caller is inside its
-                # meta-step) -- one more meta-batch alive in HBM.
-                held.append(r)
-                if len(held) > 2:
-                    trash.append(held.popleft())
-                del r, f
-                yield held[-1]
+                yield f.result()
         finally:
-            held.clear(); trash.clear()
             stop.set()
             for f in pending:
                 f.cancel()

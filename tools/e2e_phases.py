@@ -6,13 +6,15 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import gmeta_amd
 from gmeta_amd import synth, _lib
-T = 32
-args, cfg = synth.make_args('arxiv', task_num=T)
+T = int(os.environ.get('T', '32'))
+args, cfg = synth.make_args(os.environ.get('CONFIG', 'arxiv'), task_num=T)
 np.random.seed(222); random.seed(222); torch.manual_seed(222)
 data = synth.node_dataset(cfg['n'], cfg['m'], cfg['F0'], cfg['classes'])
 store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
 maml = gmeta_amd.Meta(args, synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])).to('cuda')
-maml.cone = 1; maml.hoist_z1 = 1
+FLAGS = [f for f in os.environ.get('FLAGS', 'cone,hoist_z1').split(',') if f]
+for f in FLAGS:
+    setattr(maml, f, 1)
 NB = 8
 db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=3, k_shot=3, k_query=24, batchsz=T * NB, args=args, adjs=store, h=2,
                          tables={'train': (data['names'], data['labels'])}, verbose=False)
@@ -56,7 +58,7 @@ torch.cuda.Stream.synchronize = _sync_marked
 idx = [list(range(k * T, (k + 1) * T)) for k in range(NB)]
 n_e = int(os.environ.get('STEPS', '100'))
 for wk in [int(x) for x in sys.argv[1:]] or [1, 2]:
-    it = iter(db.batches([idx[k % NB] for k in range(n_e + wk + 2)], prefetch=wk + 1, cone_layers=cfg['h'], workers=wk))
+    it = iter(db.batches([idx[k % NB] for k in range(n_e + wk + 2)], prefetch=int(os.environ.get('PREFETCH', wk + 1)), cone_layers=cfg['h'] if 'cone' in FLAGS else 0, workers=wk))
     for _ in range(wk + 2):
         maml(*next(it), data['feats'])
     torch.cuda.synchronize(); acc.clear(); cnt.clear()
