@@ -268,3 +268,52 @@ def test_sixteen_bit_prefix_words_build_the_same_batches(case):
         assert np.array_equal(x._read(8, x.subs * x.centres, np.int32), y._read(8, y.subs * y.centres, np.int32))
         for tr in (False, True):
             assert all(np.array_equal(p, q) for p, q in zip(x.csr(tr), y.csr(tr)))
+
+
+_SLAB_SCRIPT = r'''
+import hashlib, os, random, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ['GM_REPO'])
+import gmeta_amd
+from gmeta_amd import synth
+np.random.seed(222); random.seed(222); torch.manual_seed(222)
+T = 4
+args, cfg = synth.make_args('arxiv', task_num=T)
+args.update_step = 2
+data = synth.node_dataset(cfg['n'], cfg['m'], cfg['F0'], cfg['classes'])
+store = gmeta_amd.GraphStore(data['graphs'], data['feats'])
+db = gmeta_amd.Subgraphs(None, 'train', data['info'], n_way=3, k_shot=3, k_query=24, batchsz=6 * T, args=args, adjs=store, h=2,
+                         tables={'train': (data['names'], data['labels'])}, verbose=False)
+m = gmeta_amd.Meta(args, synth.make_config(cfg['F0'], cfg['hidden'], cfg['h'], cfg['n_way'])).to('cuda')
+m.cone = int(os.environ.get('SLAB_CONE', '0'))
+h = hashlib.sha256()
+lists = [list(range(k * T, (k + 1) * T)) for k in range(6)]
+for b in db.batches(lists + lists, prefetch=2, cone_layers=cfg['h'] if m.cone else 0):       # batches of different sizes come and go
+    accs = m(*b, None)
+    h.update(np.asarray(accs, np.float64).tobytes())
+    h.update(torch.cat([p.detach().reshape(-1) for p in m.net.parameters()]).cpu().numpy().tobytes())
+torch.cuda.synchronize()
+print('HASH', h.hexdigest())
+'''
+
+
+@pytest.mark.parametrize('cone', [0, 1])
+def test_slab_cache_limits_do_not_change_results(tmp_path, cone):
+    """Dropped batches go to the process-level slab cache (csrc/common.hip) instead of hipFreeAsync; a released slab is reused by a later build behind an event.
+    Twelve prefetched meta-steps give bitwise the same accuracies and weights with the cache at its default size, with a 1-MiB cache (every release evicts: the
+    hipFreeAsync path, with the evicted slab's event waited for) and with the cache off."""
+    import subprocess
+    import sys
+    script = tmp_path / 'slab.py'
+    script.write_text(_SLAB_SCRIPT)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for mb in ('default', '1', '0'):
+        env = dict(os.environ, GM_REPO=repo, SLAB_CONE=str(cone))
+        env.pop('GM_SLAB_CACHE_MB', None)
+        if mb != 'default':
+            env['GM_SLAB_CACHE_MB'] = mb
+        r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[mb] = [l for l in r.stdout.splitlines() if l.startswith('HASH')][0]
+    assert out['default'] == out['1'] == out['0'], out
