@@ -429,7 +429,7 @@ struct FillOut {
 template <bool G, bool P16 = false>
 __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* seeds, int n_seeds, int link, int cap,
                                                    const int32_t* nodes_slab, const int32_t* degi_slab, const int32_t* dego_slab,
-                                                   FillOut o0, FillOut o1, int split, int Wmax, uint32_t* gbits) {
+                                                   FillOut o0, FillOut o1, int split, int Wmax, uint32_t* gbits, const int32_t* order) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t* seen = G ? gbits + (size_t)blockIdx.x * 2 * Wmax : lds;
     static_assert(!(G && P16), "16-bit prefix words live in LDS");
@@ -437,8 +437,10 @@ __global__ __launch_bounds__(EX_BLOCK) void k_fill(ExStore S, const gm_seed_t* s
     PT* pref = reinterpret_cast<PT*>(seen + Wmax);
     int* part = (int*)(G ? lds : lds + Wmax + (P16 ? (Wmax + 1) / 2 : Wmax));
     int* sc = part + EX_BLOCK;
-    const int seed = blockIdx.x;
-    if (seed >= n_seeds) return;
+    if ((int)blockIdx.x >= n_seeds) return;
+    // workgroups start in blockIdx order: the subgraphs with the most edges first (host order, by the sizes the count pass brought), so that the last
+    // of the ~2.5 rounds a 32-task meta-batch makes over the chip's workgroup slots is made of short ones
+    const int seed = order ? order[blockIdx.x] : (int)blockIdx.x;
     const bool second = seed >= split;
     const int ls = second ? seed - split : seed, nl = second ? n_seeds - split : split;      // subgraph number inside its batch; the batch's subgraph count
     const int32_t* sub_off = second ? o1.sub_off : o0.sub_off; const int32_t* sub_eoff = second ? o1.sub_eoff : o0.sub_eoff;
@@ -1146,7 +1148,9 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int n_p
 
     tm.lap("k_nodes+sizes");
     // per batch: host prefix sums, device arrays; the edge offsets of both batches share one upload ([part 0: n0 + 1 | part 1: n1 + 1])
-    std::vector<int32_t> eoff((size_t)n_seeds + n_parts, 0);
+    std::vector<int32_t> eoff;
+    eoff.reserve(2 * (size_t)n_seeds + n_parts);          // (+ k_fill's workgroup order below: no reallocation under eoff_p)
+    eoff.assign((size_t)n_seeds + n_parts, 0);
     int32_t* eoff_p[2] = {eoff.data(), eoff.data() + split + 1};
     FillOut fo[2] = {};
     for (int p = 0, k0 = 0; p < n_parts; k0 += parts[p].n_seeds, ++p) {
@@ -1171,8 +1175,22 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int n_p
         EX_TRY(batch_alloc(b, st));
         EX_TRY(upload_small(b, sg));
     }
+    // k_fill's workgroup order rides in the same upload: subgraphs by edge count, largest first (64 linear buckets: coarse is enough, and O(n))
+    const size_t o_order = eoff.size();
+    const bool lpt = n_seeds >= 512;                      // (more subgraphs than workgroup slots in half a round: 0.156 -> 0.145 ms at the arxiv shape, profiles/r06_experiments_not_shipped.txt H)
+    if (lpt) {
+        int emax = 1;
+        for (int k = 0; k < n_seeds; ++k) emax = std::max(emax, esub[k]);
+        int cnt[65] = {0};
+        auto bucket = [&](int e) { return 63 - (int)((int64_t)e * 63 / emax); };             // 0 = largest
+        for (int k = 0; k < n_seeds; ++k) ++cnt[bucket(esub[k]) + 1];
+        for (int q = 0; q < 64; ++q) cnt[q + 1] += cnt[q];
+        eoff.resize(o_order + n_seeds);
+        for (int k = 0; k < n_seeds; ++k) eoff[o_order + cnt[bucket(esub[k])]++] = k;
+    }
     EX_TRY(gm_alloc(&d_eoff, eoff.size(), st));
     EX_TRY(sg.upload(d_eoff, eoff));
+    const int32_t* d_order = lpt ? d_eoff + o_order : nullptr;
     for (int p = 0; p < n_parts; ++p) {
         gm_batch* b = bs[p];
         fo[p] = FillOut{b->d_sub_off, d_eoff + (p ? split + 1 : 0), b->d_parent, b->d_feat_row, b->d_norm, b->d_indptr, b->d_indices, b->d_indptr_t, b->d_indices_t, b->d_centre};
@@ -1181,13 +1199,13 @@ static int extract_impl(const gm_store_t* store, const gm_seed_t* seeds, int n_p
     gm_prof_begin(GM_PROF_EX_FILL, st, n_seeds);
     if (gpath) {
         hipLaunchKernelGGL(k_fill<true>, dim3(n_seeds), dim3(EX_BLOCK), sizeof(uint32_t) * (EX_BLOCK + 16), st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap,
-                           d_nodes, d_degi, d_dego, fo[0], fo[1], (int)split, Wmax, d_gbits);
+                           d_nodes, d_degi, d_dego, fo[0], fo[1], (int)split, Wmax, d_gbits, d_order);
     } else {
         const size_t lds_b = sizeof(uint32_t) * ((size_t)Wmax + Wp + EX_BLOCK + 16);
         if (p16) hipLaunchKernelGGL((k_fill<false, true>), dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
-                                    fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr);
+                                    fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr, d_order);
         else hipLaunchKernelGGL(k_fill<false>, dim3(n_seeds), dim3(EX_BLOCK), lds_b, st, S, d_seeds, n_seeds, link ? 1 : 0, (int)cap, d_nodes, d_degi, d_dego,
-                                fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr);
+                                fo[0], fo[1], (int)split, Wmax, (uint32_t*)nullptr, d_order);
     }
     gm_prof_end(GM_PROF_EX_FILL, st);
     EX_HIP(hipGetLastError());
