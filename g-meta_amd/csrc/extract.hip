@@ -561,8 +561,22 @@ __global__ void k_row_tables(const int32_t* indptr, const int32_t* indices, cons
     for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
         const int p = indptr[r], d = indptr[r + 1] - p, dt = indptr_t[r + 1] - indptr_t[r];
         // [rows: cap][degrees: cap]; the first n_first (row, degree) pairs also go to the round trip's scratch (one download for everything the host waits for)
-        if (d > thr) { const int k = atomicAdd(hcnt, 1); if (k < cap) { heavy0[k] = (int32_t)r; heavy0[cap + k] = d; } if (k < n_first) first0[k] = make_int2((int)r, d); }
-        if (dt > thr) { const int k = atomicAdd(hcnt + 1, 1); if (k < cap) { heavy1[k] = (int32_t)r; heavy1[cap + k] = dt; } if (k < n_first) first1[k] = make_int2((int)r, dt); }
+        // (one atomic per wave and orientation: the hub rows of a wave take consecutive slots; the lists are sorted on the host anyway)
+        {
+            const unsigned long long m0 = __ballot(d > thr), m1 = __ballot(dt > thr), below = (1ull << (threadIdx.x & 63)) - 1ull;
+            if (m0) {
+                const int lead = __ffsll((long long)m0) - 1;
+                int base = ((int)(threadIdx.x & 63) == lead) ? atomicAdd(hcnt, __popcll(m0)) : 0;
+                base = __shfl(base, lead, 64);
+                if (d > thr) { const int k = base + __popcll(m0 & below); if (k < cap) { heavy0[k] = (int32_t)r; heavy0[cap + k] = d; } if (k < n_first) first0[k] = make_int2((int)r, d); }
+            }
+            if (m1) {
+                const int lead = __ffsll((long long)m1) - 1;
+                int base = ((int)(threadIdx.x & 63) == lead) ? atomicAdd(hcnt + 1, __popcll(m1)) : 0;
+                base = __shfl(base, lead, 64);
+                if (dt > thr) { const int k = base + __popcll(m1 & below); if (k < cap) { heavy1[k] = (int32_t)r; heavy1[cap + k] = dt; } if (k < n_first) first1[k] = make_int2((int)r, dt); }
+            }
+        }
         const float nrm = norm[r];
         norm_c[r] = __uint_as_float(__float_as_uint(nrm) | 0x80000000u);
         const int self = (int)r | GM_FUSE_SELF;
@@ -576,16 +590,16 @@ __global__ void k_row_tables(const int32_t* indptr, const int32_t* indices, cons
         if (d > GM_FUSE_MAXDEG) { ++nr; ne += (unsigned long long)d; }
         f2[r] = t; f2_feat[r] = tf;
     }
-    // one pair of atomics per WORKGROUP (wave shuffles, then the four wave partials through LDS): the two counters are a single contended
+    // one pair of partials per WORKGROUP (wave shuffles, then the four wave partials through LDS): as atomics the two counters are a single contended
     // address each -- per thread 92k atomics took longer than the table itself, per wave the 16k of the 1.14 M-row batch still cost ~100 us
     __shared__ unsigned long long part[2][4];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { nr += __shfl_down(nr, off, 64); ne += __shfl_down(ne, off, 64); }
     if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = nr; part[1][threadIdx.x >> 6] = ne; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long a = part[0][0] + part[0][1] + part[0][2] + part[0][3], e = part[1][0] + part[1][1] + part[1][2] + part[1][3];
-        if (a) { atomicAdd(counts, a); atomicAdd(counts + 1, e); }
+    if (threadIdx.x == 0) {         // per-workgroup partials, summed by the host after the round trip (no same-address atomics at all: 2 x 2,048 of them were a third of this kernel)
+        counts[2 * blockIdx.x] = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+        counts[2 * blockIdx.x + 1] = part[1][0] + part[1][1] + part[1][2] + part[1][3];
     }
 }
 // distinct sources of the rows with more than maxdeg in-edges: mark, then count
@@ -827,7 +841,7 @@ static void sort_rows_with_degrees(std::vector<int32_t>& row, std::vector<int32_
 // The finalisation in two halves around its host round trip, so that a caller that builds TWO batches (gm_extract_pair) queues both batches' kernels,
 // waits once, and derives both batches' host-side tables while nothing is left to wait for.
 struct FinalizeCtx {
-    int cap = 0, first = 0;
+    int cap = 0, first = 0, n_count_pairs = 0;
     char* scratch = nullptr; hipStream_t s = nullptr;            // device side of the round trip (finalize_launch); released by finalize_finish or on the way out
     const int32_t* h_cnt = nullptr; const int32_t* h_first[2] = {nullptr, nullptr};      // hub-row counts; the first (row, degree) pairs of both hub lists
     const unsigned long long* h_counts = nullptr; const int32_t* h_cdeg = nullptr; const int32_t* h_centre = nullptr;
@@ -878,15 +892,16 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
     b->heavy_deg = gm_heavy_deg_for(b->rows, b->edges);
     const int cap = (int)(b->edges / b->heavy_deg + 1);
     // scratch of the round trip in ONE allocation, ONE memset, ONE download (eight copies before):
-    // ints [0,4) fused-launch counts (2 x u64) | [4,6) hub-row counts | [8, 8 + n_c) centre in-degrees | n_c local centre ids | 2 x first (row, degree) pairs of the hub lists
+    // ints [4,6) hub-row counts | [8, 8 + n_c) centre in-degrees | n_c local centre ids | 2 x first (row, degree) pairs of the hub lists | k_row_tables' per-workgroup {rows, edges} partials (u64 pairs)
     const int nc = b->centres; b->n_c = b->subs * nc;
     const int first = std::min(cap, GM_HEAVY_FIRST);
-    const size_t o_cdeg = 8, o_centre = o_cdeg + b->n_c, o_first = (o_centre + b->n_c + 1) / 2 * 2, scr_ints = o_first + 4 * (size_t)first;
+    const int rt_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (b->rows + 255) / 256));        // k_row_tables' grid: one {rows, edges} partial pair per workgroup
+    const size_t o_cdeg = 8, o_centre = o_cdeg + b->n_c, o_first = (o_centre + b->n_c + 1) / 2 * 2, o_part = o_first + 4 * (size_t)first, scr_ints = o_part + 4 * (size_t)rt_blocks;
     char* scratch = nullptr;
     GM_TRY(gm_dev_alloc((void**)&scratch, 4 * scr_ints, s));
     fc.scratch = scratch; fc.s = s;
     GM_HIP(hipMemsetAsync(scratch, 0, 32, s));
-    unsigned long long* d_counts = (unsigned long long*)scratch;
+    unsigned long long* d_counts = (unsigned long long*)((int32_t*)scratch + o_part);
     int32_t* d_cnt = (int32_t*)scratch + 4;
     int32_t* d_cdeg = (int32_t*)scratch + o_cdeg;
     int2* d_first[2] = {(int2*)((int32_t*)scratch + o_first), (int2*)((int32_t*)scratch + o_first) + first};
@@ -902,7 +917,7 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
         int4 *f0 = nullptr, *ff = nullptr;
         GM_TRY(gm_balloc(b, &f0, (size_t)b->rows, s)); GM_TRY(gm_balloc(b, &ff, (size_t)b->rows, s));
         b->d_fuse2 = f0; b->d_fuse2_feat = ff;
-        hipLaunchKernelGGL(k_row_tables, dim3((int)std::min<int64_t>(2048, (b->rows + 255) / 256)), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, (int64_t)b->rows,
+        hipLaunchKernelGGL(k_row_tables, dim3(rt_blocks), dim3(256), 0, s, b->d_indptr, b->d_indices, b->d_indptr_t, (int64_t)b->rows,
                            b->d_norm, b->d_feat_row, f0, ff, d_counts, b->d_heavy[0], b->d_heavy[1], d_cnt, cap, b->heavy_deg, b->d_norm_c, d_first[0], d_first[1], first);
     }
     GM_TRY(gm_balloc(b, &b->d_crow, b->n_c, s)); GM_TRY(gm_balloc(b, &b->d_cnorm, b->n_c, s));
@@ -914,7 +929,7 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
     GM_REQUIRE(h_scr, GM_ENOMEM, "finalize: pinned staging failed");
     tm.lap("launches");
     fc.cap = cap; fc.first = first;
-    fc.h_cnt = h_scr + 4; fc.h_counts = (const unsigned long long*)h_scr; fc.h_cdeg = h_scr + o_cdeg; fc.h_centre = h_scr + o_centre;
+    fc.h_cnt = h_scr + 4; fc.h_counts = b->rows > 0 ? (const unsigned long long*)(h_scr + o_part) : nullptr; fc.n_count_pairs = rt_blocks; fc.h_cdeg = h_scr + o_cdeg; fc.h_centre = h_scr + o_centre;
     fc.h_first[0] = h_scr + o_first; fc.h_first[1] = h_scr + o_first + 2 * (size_t)first;
     return GM_OK;
 }
@@ -924,7 +939,11 @@ static int finalize_finish(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
 
     const int32_t* h_cnt = fc.h_cnt; const unsigned long long* h_counts = fc.h_counts; const int32_t* h_cdeg = fc.h_cdeg;
     gm_dev_free(fc.scratch, s); fc.scratch = nullptr;
-    if (h_counts) { b->unfused_rows = (int64_t)h_counts[0]; b->unfused_edges = (int64_t)h_counts[1]; }
+    if (h_counts) {
+        unsigned long long nr = 0, ne = 0;
+        for (int k = 0; k < fc.n_count_pairs; ++k) { nr += h_counts[2 * k]; ne += h_counts[2 * k + 1]; }
+        b->unfused_rows = (int64_t)nr; b->unfused_edges = (int64_t)ne;
+    }
     b->h_centre.assign(fc.h_centre, fc.h_centre + b->n_c);
     b->sched_win = gm_agg_window(b->rows, b->edges);
     std::vector<int32_t> heavy0, tab0;                       // forward orientation: sorted hub rows and their part table (for the list schedule below)
