@@ -895,7 +895,7 @@ static int finalize_launch(gm_batch* b, hipStream_t s, gm_stager& sg, FinalizeCt
     // ints [4,6) hub-row counts | [8, 8 + n_c) centre in-degrees | n_c local centre ids | 2 x first (row, degree) pairs of the hub lists | k_row_tables' per-workgroup {rows, edges} partials (u64 pairs)
     const int nc = b->centres; b->n_c = b->subs * nc;
     const int first = std::min(cap, GM_HEAVY_FIRST);
-    const int rt_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (b->rows + 255) / 256));        // (512 .. 8,192 workgroups: the same 91 us on the query batch)        // k_row_tables' grid: one {rows, edges} partial pair per workgroup
+    const int rt_blocks = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (b->rows + 255) / 256));        // k_row_tables' grid, one {rows, edges} partial pair per workgroup (512 .. 8,192 workgroups: the same 91 us on the query batch)
     const size_t o_cdeg = 8, o_centre = o_cdeg + b->n_c, o_first = (o_centre + b->n_c + 1) / 2 * 2, o_part = o_first + 4 * (size_t)first, scr_ints = o_part + 4 * (size_t)rt_blocks;
     char* scratch = nullptr;
     GM_TRY(gm_dev_alloc((void**)&scratch, 4 * scr_ints, s));
